@@ -1,0 +1,227 @@
+"""oracle/make_golden.py -- TEST INFRASTRUCTURE.  Emits tests/golden/*.npz from the reference.
+
+Run in the build container only (needs /root/reference):   python -m oracle.make_golden
+Each fixture = seeded inputs + the reference module's state_dict + the reference module's outputs
+(and input/parameter gradients for a fixed random cotangent).  Fixtures are data only; no reference
+source travels.  RoIAlign inside ORViT is bound to oracle.focus_oracle.roi_align_list (torchvision is
+absent: that one op stays "parity unpinned").
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle import focus_oracle as fo            # noqa: E402
+from oracle._ref_loader import load_reference, load_motionformer  # noqa: E402
+
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+
+
+def _roi_align_tv(features, boxes, output_size, spatial_scale, sampling_ratio, aligned):
+    return fo.roi_align_list(features, boxes, output_size, spatial_scale, sampling_ratio, aligned)
+
+
+def ns(**kw):
+    return types.SimpleNamespace(**kw)
+
+
+def pack(prefix, sd):
+    return {prefix + k: v.detach().cpu().numpy() for k, v in sd.items()}
+
+
+def grads_of(module, names):
+    return {"grad." + n: dict(module.named_parameters())[n].grad.detach().numpy() for n in names}
+
+
+def small_cfg(crop=64, O=3, T=2):
+    return ns(
+        ORVIT=ns(ENABLE=True, O=O, LAYERS=[1], USE_MOTION_STREAM=True, MOTION_STREAM_ATTN_TYPE="joint",
+                 MOTION_STREAM_DIM=-1, MOTION_STREAM_SEP_POS_EMB=False, INIT_WEIGHTS=False,
+                 ZERO_INIT_ORVIT=False),
+        DATA=ns(TRAIN_CROP_SIZE=crop, NUM_FRAMES=2 * T),
+        MF=ns(PATCH_SIZE=16, PATCH_SIZE_TEMP=2, CHANNELS=3, EMBED_DIM=64, DEPTH=3, NUM_HEADS=4, MLP_RATIO=4,
+              QKV_BIAS=True, DROP=0.0, DROP_PATH=0.0, HEAD_DROPOUT=0.0, VIDEO_INPUT=True,
+              TEMPORAL_RESOLUTION=T, USE_MLP=True, ATTN_DROPOUT=0.0, HEAD_ACT="tanh", POS_DROPOUT=0.0,
+              POS_EMBED="separate"),
+        TRAIN=ns(DATASET="Ssv2"),
+        MODEL=ns(NUM_CLASSES=10),
+    )
+
+
+def make_boxes(g, B, T, O, zero=((1, None, 2),)):
+    """cxcywh in [0,1], boxes kept inside the frame; selected (b, t|None, o) slots zeroed."""
+    wh = 0.1 + 0.4 * torch.rand(B, T, O, 2, generator=g)
+    c = 0.3 + 0.4 * torch.rand(B, T, O, 2, generator=g)
+    c = torch.minimum(torch.maximum(c, wh / 2), 1 - wh / 2)
+    bx = torch.cat([c, wh], dim=-1)
+    for (b, t, o) in zero:
+        if t is None:
+            bx[b, :, o] = 0
+        else:
+            bx[b, t, o] = 0
+    return bx
+
+
+def randomize(module, g, std=0.2):
+    """Reference init leaves several tensors at zero (box_categories, conv weight); fixtures use
+    seeded non-degenerate values everywhere instead (weights are part of the fixture)."""
+    with torch.no_grad():
+        for n, prm in module.named_parameters():
+            if n.endswith("norm1.weight") or n.endswith("norm2.weight") or "norm" in n and n.endswith(".weight"):
+                prm.copy_(1.0 + 0.1 * torch.randn(prm.shape, generator=g))
+            else:
+                prm.copy_(std * torch.randn(prm.shape, generator=g))
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    torch.set_grad_enabled(True)
+    mods = load_reference(_roi_align_tv)
+    att, orv, outl = mods["attention"], mods["orvit"], mods["orvit_utils"]
+    g = torch.Generator().manual_seed(1234)
+
+    # 1. trajectory attention (attention.py:479-557)
+    m = att.TrajectoryAttention(64, num_heads=4, qkv_bias=True).double()
+    randomize(m, g)
+    x = torch.randn(2, 1 + 2 * 16, 64, generator=g, dtype=torch.float64, requires_grad=True)
+    ct = torch.randn(2, 33, 64, generator=g, dtype=torch.float64)
+    y, _ = m(x, [2, 4, 4])
+    (y * ct).sum().backward()
+    np.savez(os.path.join(OUT, "traj_attn.npz"), x=x.detach().numpy(), ct=ct.numpy(), y=y.detach().numpy(),
+             dx=x.grad.numpy(), thw=np.array([2, 4, 4]), heads=4, **pack("p.", m.state_dict()),
+             **grads_of(m, ["qkv.weight", "qkv.bias", "proj_q.weight", "proj_kv.weight", "proj_kv.bias",
+                            "proj.weight"]))
+
+    # 1b. non-square frame size P=18+3 (ORViT calling convention thw=[T, HW+O, 1])
+    m = att.TrajectoryAttention(32, num_heads=2, qkv_bias=True).double()
+    randomize(m, g)
+    x = torch.randn(1, 1 + 3 * 21, 32, generator=g, dtype=torch.float64, requires_grad=True)
+    ct = torch.randn(1, 64, 32, generator=g, dtype=torch.float64)
+    y, _ = m(x, [3, 21, 1])
+    (y * ct).sum().backward()
+    np.savez(os.path.join(OUT, "traj_attn_p21.npz"), x=x.detach().numpy(), ct=ct.numpy(),
+             y=y.detach().numpy(), dx=x.grad.numpy(), thw=np.array([3, 21, 1]), heads=2,
+             **pack("p.", m.state_dict()), **grads_of(m, ["qkv.weight", "proj_kv.weight"]))
+
+    # 2. trajectory block + 3. joint (motion-stream) block
+    from functools import partial
+    ln = partial(torch.nn.LayerNorm, eps=1e-6)
+    m = att.TrajectoryAttentionBlock(dim=64, num_heads=4, qkv_bias=True, norm_layer=ln).double()
+    randomize(m, g)
+    x = torch.randn(2, 33, 64, generator=g, dtype=torch.float64, requires_grad=True)
+    ct = torch.randn(2, 33, 64, generator=g, dtype=torch.float64)
+    y, _ = m(x, None, [2, 4, 4])
+    (y * ct).sum().backward()
+    np.savez(os.path.join(OUT, "traj_block.npz"), x=x.detach().numpy(), ct=ct.numpy(), y=y.detach().numpy(),
+             dx=x.grad.numpy(), thw=np.array([2, 4, 4]), heads=4, **pack("p.", m.state_dict()),
+             **grads_of(m, ["norm1.weight", "norm1.bias", "mlp.fc1.weight", "mlp.fc2.bias"]))
+
+    m = att.SeltAttentionBlock(dim=64, num_heads=4, qkv_bias=True, norm_layer=ln).double()
+    randomize(m, g)
+    x = torch.randn(2, 6, 64, generator=g, dtype=torch.float64, requires_grad=True)
+    ct = torch.randn(2, 6, 64, generator=g, dtype=torch.float64)
+    y, _ = m(x, None, None)
+    (y * ct).sum().backward()
+    np.savez(os.path.join(OUT, "joint_block.npz"), x=x.detach().numpy(), ct=ct.numpy(), y=y.detach().numpy(),
+             dx=x.grad.numpy(), heads=4, **pack("p.", m.state_dict()),
+             **grads_of(m, ["attn.qkv.weight", "attn.proj.bias"]))
+
+    # 4. box layout (ORViT/utils.py:8-28 + layout.py) incl. a zero box and a border-touching box
+    B, T, O, C, H, W = 2, 2, 3, 8, 5, 5
+    boxes = make_boxes(g, B, T, O, zero=((1, 0, 2), (0, None, 1)))
+    boxes[0, 0, 0] = torch.tensor([0.25, 0.25, 0.5, 0.5])       # touches the top-left corner
+    vecs = torch.randn(B, T, O, C, generator=g, requires_grad=True)
+    ct = torch.randn(B, C, T, H, W, generator=g)
+    lay = outl.box2spatial_layout(boxes, vecs, H, W)              # [B,C,T,H,W]
+    (lay * ct).sum().backward()
+    np.savez(os.path.join(OUT, "box_layout.npz"), boxes=boxes.numpy(), vecs=vecs.detach().numpy(),
+             ct=ct.numpy(), out=lay.detach().numpy(), dvecs=vecs.grad.numpy())
+
+    # 5. ORViT block (orvit.py:39-172), fp32 (layout and RoIAlign force fp32 inside)
+    cfg = small_cfg()
+    m = orv.ORViT(cfg=cfg, dim=64, num_heads=4, mlp_ratio=4, qkv_bias=True, norm_layer=ln, nb_frames=2)
+    randomize(m, g)
+    boxes = make_boxes(g, 2, 4, 3)                                # T_in = 4 -> every 2nd frame is used
+    x = torch.randn(2, 1 + 2 * 16, 64, generator=g, requires_grad=True)
+    ct = torch.randn(2, 33, 64, generator=g)
+    y, _ = m(x, {"orvit_bboxes": boxes.clone()}, [2, 4, 4])
+    (y * ct).sum().backward()
+    np.savez(os.path.join(OUT, "orvit_block.npz"), x=x.detach().numpy(), boxes=boxes.numpy(), ct=ct.numpy(),
+             y=y.detach().numpy(), dx=x.grad.numpy(), thw=np.array([2, 4, 4]), heads=4, crop=64,
+             **pack("p.", m.state_dict()),
+             **grads_of(m, ["patch_to_d.0.weight", "box_categories", "c_coord_to_feature.2.weight",
+                            "motion_stream.box_categories", "motion_stream.attn.attn.qkv.weight",
+                            "motion_mlp.fc1.weight", "attn.qkv.weight", "norm1.weight"]))
+
+    # 6. slot attention over video (steve.py:11-105), dropout 0 (SLOTS.PREDICTOR_DROPOUT default)
+    st = mods["steve"]
+    m = st.SlotAttentionVideo(num_iterations=3, num_slots=3, input_size=12, slot_size=8, mlp_hidden_size=16,
+                              num_predictor_blocks=2, num_predictor_heads=2, dropout=0.0).double()
+    randomize(m, g, std=0.4)
+    inp = torch.randn(2, 3, 16, 12, generator=g, dtype=torch.float64, requires_grad=True)
+    torch.manual_seed(77)
+    noise = torch.empty(2, 3, 8, dtype=torch.float64).normal_()   # the draw forward() makes at steve.py:56
+    torch.manual_seed(77)
+    slots, attns = m(inp)
+    cs = torch.randn(slots.shape, generator=g, dtype=torch.float64)
+    ca = torch.randn(attns.shape, generator=g, dtype=torch.float64)
+    ((slots * cs).sum() + (attns * ca).sum()).backward()
+    np.savez(os.path.join(OUT, "slot_attention.npz"), inputs=inp.detach().numpy(), noise=noise.numpy(),
+             slots=slots.detach().numpy(), attns=attns.detach().numpy(), ct_slots=cs.numpy(),
+             ct_attns=ca.numpy(), dinputs=inp.grad.numpy(), iters=3, pred_heads=2, pred_blocks=2,
+             **pack("p.", m.state_dict()),
+             **grads_of(m, ["slot_mu", "slot_log_sigma", "project_q.weight", "project_k.weight",
+                            "gru.weight_ih", "gru.weight_hh", "gru.bias_hh", "mlp.0.weight",
+                            "predictor.blocks.0.attn.proj_q.weight", "predictor.layer_norm.weight"]))
+
+    # 7. whole Motionformer (video_model_builder.py:1103-1353), reduced: D=64, depth 3, ORViT at 1,
+    #    crop 64 (exercises the bicubic pos-embed path), 4 input frames
+    load_motionformer(mods)
+    cfg = small_cfg()
+    torch.manual_seed(0)
+    m = mods["video_model_builder"].Motionformer(cfg)
+    randomize(m, g, std=0.1)
+    m.train()
+    x = torch.randn(2, 3, 4, 64, 64, generator=g)
+    boxes = make_boxes(g, 2, 4, 3)
+    labels = torch.tensor([3, 7])
+    logits = m([x], {"orvit_bboxes": boxes.clone()})
+    loss = mods_loss(logits, labels)
+    loss.backward()
+    keys = ["patch_embed_3d.proj.weight", "pos_embed", "temp_embed", "cls_token", "blocks.0.attn.qkv.weight",
+            "blocks.1.patch_to_d.2.weight", "blocks.1.motion_stream.c_coord_to_feature.0.weight",
+            "blocks.2.mlp.fc2.weight", "head.weight", "pre_logits.fc.bias"]
+    np.savez(os.path.join(OUT, "motionformer_small.npz"), x=x.numpy(), boxes=boxes.numpy(),
+             labels=labels.numpy(), logits=logits.detach().numpy(), loss=loss.detach().numpy(),
+             **pack("p.", m.state_dict()), **grads_of(m, keys))
+    names = np.array(sorted(m.state_dict().keys()))
+    shapes = np.array([",".join(map(str, m.state_dict()[k].shape)) for k in names])
+    np.savez(os.path.join(OUT, "motionformer_small_keys.npz"), names=names, shapes=shapes)
+
+    # 8. checkpoint ABI of the full-size model (names + shapes only; SSv2_ORViT-MF_224_16x4.yaml)
+    cfg = small_cfg(crop=224, O=4, T=8)
+    cfg.ORVIT.LAYERS = [1, 6, 10]
+    cfg.MF.EMBED_DIM, cfg.MF.DEPTH, cfg.MF.NUM_HEADS, cfg.MODEL.NUM_CLASSES = 768, 12, 12, 174
+    cfg.MF.DROP_PATH = 0.2
+    m = mods["video_model_builder"].Motionformer(cfg)
+    sd = m.state_dict()
+    names = np.array(sorted(sd.keys()))
+    shapes = np.array([",".join(map(str, sd[k].shape)) for k in names])
+    np.savez(os.path.join(OUT, "motionformer_224_keys.npz"), names=names, shapes=shapes,
+             nparams=sum(v.numel() for v in m.parameters()))
+    print("wrote", sorted(os.listdir(OUT)))
+
+
+def mods_loss(logits, labels):
+    """LabelSmoothingCrossEntropy (losses.py:40-59) is plain torch; restated inline to avoid loading
+    losses.py's unrelated imports."""
+    lp = torch.log_softmax(logits, dim=-1)
+    nll = -lp.gather(-1, labels.unsqueeze(1)).squeeze(1)
+    return (0.9 * nll + 0.1 * (-lp.mean(-1))).mean()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,118 @@
+"""Pins the CPU oracle (oracle/focus_oracle.py) to fixtures produced by the reference's own modules
+(oracle/make_golden.py).  CPU only."""
+import numpy as np
+import torch
+
+from conftest import load_golden
+
+
+def T(a, dtype=None, grad=False):
+    t = torch.from_numpy(np.asarray(a))
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.requires_grad_(grad)
+
+
+def close(a, b, tol):
+    a = a.detach().numpy() if isinstance(a, torch.Tensor) else a
+    err = np.abs(a - b).max() / max(np.abs(b).max(), 1e-3)  # floor: some grads are analytically 0
+    assert err < tol, err
+
+
+def leafify(p):
+    return {k: v.clone().requires_grad_(v.is_floating_point()) for k, v in p.items()}
+
+
+def check_grads(arrs, p, tol):
+    for k, g in arrs.items():
+        if k.startswith("grad."):
+            close(p[k[5:]].grad, g, tol)
+
+
+def test_trajectory_attention(oracle):
+    for fx in ("traj_attn", "traj_attn_p21"):
+        a, p = load_golden(fx)
+        p = leafify(p)
+        x = T(a["x"], grad=True)
+        y = oracle.trajectory_attention(p, "", x, list(a["thw"]), int(a["heads"])) if False else \
+            oracle.trajectory_attention({("." + k): v for k, v in p.items()}, "", x, list(a["thw"]), int(a["heads"]))
+        close(y, a["y"], 1e-12)
+        (y * T(a["ct"])).sum().backward()
+        close(x.grad, a["dx"], 1e-11)
+        check_grads(a, p, 1e-11)
+        # the v2 half of proj_kv is dead under use_original_code=True (gradient exactly zero)
+        C = x.shape[-1]
+        assert float(p["proj_kv.weight"].grad[C:].abs().max()) == 0.0
+
+
+def test_trajectory_block(oracle):
+    a, p = load_golden("traj_block")
+    p = leafify(p)
+    x = T(a["x"], grad=True)
+    y = oracle.trajectory_block({("b." + k): v for k, v in p.items()}, "b", x, list(a["thw"]), int(a["heads"]))
+    close(y, a["y"], 1e-12)
+    (y * T(a["ct"])).sum().backward()
+    close(x.grad, a["dx"], 1e-11)
+    check_grads(a, p, 1e-11)
+
+
+def test_joint_block(oracle):
+    a, p = load_golden("joint_block")
+    p = leafify(p)
+    x = T(a["x"], grad=True)
+    y = oracle.joint_attention_block({("b." + k): v for k, v in p.items()}, "b", x, int(a["heads"]))
+    close(y, a["y"], 1e-12)
+    (y * T(a["ct"])).sum().backward()
+    close(x.grad, a["dx"], 1e-11)
+    check_grads(a, p, 1e-11)
+
+
+def test_box_layout_and_closed_form(oracle):
+    a, _ = load_golden("box_layout")
+    vecs = T(a["vecs"], grad=True)
+    boxes = T(a["boxes"])
+    B, C, Tn, H, W = a["out"].shape
+    out = oracle.box_layout(vecs, boxes, H, W)                     # [B,T,H,W,C]
+    close(out.permute(0, 4, 1, 2, 3), a["out"], 1e-6)
+    (out.permute(0, 4, 1, 2, 3) * T(a["ct"])).sum().backward()
+    close(vecs.grad, a["dvecs"], 1e-6)
+    wy, wx, keep = oracle.box_layout_weights(boxes, H, W)
+    cf = torch.einsum("btoc,btoy,btox->btyxc", vecs.detach() * keep[..., None], wy, wx)
+    close(cf.permute(0, 4, 1, 2, 3), a["out"], 2e-6)
+
+
+def test_orvit_block(oracle):
+    a, p = load_golden("orvit_block")
+    p = leafify(p)
+    x = T(a["x"], grad=True)
+    y = oracle.orvit_block({("b." + k): v for k, v in p.items()}, "b", x, T(a["boxes"]), list(a["thw"]),
+                           int(a["heads"]), int(a["crop"]))
+    close(y, a["y"], 2e-6)
+    (y * T(a["ct"])).sum().backward()
+    close(x.grad, a["dx"], 2e-5)
+    check_grads(a, p, 2e-5)
+
+
+def test_slot_attention_video(oracle):
+    a, p = load_golden("slot_attention")
+    p = leafify(p)
+    inp = T(a["inputs"], grad=True)
+    slots, attns = oracle.slot_attention_video(p, inp, T(a["noise"]), int(a["iters"]), int(a["pred_heads"]),
+                                               int(a["pred_blocks"]))
+    close(slots, a["slots"], 1e-12)
+    close(attns, a["attns"], 1e-12)
+    ((slots * T(a["ct_slots"])).sum() + (attns * T(a["ct_attns"])).sum()).backward()
+    close(inp.grad, a["dinputs"], 1e-10)
+    check_grads(a, p, 1e-10)
+
+
+def test_motionformer_small(oracle):
+    a, p = load_golden("motionformer_small")
+    p = leafify(p)
+    cfg = dict(depth=3, heads=4, orvit_layers=[1], temporal_resolution=2, patch=(2, 16, 16), crop=64)
+    logits = oracle.motionformer_forward(p, T(a["x"]), T(a["boxes"]), cfg, training=True)
+    close(logits, a["logits"], 5e-6)
+    loss = oracle.label_smoothing_ce(logits, T(a["labels"]))
+    close(loss, a["loss"], 1e-6)
+    loss.backward()
+    check_grads(a, p, 1e-4)
