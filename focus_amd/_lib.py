@@ -1,0 +1,87 @@
+"""ctypes binding of libfocus_amd.so.  argtypes are derived from include/focus_amd.h itself, so the
+Python side cannot drift from the C ABI.  Loading fails loudly: there is no CPU or PyTorch fallback."""
+import ctypes
+import os
+import re
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+HEADER = os.path.join(_HERE, "..", "include", "focus_amd.h")
+LIB_PATH = os.path.join(_HERE, "lib", "libfocus_amd.so")
+
+F32, BF16 = 0, 1
+EPI_NONE, EPI_GELU, EPI_RELU, EPI_TANH, EPI_DGELU, EPI_DRELU, EPI_DTANH = range(7)
+
+
+class GemmDesc(ctypes.Structure):
+    _fields_ = [
+        ("M", ctypes.c_int32), ("N", ctypes.c_int32), ("K", ctypes.c_int32),
+        ("batch0", ctypes.c_int32), ("batch1", ctypes.c_int32),
+        ("A", ctypes.c_void_p), ("rsA", ctypes.c_int64), ("csA", ctypes.c_int64),
+        ("bsA0", ctypes.c_int64), ("bsA1", ctypes.c_int64),
+        ("B", ctypes.c_void_p), ("rsB", ctypes.c_int64), ("csB", ctypes.c_int64),
+        ("bsB0", ctypes.c_int64), ("bsB1", ctypes.c_int64),
+        ("C", ctypes.c_void_p), ("rsC", ctypes.c_int64), ("csC", ctypes.c_int64),
+        ("bsC0", ctypes.c_int64), ("bsC1", ctypes.c_int64),
+        ("bias", ctypes.c_void_p), ("residual", ctypes.c_void_p), ("aux", ctypes.c_void_p),
+        ("alpha", ctypes.c_float), ("accumulate", ctypes.c_int32), ("epilogue", ctypes.c_int32),
+        ("dtype_ab", ctypes.c_int32), ("dtype_c", ctypes.c_int32),
+    ]
+
+
+_CTYPE = {"int": ctypes.c_int, "int32_t": ctypes.c_int32, "int64_t": ctypes.c_int64,
+          "size_t": ctypes.c_size_t, "float": ctypes.c_float}
+
+
+def parse_header(path=HEADER):
+    """-> {name: (restype, [argtypes])} for every function declared in the public header."""
+    src = open(path).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    src = re.sub(r"typedef struct focus_gemm_desc \{.*?\} focus_gemm_desc;", "", src, flags=re.S)
+    src = re.sub(r"enum \w+ \{.*?\};", "", src, flags=re.S)
+    out = {}
+    for m in re.finditer(r"([\w\s\*]+?)\b(focus_\w+)\s*\(([^;{]*?)\)\s*;", src):
+        ret, name, args = m.group(1).strip(), m.group(2), m.group(3).strip()
+        if "char" in ret:
+            restype = ctypes.c_char_p
+        elif "size_t" in ret:
+            restype = ctypes.c_size_t
+        else:
+            restype = ctypes.c_int
+        argtypes = []
+        if args and args != "void":
+            for a in args.split(","):
+                a = a.strip()
+                if "*" in a:
+                    argtypes.append(ctypes.POINTER(GemmDesc) if "focus_gemm_desc" in a else ctypes.c_void_p)
+                else:
+                    ty = a.replace("const", "").split()[0]
+                    argtypes.append(_CTYPE[ty])
+        out[name] = (restype, argtypes)
+    return out
+
+
+_lib = None
+
+
+def lib():
+    """The loaded library with typed entry points (raises if the HIP extension has not been built)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                "focus_amd: %s is missing -- build it with `python -m focus_amd.build` "
+                "(there is no CPU/PyTorch fallback for the hot path)" % LIB_PATH)
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (restype, argtypes) in parse_header().items():
+            fn = getattr(L, name)          # AttributeError here = header/library mismatch
+            fn.restype = restype
+            fn.argtypes = argtypes
+        if L.focus_abi_version() != 1:
+            raise RuntimeError("focus_amd: ABI version mismatch")
+        _lib = L
+    return _lib
+
+
+def check(status, what=""):
+    if status != 0:
+        raise RuntimeError("focus_amd %s failed: %s (%d)" % (what, lib().focus_strerror(status).decode(), status))

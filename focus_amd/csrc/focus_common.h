@@ -1,0 +1,97 @@
+// focus_common.h -- shared device/host helpers for libfocus_amd.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/focus_amd.h"
+
+typedef uint16_t bf16_t;  // raw bfloat16 bits
+
+// ---- storage <-> fp32 ---------------------------------------------------------------------------
+__device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+// Plain cast keeps NaNs (MI355X_MICROARCH.md "Correctness boundaries"); hipcc emits v_cvt_pk_bf16_f32.
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) {
+    __bf16 b = (__bf16)f;
+    return __builtin_bit_cast(bf16_t, b);
+}
+
+template <typename T> __device__ __forceinline__ float ld(const T* p);
+template <> __device__ __forceinline__ float ld<float>(const float* p) { return *p; }
+template <> __device__ __forceinline__ float ld<bf16_t>(const bf16_t* p) { return bf16_to_f32(*p); }
+template <typename T> __device__ __forceinline__ void st(T* p, float v);
+template <> __device__ __forceinline__ void st<float>(float* p, float v) { *p = v; }
+template <> __device__ __forceinline__ void st<bf16_t>(bf16_t* p, float v) { *p = f32_to_bf16(v); }
+
+// 4-wide vector access (16 B for fp32, 8 B for bf16); pointers must be aligned accordingly.
+struct f4 { float x, y, z, w; };
+template <typename T> __device__ __forceinline__ f4 ld4(const T* p);
+template <> __device__ __forceinline__ f4 ld4<float>(const float* p) {
+    float4 v = *reinterpret_cast<const float4*>(p);
+    return {v.x, v.y, v.z, v.w};
+}
+template <> __device__ __forceinline__ f4 ld4<bf16_t>(const bf16_t* p) {
+    uint2 v = *reinterpret_cast<const uint2*>(p);
+    return {__uint_as_float(v.x << 16), __uint_as_float(v.x & 0xffff0000u), __uint_as_float(v.y << 16),
+            __uint_as_float(v.y & 0xffff0000u)};
+}
+template <typename T> __device__ __forceinline__ void st4(T* p, f4 v);
+template <> __device__ __forceinline__ void st4<float>(float* p, f4 v) {
+    *reinterpret_cast<float4*>(p) = make_float4(v.x, v.y, v.z, v.w);
+}
+template <> __device__ __forceinline__ void st4<bf16_t>(bf16_t* p, f4 v) {
+    uint2 o;
+    o.x = (uint32_t)f32_to_bf16(v.x) | ((uint32_t)f32_to_bf16(v.y) << 16);
+    o.y = (uint32_t)f32_to_bf16(v.z) | ((uint32_t)f32_to_bf16(v.w) << 16);
+    *reinterpret_cast<uint2*>(p) = o;
+}
+
+// ---- wave (64 lanes) and block reductions --------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+// Block-wide sum for blockDim.x <= 1024 (multiple of 64); `red` is >= 16 floats of LDS.
+__device__ __forceinline__ float block_sum(float v, float* red) {
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    __syncthreads();
+    if (lane == 0) red[w] = v;
+    __syncthreads();
+    float t = 0.f;
+    for (int i = 0; i < nw; ++i) t += red[i];
+    return t;
+}
+__device__ __forceinline__ float block_max(float v, float* red) {
+    v = wave_max(v);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    __syncthreads();
+    if (lane == 0) red[w] = v;
+    __syncthreads();
+    float t = -INFINITY;
+    for (int i = 0; i < nw; ++i) t = fmaxf(t, red[i]);
+    return t;
+}
+
+// ---- activations -------------------------------------------------------------------------------
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float dgelu_erf(float x) {
+    const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
+    const float pdf = 0.3989422804014327f * __expf(-0.5f * x * x);
+    return cdf + x * pdf;
+}
+
+// ---- host side ----------------------------------------------------------------------------------
+#define FOCUS_CHECK_LAUNCH()                                  \
+    do {                                                      \
+        if (hipGetLastError() != hipSuccess) return FOCUS_ERR_LAUNCH; \
+    } while (0)
+
+static inline bool focus_aligned(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
+static inline size_t focus_esize(int dtype) { return dtype == FOCUS_BF16 ? 2 : 4; }
+static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }

@@ -1,0 +1,10 @@
+// gemm_internal.h -- internal entry points behind focus_gemm().
+#pragma once
+#include <hip/hip_runtime.h>
+#include "../../include/focus_amd.h"
+
+int focus_gemm_generic(const focus_gemm_desc& d, hipStream_t s);
+// bf16 MFMA kernel for K-contiguous A [M,K] and B given as [N,K] rows (rsB==1): returns
+// FOCUS_ERR_ALIGN / FOCUS_ERR_SHAPE when the operands do not qualify (caller falls back).
+int focus_gemm_mfma_nt(const focus_gemm_desc& d, hipStream_t s);
+bool focus_gemm_mfma_nt_ok(const focus_gemm_desc& d);

@@ -1,0 +1,195 @@
+// layernorm.hip -- LayerNorm forward/backward, one wave (64 lanes) per row, 4-wide vector access.
+// HBM-bound: fwd reads x once and writes y once (2*D*esize B/row); bwd reads dy,x once, writes dx once.
+#include "focus_common.h"
+
+namespace {
+
+constexpr int MAXV = 16;  // up to 16 x (64 lanes x 4) = 4096 columns
+
+template <typename T, int NV>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta, T* __restrict__ y,
+                                                     float* __restrict__ mean, float* __restrict__ rstd, int rows,
+                                                     int D, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const T* xr = x + (int64_t)row * D;
+    f4 v[NV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        if (c < D) { v[i] = ld4<T>(xr + c); s += v[i].x + v[i].y + v[i].z + v[i].w; }
+    }
+    const float mu = wave_sum(s) / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        if (c < D) {
+            const float a = v[i].x - mu, b = v[i].y - mu, cc = v[i].z - mu, dd = v[i].w - mu;
+            q += a * a + b * b + cc * cc + dd * dd;
+        }
+    }
+    const float rs = rsqrtf(wave_sum(q) / (float)D + eps);
+    if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
+    T* yr = y + (int64_t)row * D;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        if (c < D) {
+            const f4 g = ld4<float>(gamma + c), b = ld4<float>(beta + c);
+            f4 o = {(v[i].x - mu) * rs * g.x + b.x, (v[i].y - mu) * rs * g.y + b.y,
+                    (v[i].z - mu) * rs * g.z + b.z, (v[i].w - mu) * rs * g.w + b.w};
+            st4<T>(yr + c, o);
+        }
+    }
+}
+
+// Each block walks rows blockIdx.x*4+w, += gridDim.x*4; per-lane partial dgamma/dbeta kept in registers,
+// combined across the block's 4 waves through LDS, written to partial[0|1][blk][D].
+template <typename T, int NV>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+                                                     const float* __restrict__ gamma,
+                                                     const float* __restrict__ mean,
+                                                     const float* __restrict__ rstd, T* __restrict__ dx,
+                                                     float* __restrict__ partial, int rows, int D) {
+    __shared__ float red[4][64 * 4 + 4];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    f4 dg[NV], db[NV], g[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        dg[i] = {0.f, 0.f, 0.f, 0.f};
+        db[i] = {0.f, 0.f, 0.f, 0.f};
+        const int c = (i * 64 + lane) * 4;
+        g[i] = c < D ? ld4<float>(gamma + c) : (f4){0.f, 0.f, 0.f, 0.f};
+    }
+    for (int row = blockIdx.x * 4 + w; row < rows; row += gridDim.x * 4) {
+        const float mu = mean[row], rs = rstd[row];
+        const T* xr = x + (int64_t)row * D;
+        const T* dr = dy + (int64_t)row * D;
+        f4 xh[NV], gd[NV];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = (i * 64 + lane) * 4;
+            if (c < D) {
+                const f4 xv = ld4<T>(xr + c), dv = ld4<T>(dr + c);
+                xh[i] = {(xv.x - mu) * rs, (xv.y - mu) * rs, (xv.z - mu) * rs, (xv.w - mu) * rs};
+                gd[i] = {dv.x * g[i].x, dv.y * g[i].y, dv.z * g[i].z, dv.w * g[i].w};
+                s1 += gd[i].x + gd[i].y + gd[i].z + gd[i].w;
+                s2 += gd[i].x * xh[i].x + gd[i].y * xh[i].y + gd[i].z * xh[i].z + gd[i].w * xh[i].w;
+                dg[i].x += dv.x * xh[i].x; dg[i].y += dv.y * xh[i].y; dg[i].z += dv.z * xh[i].z; dg[i].w += dv.w * xh[i].w;
+                db[i].x += dv.x; db[i].y += dv.y; db[i].z += dv.z; db[i].w += dv.w;
+            }
+        }
+        const float m1 = wave_sum(s1) / (float)D, m2 = wave_sum(s2) / (float)D;
+        T* dxr = dx + (int64_t)row * D;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = (i * 64 + lane) * 4;
+            if (c < D) {
+                f4 o = {rs * (gd[i].x - m1 - xh[i].x * m2), rs * (gd[i].y - m1 - xh[i].y * m2),
+                        rs * (gd[i].z - m1 - xh[i].z * m2), rs * (gd[i].w - m1 - xh[i].w * m2)};
+                st4<T>(dxr + c, o);
+            }
+        }
+    }
+    float* pg = partial + (int64_t)blockIdx.x * D;
+    float* pb = partial + (int64_t)(gridDim.x + blockIdx.x) * D;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        for (int pass = 0; pass < 2; ++pass) {
+            const f4 val = pass == 0 ? dg[i] : db[i];
+            __syncthreads();
+            red[w][lane * 4 + 0] = val.x; red[w][lane * 4 + 1] = val.y;
+            red[w][lane * 4 + 2] = val.z; red[w][lane * 4 + 3] = val.w;
+            __syncthreads();
+            if (w == 0) {
+                const int c = (i * 64 + lane) * 4;
+                if (c < D) {
+                    f4 o;
+                    o.x = red[0][lane * 4 + 0] + red[1][lane * 4 + 0] + red[2][lane * 4 + 0] + red[3][lane * 4 + 0];
+                    o.y = red[0][lane * 4 + 1] + red[1][lane * 4 + 1] + red[2][lane * 4 + 1] + red[3][lane * 4 + 1];
+                    o.z = red[0][lane * 4 + 2] + red[1][lane * 4 + 2] + red[2][lane * 4 + 2] + red[3][lane * 4 + 2];
+                    o.w = red[0][lane * 4 + 3] + red[1][lane * 4 + 3] + red[2][lane * 4 + 3] + red[3][lane * 4 + 3];
+                    st4<float>((pass == 0 ? pg : pb) + c, o);
+                }
+            }
+        }
+    }
+}
+
+__global__ void ln_bwd_finish(const float* __restrict__ partial, float* __restrict__ dgamma,
+                              float* __restrict__ dbeta, int nblk, int D) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= D) return;
+    float a = 0.f, b = 0.f;
+    for (int k = 0; k < nblk; ++k) {
+        a += partial[(int64_t)k * D + c];
+        b += partial[(int64_t)(nblk + k) * D + c];
+    }
+    dgamma[c] = a;
+    dbeta[c] = b;
+}
+
+template <typename T>
+int ln_fwd_launch(const void* x, const float* g, const float* b, void* y, float* mean, float* rstd, int rows, int D,
+                  float eps, hipStream_t s) {
+    const int nv = (D + 255) / 256;
+    dim3 grid((rows + 3) / 4), blk(256);
+#define LN_FWD(NV) hipLaunchKernelGGL((ln_fwd_kernel<T, NV>), grid, blk, 0, s, (const T*)x, g, b, (T*)y, mean, rstd, rows, D, eps)
+    if (nv <= 1) LN_FWD(1); else if (nv <= 2) LN_FWD(2); else if (nv <= 3) LN_FWD(3); else if (nv <= 4) LN_FWD(4);
+    else if (nv <= 8) LN_FWD(8); else LN_FWD(16);
+#undef LN_FWD
+    FOCUS_CHECK_LAUNCH();
+    return FOCUS_OK;
+}
+
+template <typename T>
+int ln_bwd_launch(const void* dy, const void* x, const float* g, const float* mean, const float* rstd, void* dx,
+                  float* partial, int rows, int D, int nblk, hipStream_t s) {
+    const int nv = (D + 255) / 256;
+    dim3 grid(nblk), blk(256);
+#define LN_BWD(NV) hipLaunchKernelGGL((ln_bwd_kernel<T, NV>), grid, blk, 0, s, (const T*)dy, (const T*)x, g, mean, rstd, (T*)dx, partial, rows, D)
+    if (nv <= 1) LN_BWD(1); else if (nv <= 2) LN_BWD(2); else if (nv <= 3) LN_BWD(3); else if (nv <= 4) LN_BWD(4);
+    else if (nv <= 8) LN_BWD(8); else LN_BWD(16);
+#undef LN_BWD
+    FOCUS_CHECK_LAUNCH();
+    return FOCUS_OK;
+}
+
+}  // namespace
+
+extern "C" int focus_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean,
+                                   float* rstd, int rows, int D, float eps, int dtype, void* stream) {
+    if (!x || !gamma || !beta || !y || !mean || !rstd) return FOCUS_ERR_NULL;
+    if (rows <= 0) return FOCUS_OK;
+    if (D <= 0 || (D & 3) || D > MAXV * 256) return FOCUS_ERR_SHAPE;
+    if (!focus_aligned(x, 8) || !focus_aligned(y, 8) || !focus_aligned(gamma, 16) || !focus_aligned(beta, 16))
+        return FOCUS_ERR_ALIGN;
+    hipStream_t s = (hipStream_t)stream;
+    return dtype == FOCUS_BF16 ? ln_fwd_launch<bf16_t>(x, gamma, beta, y, mean, rstd, rows, D, eps, s)
+                               : ln_fwd_launch<float>(x, gamma, beta, y, mean, rstd, rows, D, eps, s);
+}
+
+extern "C" int focus_layernorm_bwd_blocks(int rows) {
+    int b = (rows + 3) / 4;
+    return b < 1 ? 1 : (b > 1024 ? 1024 : b);
+}
+
+extern "C" int focus_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean,
+                                   const float* rstd, void* dx, float* dgamma, float* dbeta, float* partial,
+                                   int rows, int D, int dtype, void* stream) {
+    if (!dy || !x || !gamma || !mean || !rstd || !dx || !dgamma || !dbeta || !partial) return FOCUS_ERR_NULL;
+    if (D <= 0 || (D & 3) || D > MAXV * 256 || rows <= 0) return FOCUS_ERR_SHAPE;
+    hipStream_t s = (hipStream_t)stream;
+    const int nblk = focus_layernorm_bwd_blocks(rows);
+    int rc = dtype == FOCUS_BF16 ? ln_bwd_launch<bf16_t>(dy, x, gamma, mean, rstd, dx, partial, rows, D, nblk, s)
+                                 : ln_bwd_launch<float>(dy, x, gamma, mean, rstd, dx, partial, rows, D, nblk, s);
+    if (rc) return rc;
+    hipLaunchKernelGGL(ln_bwd_finish, dim3((D + 255) / 256), dim3(256), 0, s, partial, dgamma, dbeta, nblk, D);
+    FOCUS_CHECK_LAUNCH();
+    return FOCUS_OK;
+}

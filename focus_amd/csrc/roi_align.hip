@@ -1,0 +1,190 @@
+// roi_align.hip -- RoIAlign over channels-last patch-token feature maps (ORViT/utils.py:58-75).
+// Geometry follows oracle/roi_align_ref.c operation by operation in IEEE fp32 WITHOUT fma contraction
+// (__fmul_rn/__fadd_rn/...), so sampling-grid sizes and neighbour indices are bit-exact with the oracle.
+// HBM-bound: per output cell and channel, 4 gathered reads (L2-resident: a 14x14x768 map is 300 KB)
+// and one write.
+#include "focus_common.h"
+
+namespace {
+
+struct Geom { float y1, x1, bin_h, bin_w; int grid_h, grid_w; float count; };
+struct Nbr { int y_low, x_low, y_high, x_high; float w1, w2, w3, w4; };
+
+__device__ __forceinline__ Geom roi_geometry(const float* roi, float scale, int PH, int PW, int sampling_ratio,
+                                             int aligned) {
+    Geom g;
+    const float off = aligned ? 0.5f : 0.0f;
+    g.x1 = __fsub_rn(__fmul_rn(roi[0], scale), off);
+    g.y1 = __fsub_rn(__fmul_rn(roi[1], scale), off);
+    const float x2 = __fsub_rn(__fmul_rn(roi[2], scale), off);
+    const float y2 = __fsub_rn(__fmul_rn(roi[3], scale), off);
+    float rw = __fsub_rn(x2, g.x1), rh = __fsub_rn(y2, g.y1);
+    if (!aligned) { if (rw < 1.0f) rw = 1.0f; if (rh < 1.0f) rh = 1.0f; }
+    g.bin_h = __fdiv_rn(rh, (float)PH);
+    g.bin_w = __fdiv_rn(rw, (float)PW);
+    g.grid_h = sampling_ratio > 0 ? sampling_ratio : (int)ceilf(__fdiv_rn(rh, (float)PH));
+    g.grid_w = sampling_ratio > 0 ? sampling_ratio : (int)ceilf(__fdiv_rn(rw, (float)PW));
+    const int c = g.grid_h * g.grid_w;
+    g.count = (float)(c > 1 ? c : 1);
+    return g;
+}
+__device__ __forceinline__ float sample_coord(float start, int p, float bin, int i, int grid) {
+    // start + p*bin + (i + 0.5)*bin/grid, evaluated left to right as in the oracle
+    return __fadd_rn(__fadd_rn(start, __fmul_rn((float)p, bin)),
+                     __fdiv_rn(__fmul_rn(__fadd_rn((float)i, 0.5f), bin), (float)grid));
+}
+__device__ __forceinline__ Nbr locate(float y, float x, int H, int W) {
+    Nbr n;
+    if (y < -1.0f || y > (float)H || x < -1.0f || x > (float)W) {
+        n.y_low = n.x_low = n.y_high = n.x_high = -1;
+        n.w1 = n.w2 = n.w3 = n.w4 = 0.f;
+        return n;
+    }
+    if (y <= 0.f) y = 0.f;
+    if (x <= 0.f) x = 0.f;
+    n.y_low = (int)y;
+    n.x_low = (int)x;
+    if (n.y_low >= H - 1) { n.y_high = n.y_low = H - 1; y = (float)n.y_low; } else n.y_high = n.y_low + 1;
+    if (n.x_low >= W - 1) { n.x_high = n.x_low = W - 1; x = (float)n.x_low; } else n.x_high = n.x_low + 1;
+    const float ly = __fsub_rn(y, (float)n.y_low), lx = __fsub_rn(x, (float)n.x_low);
+    const float hy = __fsub_rn(1.0f, ly), hx = __fsub_rn(1.0f, lx);
+    n.w1 = __fmul_rn(hy, hx); n.w2 = __fmul_rn(hy, lx); n.w3 = __fmul_rn(ly, hx); n.w4 = __fmul_rn(ly, lx);
+    return n;
+}
+
+// grid: (PH, K); block 256 threads sweep (pw, channel-quad) of one output row of one RoI.
+template <typename T>
+__global__ __launch_bounds__(256) void roi_fwd_kernel(const T* __restrict__ feat, int64_t img_stride,
+                                                      const float* __restrict__ rois,
+                                                      const int32_t* __restrict__ roi_img, T* __restrict__ out, int C,
+                                                      int H, int W, int PH, int PW, float scale, int sr, int aligned) {
+    const int k = blockIdx.y, ph = blockIdx.x;
+    const Geom g = roi_geometry(rois + 4 * k, scale, PH, PW, sr, aligned);
+    const T* img = feat + (int64_t)roi_img[k] * img_stride;
+    const int cq = C >> 2;
+    for (int it = threadIdx.x; it < PW * cq; it += 256) {
+        const int pw = it / cq, c = (it % cq) * 4;
+        f4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int iy = 0; iy < g.grid_h; ++iy) {
+            const float y = sample_coord(g.y1, ph, g.bin_h, iy, g.grid_h);
+            for (int ix = 0; ix < g.grid_w; ++ix) {
+                const float x = sample_coord(g.x1, pw, g.bin_w, ix, g.grid_w);
+                const Nbr n = locate(y, x, H, W);
+                if (n.y_low < 0) continue;
+                const f4 a = ld4<T>(img + (int64_t)(n.y_low * W + n.x_low) * C + c);
+                const f4 b = ld4<T>(img + (int64_t)(n.y_low * W + n.x_high) * C + c);
+                const f4 cc = ld4<T>(img + (int64_t)(n.y_high * W + n.x_low) * C + c);
+                const f4 dd = ld4<T>(img + (int64_t)(n.y_high * W + n.x_high) * C + c);
+                // same association as the oracle: acc += w1*a + w2*b + w3*c + w4*d
+                acc.x += __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(n.w1, a.x), __fmul_rn(n.w2, b.x)), __fmul_rn(n.w3, cc.x)), __fmul_rn(n.w4, dd.x));
+                acc.y += __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(n.w1, a.y), __fmul_rn(n.w2, b.y)), __fmul_rn(n.w3, cc.y)), __fmul_rn(n.w4, dd.y));
+                acc.z += __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(n.w1, a.z), __fmul_rn(n.w2, b.z)), __fmul_rn(n.w3, cc.z)), __fmul_rn(n.w4, dd.z));
+                acc.w += __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(n.w1, a.w), __fmul_rn(n.w2, b.w)), __fmul_rn(n.w3, cc.w)), __fmul_rn(n.w4, dd.w));
+            }
+        }
+        acc.x = __fdiv_rn(acc.x, g.count); acc.y = __fdiv_rn(acc.y, g.count);
+        acc.z = __fdiv_rn(acc.z, g.count); acc.w = __fdiv_rn(acc.w, g.count);
+        st4<T>(out + ((int64_t)k * PH * PW + ph * PW + pw) * C + c, acc);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void roi_bwd_kernel(const T* __restrict__ dout, const float* __restrict__ rois,
+                                                      const int32_t* __restrict__ roi_img, float* __restrict__ dfeat,
+                                                      int C, int H, int W, int PH, int PW, float scale, int sr,
+                                                      int aligned) {
+    const int k = blockIdx.y, ph = blockIdx.x;
+    const Geom g = roi_geometry(rois + 4 * k, scale, PH, PW, sr, aligned);
+    float* img = dfeat + (int64_t)roi_img[k] * H * W * C;
+    const int cq = C >> 2;
+    for (int it = threadIdx.x; it < PW * cq; it += 256) {
+        const int pw = it / cq, c = (it % cq) * 4;
+        f4 gr = ld4<T>(dout + ((int64_t)k * PH * PW + ph * PW + pw) * C + c);
+        gr.x /= g.count; gr.y /= g.count; gr.z /= g.count; gr.w /= g.count;
+        for (int iy = 0; iy < g.grid_h; ++iy) {
+            const float y = sample_coord(g.y1, ph, g.bin_h, iy, g.grid_h);
+            for (int ix = 0; ix < g.grid_w; ++ix) {
+                const float x = sample_coord(g.x1, pw, g.bin_w, ix, g.grid_w);
+                const Nbr n = locate(y, x, H, W);
+                if (n.y_low < 0) continue;
+                float* p1 = img + (int64_t)(n.y_low * W + n.x_low) * C + c;
+                float* p2 = img + (int64_t)(n.y_low * W + n.x_high) * C + c;
+                float* p3 = img + (int64_t)(n.y_high * W + n.x_low) * C + c;
+                float* p4 = img + (int64_t)(n.y_high * W + n.x_high) * C + c;
+                const float gv[4] = {gr.x, gr.y, gr.z, gr.w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    atomicAdd(p1 + j, gv[j] * n.w1);
+                    atomicAdd(p2 + j, gv[j] * n.w2);
+                    atomicAdd(p3 + j, gv[j] * n.w3);
+                    atomicAdd(p4 + j, gv[j] * n.w4);
+                }
+            }
+        }
+    }
+}
+
+__global__ void roi_indices_kernel(const float* __restrict__ rois, int32_t* __restrict__ grid,
+                                   int32_t* __restrict__ nbr, int H, int W, int K, int PH, int PW, float scale,
+                                   int sr, int aligned) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= K * PH * PW) return;
+    const int pw = i % PW, ph = (i / PW) % PH, k = i / (PW * PH);
+    const Geom g = roi_geometry(rois + 4 * k, scale, PH, PW, sr, aligned);
+    if (ph == 0 && pw == 0) { grid[2 * k] = g.grid_h; grid[2 * k + 1] = g.grid_w; }
+    int32_t* o = nbr + (int64_t)i * 4;
+    if (g.grid_h <= 0 || g.grid_w <= 0) { o[0] = o[1] = o[2] = o[3] = -1; return; }
+    const Nbr n = locate(sample_coord(g.y1, ph, g.bin_h, 0, g.grid_h), sample_coord(g.x1, pw, g.bin_w, 0, g.grid_w),
+                         H, W);
+    o[0] = n.y_low; o[1] = n.x_low; o[2] = n.y_high; o[3] = n.x_high;
+}
+
+}  // namespace
+
+extern "C" int focus_roi_align_fwd(const void* feat, int64_t img_stride, const float* rois, const int32_t* roi_img,
+                                   void* out, int NI, int C, int H, int W, int K, int PH, int PW, float scale,
+                                   int sr, int aligned, int dtype, void* stream) {
+    (void)NI;
+    if (!feat || !rois || !roi_img || !out) return FOCUS_ERR_NULL;
+    if (K <= 0) return FOCUS_OK;
+    if ((C & 3) || PH <= 0 || PW <= 0 || K > 65535 * 1024) return FOCUS_ERR_SHAPE;
+    if (K > 65535) return FOCUS_ERR_SHAPE;
+    dim3 grid(PH, K);
+    if (dtype == FOCUS_BF16)
+        hipLaunchKernelGGL((roi_fwd_kernel<bf16_t>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)feat,
+                           img_stride, rois, roi_img, (bf16_t*)out, C, H, W, PH, PW, scale, sr, aligned);
+    else
+        hipLaunchKernelGGL((roi_fwd_kernel<float>), grid, dim3(256), 0, (hipStream_t)stream, (const float*)feat,
+                           img_stride, rois, roi_img, (float*)out, C, H, W, PH, PW, scale, sr, aligned);
+    FOCUS_CHECK_LAUNCH();
+    return FOCUS_OK;
+}
+
+extern "C" int focus_roi_align_bwd(const void* dout, const float* rois, const int32_t* roi_img, float* dfeat, int NI,
+                                   int C, int H, int W, int K, int PH, int PW, float scale, int sr, int aligned,
+                                   int dtype, void* stream) {
+    (void)NI;
+    if (!dout || !rois || !roi_img || !dfeat) return FOCUS_ERR_NULL;
+    if (K <= 0) return FOCUS_OK;
+    if ((C & 3) || PH <= 0 || PW <= 0 || K > 65535) return FOCUS_ERR_SHAPE;
+    dim3 grid(PH, K);
+    if (dtype == FOCUS_BF16)
+        hipLaunchKernelGGL((roi_bwd_kernel<bf16_t>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dout,
+                           rois, roi_img, dfeat, C, H, W, PH, PW, scale, sr, aligned);
+    else
+        hipLaunchKernelGGL((roi_bwd_kernel<float>), grid, dim3(256), 0, (hipStream_t)stream, (const float*)dout, rois,
+                           roi_img, dfeat, C, H, W, PH, PW, scale, sr, aligned);
+    FOCUS_CHECK_LAUNCH();
+    return FOCUS_OK;
+}
+
+extern "C" int focus_roi_align_indices(const float* rois, int32_t* grid, int32_t* nbr, int H, int W, int K, int PH,
+                                       int PW, float scale, int sr, int aligned, void* stream) {
+    if (!rois || !grid || !nbr) return FOCUS_ERR_NULL;
+    if (K <= 0) return FOCUS_OK;
+    const int n = K * PH * PW;
+    hipLaunchKernelGGL(roi_indices_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, rois, grid, nbr,
+                       H, W, K, PH, PW, scale, sr, aligned);
+    FOCUS_CHECK_LAUNCH();
+    return FOCUS_OK;
+}

@@ -1,0 +1,660 @@
+"""Autograd operators over the C ABI of libfocus_amd.so.
+
+Every function here enqueues hand-written HIP kernels on torch's current stream through ctypes;
+PyTorch only owns memory and the autograd tape.  CPU tensors are rejected: the hot path has no
+fallback (the CPU restatement lives in oracle/ and is test infrastructure only).
+"""
+import ctypes
+import weakref
+
+import torch
+
+from . import _lib
+from ._lib import BF16, F32, GemmDesc
+
+EPI_NONE, EPI_GELU, EPI_RELU, EPI_TANH = _lib.EPI_NONE, _lib.EPI_GELU, _lib.EPI_RELU, _lib.EPI_TANH
+_DEPI = {EPI_GELU: _lib.EPI_DGELU, EPI_RELU: _lib.EPI_DRELU, EPI_TANH: _lib.EPI_DTANH}
+
+
+# --------------------------------------------------------------------------------------------------
+# plumbing
+# --------------------------------------------------------------------------------------------------
+def _dt(t):
+    if t.dtype == torch.float32:
+        return F32
+    if t.dtype == torch.bfloat16:
+        return BF16
+    raise RuntimeError("focus_amd: unsupported dtype %s (float32 or bfloat16)" % t.dtype)
+
+
+def _need_gpu(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("focus_amd: the hot path runs on the MI355X only (got a %s tensor); "
+                               "there is no CPU fallback" % t.device)
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t, off=0):
+    if t is None:
+        return None
+    return ctypes.c_void_p(t.data_ptr() + off * t.element_size())
+
+
+def gemm(M, N, K, A, sA, B, sB, C, sC, batch=(1, 1), bias=None, residual=None, aux=None, alpha=1.0,
+         accumulate=False, epilogue=EPI_NONE):
+    """C = epi(alpha*A.B + bias) + residual.  A/B/C are (tensor, element_offset); s* = (rs, cs, bs0, bs1)."""
+    d = GemmDesc()
+    d.M, d.N, d.K = M, N, K
+    d.batch0, d.batch1 = batch
+    (ta, oa), (tb, ob), (tc, oc) = A, B, C
+    d.A, d.B, d.C = _p(ta, oa).value, _p(tb, ob).value, _p(tc, oc).value
+    d.rsA, d.csA, d.bsA0, d.bsA1 = sA
+    d.rsB, d.csB, d.bsB0, d.bsB1 = sB
+    d.rsC, d.csC, d.bsC0, d.bsC1 = sC
+    d.bias = bias.data_ptr() if bias is not None else None
+    d.residual = (residual[0].data_ptr() + residual[1] * residual[0].element_size()) if residual is not None else None
+    d.aux = (aux[0].data_ptr() + aux[1] * aux[0].element_size()) if aux is not None else None
+    d.alpha = alpha
+    d.accumulate = int(accumulate)
+    d.epilogue = epilogue
+    d.dtype_ab = _dt(ta)
+    d.dtype_c = _dt(tc)
+    assert ta.dtype == tb.dtype
+    _lib.check(_lib.lib().focus_gemm(ctypes.byref(d), _stream()), "gemm")
+
+
+def mm_nt(a, b, bias=None, residual=None, aux=None, epilogue=EPI_NONE, out_dtype=None, alpha=1.0, out=None):
+    """a [M,K] . b[N,K]^T -> [M,N]  (both K-contiguous: the MFMA layout)."""
+    M, K = a.shape
+    N = b.shape[0]
+    c = out if out is not None else torch.empty(M, N, device=a.device, dtype=out_dtype or a.dtype)
+    gemm(M, N, K, (a, 0), (a.stride(0), 1, 0, 0), (b, 0), (1, b.stride(0), 0, 0), (c, 0), (N, 1, 0, 0),
+         bias=bias, residual=(residual, 0) if residual is not None else None,
+         aux=(aux, 0) if aux is not None else None, alpha=alpha, epilogue=epilogue)
+    return c
+
+
+def mm_nn(a, b, aux=None, epilogue=EPI_NONE):
+    """a [M,K] . b [K,N] -> [M,N] for row-major b (generic kernel unless the caller supplies b^T to mm_nt)."""
+    M, K = a.shape
+    N = b.shape[1]
+    c = torch.empty(M, N, device=a.device, dtype=a.dtype)
+    gemm(M, N, K, (a, 0), (a.stride(0), 1, 0, 0), (b, 0), (b.stride(0), 1, 0, 0), (c, 0), (N, 1, 0, 0),
+         aux=(aux, 0) if aux is not None else None, epilogue=epilogue)
+    return c
+
+
+def transpose_pad(x, pad_to=64, dtype=None):
+    """x [R,C] -> x^T zero-padded along R to a multiple of `pad_to`: [C, Rpad]."""
+    R, Cc = x.shape
+    Rp = (R + pad_to - 1) // pad_to * pad_to
+    out = torch.empty(Cc, Rp, device=x.device, dtype=dtype or x.dtype)
+    _lib.check(_lib.lib().focus_transpose_pad(_p(x), _dt(x), x.stride(0), 0, _p(out), _dt(out), Rp, 0, R, Cc, 1,
+                                              _stream()), "transpose_pad")
+    return out
+
+
+def mm_tn(a, b):
+    """a[M,N]^T . b[M,K] -> [N,K] fp32 (weight gradients).  bf16: both operands are re-laid K(=M)-contiguous
+    by focus_transpose_pad and fed to the MFMA kernel; fp32: strided generic kernel."""
+    M, N = a.shape
+    K = b.shape[1]
+    c = torch.empty(N, K, device=a.device, dtype=torch.float32)
+    if a.dtype == torch.bfloat16:
+        at, bt = transpose_pad(a), transpose_pad(b)
+        Mp = at.shape[1]
+        gemm(N, K, Mp, (at, 0), (Mp, 1, 0, 0), (bt, 0), (1, Mp, 0, 0), (c, 0), (K, 1, 0, 0))
+    else:
+        gemm(N, K, M, (a, 0), (1, a.stride(0), 0, 0), (b, 0), (b.stride(0), 1, 0, 0), (c, 0), (K, 1, 0, 0))
+    return c
+
+
+def colsum(x):
+    M, N = x.shape
+    out = torch.empty(N, device=x.device, dtype=torch.float32)
+    _lib.check(_lib.lib().focus_colsum(_p(x), _p(out), M, N, x.stride(0), 0, _dt(x), _stream()), "colsum")
+    return out
+
+
+def cast(x, dtype):
+    if x.dtype == dtype:
+        return x
+    x = x.contiguous()
+    out = torch.empty(x.shape, device=x.device, dtype=dtype)
+    _lib.check(_lib.lib().focus_cast(_p(x), _dt(x), _p(out), _dt(out), x.numel(), _stream()), "cast")
+    return out
+
+
+# bf16 shadow copies of the fp32 master weights (and their transposes), refreshed when the parameter's
+# version counter changes (optimizer steps are in-place).
+_shadow_cache = {}
+
+
+def shadow(w, dtype, transposed=False):
+    if dtype == torch.float32 and not transposed:
+        return w.detach()
+    key = (id(w), dtype, transposed)
+    hit = _shadow_cache.get(key)
+    if hit is not None and hit[0]() is w and hit[1] == (w._version, w.data_ptr()):
+        return hit[2]
+    wd = w.detach()
+    if transposed:
+        N, K = wd.shape
+        out = torch.empty(K, N, device=w.device, dtype=dtype)
+        _lib.check(_lib.lib().focus_transpose_pad(_p(wd), _dt(wd), K, 0, _p(out), _dt(out), N, 0, N, K, 1, _stream()),
+                   "shadow^T")
+    else:
+        out = cast(wd, dtype)
+    _shadow_cache[key] = (weakref.ref(w, lambda _r, k=key: _shadow_cache.pop(k, None)),
+                          (w._version, w.data_ptr()), out)
+    return out
+
+
+def _dx_from(dy, w, dtype, aux=None, epilogue=EPI_NONE):
+    """dy [M,N] . w[N,K] -> [M,K]."""
+    if dtype == torch.bfloat16 and w.shape[0] % 64 == 0:
+        return mm_nt(dy, shadow(w, dtype, transposed=True), aux=aux, epilogue=epilogue)
+    return mm_nn(dy, shadow(w, dtype), aux=aux, epilogue=epilogue)
+
+
+# --------------------------------------------------------------------------------------------------
+# Linear / MLP
+# --------------------------------------------------------------------------------------------------
+class _LinearFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, b, residual):
+        _need_gpu(x, w)
+        shp = x.shape
+        x2 = x.reshape(-1, shp[-1])
+        if not x2.is_contiguous():
+            x2 = x2.contiguous()
+        r2 = residual.reshape(-1, w.shape[0]).contiguous() if residual is not None else None
+        y = mm_nt(x2, shadow(w, x.dtype), bias=b, residual=r2)
+        ctx.save_for_backward(x2, w)
+        ctx.has_b, ctx.has_r, ctx.shp = b is not None, residual is not None, shp
+        return y.reshape(*shp[:-1], w.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, w = ctx.saved_tensors
+        dy2 = dy.reshape(-1, w.shape[0])
+        if not dy2.is_contiguous():
+            dy2 = dy2.contiguous()
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = _dx_from(dy2, w, dy2.dtype).reshape(ctx.shp)
+        if ctx.needs_input_grad[1]:
+            dw = mm_tn(dy2, x2)
+        if ctx.has_b and ctx.needs_input_grad[2]:
+            db = colsum(dy2)
+        return dx, dw, db, (dy if ctx.has_r else None)
+
+
+def linear(x, w, b=None, residual=None):
+    """nn.Linear forward (+ fused residual add): y = x.w^T + b (+ residual)."""
+    return _LinearFn.apply(x, w, b, residual)
+
+
+class _MlpFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, residual, act):
+        _need_gpu(x, w1, w2)
+        shp = x.shape
+        x2 = x.reshape(-1, shp[-1])
+        if not x2.is_contiguous():
+            x2 = x2.contiguous()
+        M = x2.shape[0]
+        H = w1.shape[0]
+        z = torch.empty(M, H, device=x.device, dtype=x.dtype) if act == EPI_GELU else None
+        a = mm_nt(x2, shadow(w1, x.dtype), bias=b1, aux=z, epilogue=act)
+        r2 = residual.reshape(-1, w2.shape[0]).contiguous() if residual is not None else None
+        y = mm_nt(a, shadow(w2, x.dtype), bias=b2, residual=r2)
+        ctx.save_for_backward(x2, w1, w2, a, z)
+        ctx.act, ctx.shp = act, shp
+        ctx.has = (b1 is not None, b2 is not None, residual is not None)
+        return y.reshape(*shp[:-1], w2.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, w1, w2, a, z = ctx.saved_tensors
+        dy2 = dy.reshape(-1, w2.shape[0])
+        if not dy2.is_contiguous():
+            dy2 = dy2.contiguous()
+        dw2 = mm_tn(dy2, a) if ctx.needs_input_grad[3] else None
+        db2 = colsum(dy2) if ctx.has[1] else None
+        # dz = (dy . w2) * act'(.) fused in the GEMM epilogue
+        dz = _dx_from(dy2, w2, dy2.dtype, aux=(z if ctx.act == EPI_GELU else a), epilogue=_DEPI[ctx.act])
+        dw1 = mm_tn(dz, x2) if ctx.needs_input_grad[1] else None
+        db1 = colsum(dz) if ctx.has[0] else None
+        dx = _dx_from(dz, w1, dz.dtype).reshape(ctx.shp) if ctx.needs_input_grad[0] else None
+        return dx, dw1, db1, dw2, db2, (dy if ctx.has[2] else None), None
+
+
+def mlp(x, w1, b1, w2, b2, residual=None, act=EPI_GELU):
+    """Linear -> act -> Linear (+ residual): common.py:26-34 (GELU), steve.py:46-49 / transformer.py:62-66 (ReLU)."""
+    return _MlpFn.apply(x, w1, b1, w2, b2, residual, act)
+
+
+# --------------------------------------------------------------------------------------------------
+# LayerNorm
+# --------------------------------------------------------------------------------------------------
+class _LayerNormFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps):
+        _need_gpu(x, gamma)
+        D = x.shape[-1]
+        x2 = x.reshape(-1, D)
+        if not x2.is_contiguous():
+            x2 = x2.contiguous()
+        rows = x2.shape[0]
+        y = torch.empty_like(x2)
+        mean = torch.empty(rows, device=x.device, dtype=torch.float32)
+        rstd = torch.empty(rows, device=x.device, dtype=torch.float32)
+        _lib.check(_lib.lib().focus_layernorm_fwd(_p(x2), _p(gamma), _p(beta), _p(y), _p(mean), _p(rstd), rows, D,
+                                                  eps, _dt(x2), _stream()), "layernorm_fwd")
+        ctx.save_for_backward(x2, gamma, mean, rstd)
+        ctx.shp = x.shape
+        return y.reshape(x.shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, gamma, mean, rstd = ctx.saved_tensors
+        D = x2.shape[1]
+        rows = x2.shape[0]
+        dy2 = dy.reshape(-1, D)
+        if not dy2.is_contiguous():
+            dy2 = dy2.contiguous()
+        L = _lib.lib()
+        nblk = L.focus_layernorm_bwd_blocks(rows)
+        partial = torch.empty(2, nblk, D, device=x2.device, dtype=torch.float32)
+        dx = torch.empty_like(x2)
+        dg = torch.empty(D, device=x2.device, dtype=torch.float32)
+        db = torch.empty(D, device=x2.device, dtype=torch.float32)
+        _lib.check(L.focus_layernorm_bwd(_p(dy2), _p(x2), _p(gamma), _p(mean), _p(rstd), _p(dx), _p(dg), _p(db),
+                                         _p(partial), rows, D, _dt(x2), _stream()), "layernorm_bwd")
+        return dx.reshape(ctx.shp), dg, db, None
+
+
+def layer_norm(x, gamma, beta, eps):
+    return _LayerNormFn.apply(x, gamma, beta, eps)
+
+
+# --------------------------------------------------------------------------------------------------
+# Trajectory attention
+# --------------------------------------------------------------------------------------------------
+class _TrajSpaceFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, qkv, F_, P, heads):
+        _need_gpu(qkv)
+        qkv = qkv.contiguous()
+        B, N, C3 = qkv.shape
+        C = C3 // 3
+        d = C // heads
+        S = F_ * P
+        assert N == S + 1
+        dev, dt = qkv.device, qkv.dtype
+        xt = torch.empty(B, S, F_, C, device=dev, dtype=dt)
+        xdiag = torch.empty(B, S, C, device=dev, dtype=dt)
+        cls_out = torch.empty(B, 1, C, device=dev, dtype=dt)
+        lse = torch.empty(B, heads, S, F_, device=dev, dtype=torch.float32)
+        cls_lse = torch.empty(B, heads, device=dev, dtype=torch.float32)
+        L = _lib.lib()
+        nb = L.focus_traj_space_workspace_bytes(B, F_, P, heads, d, _dt(qkv), 0)
+        ws = torch.empty(max(nb, 16), device=dev, dtype=torch.uint8)
+        _lib.check(L.focus_traj_space_fwd(_p(qkv), _p(xt), _p(xdiag), _p(cls_out), _p(lse), _p(cls_lse), _p(ws), nb,
+                                          B, F_, P, heads, d, _dt(qkv), _stream()), "traj_space_fwd")
+        ctx.save_for_backward(qkv, xt, cls_out, lse, cls_lse)
+        ctx.dims = (B, F_, P, heads, d)
+        return xt, xdiag, cls_out
+
+    @staticmethod
+    def backward(ctx, dxt, dxdiag, dcls):
+        qkv, xt, cls_out, lse, cls_lse = ctx.saved_tensors
+        B, F_, P, heads, d = ctx.dims
+        dxt, dxdiag, dcls = dxt.contiguous(), dxdiag.contiguous(), dcls.contiguous()
+        dqkv = torch.empty_like(qkv)
+        L = _lib.lib()
+        nb = L.focus_traj_space_workspace_bytes(B, F_, P, heads, d, _dt(qkv), 1)
+        ws = torch.empty(max(nb, 16), device=qkv.device, dtype=torch.uint8)
+        _lib.check(L.focus_traj_space_bwd(_p(qkv), _p(xt), _p(cls_out), _p(lse), _p(cls_lse), _p(dxt), _p(dxdiag),
+                                          _p(dcls), _p(dqkv), _p(ws), nb, B, F_, P, heads, d, _dt(qkv), _stream()),
+                   "traj_space_bwd")
+        return dqkv, None, None, None
+
+
+def traj_space(qkv, F_, P, heads):
+    """(x~ [B,S,F,C], x_diag [B,S,C], cls_out [B,1,C]) from the fused qkv projection [B,1+F*P,3C]."""
+    return _TrajSpaceFn.apply(qkv, F_, P, heads)
+
+
+class _TrajTimeFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, q2, k2, xt, heads):
+        _need_gpu(q2, k2, xt)
+        q2, k2, xt = q2.contiguous(), k2.contiguous(), xt.contiguous()
+        B, S, F_, C = xt.shape
+        d = C // heads
+        out = torch.empty(B, S, C, device=xt.device, dtype=xt.dtype)
+        attn2 = torch.empty(B, heads, S, F_, device=xt.device, dtype=torch.float32)
+        _lib.check(_lib.lib().focus_traj_time_fwd(_p(q2), _p(k2), _p(xt), _p(out), _p(attn2), B, S, F_, heads, d,
+                                                  _dt(xt), _stream()), "traj_time_fwd")
+        ctx.save_for_backward(q2, k2, xt, attn2)
+        ctx.heads = heads
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        q2, k2, xt, attn2 = ctx.saved_tensors
+        B, S, F_, C = xt.shape
+        dout = dout.contiguous()
+        dq2, dk2, dxt = torch.empty_like(q2), torch.empty_like(k2), torch.empty_like(xt)
+        _lib.check(_lib.lib().focus_traj_time_bwd(_p(q2), _p(k2), _p(xt), _p(attn2), _p(dout), _p(dq2), _p(dk2),
+                                                  _p(dxt), 0, B, S, F_, ctx.heads, C // ctx.heads, _dt(xt),
+                                                  _stream()), "traj_time_bwd")
+        return dq2, dk2, dxt, None
+
+
+def traj_time(q2, k2, xt, heads):
+    return _TrajTimeFn.apply(q2, k2, xt, heads)
+
+
+# --------------------------------------------------------------------------------------------------
+# Small joint attention (motion stream: attention.py:369-385; slot predictor: transformer.py:23-49)
+# --------------------------------------------------------------------------------------------------
+class _SmallAttnFn(torch.autograd.Function):
+    """softmax(scale * q k^T) v per head on short sequences; q,k,v [B,N,C] (may be views of one buffer)."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, heads, scale):
+        _need_gpu(q, k, v)
+        B, N, C = q.shape
+        d = C // heads
+        dev, dt = q.device, q.dtype
+        q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
+        att = torch.empty(B, heads, N, N, device=dev, dtype=dt)
+        gemm(N, N, d, (q, 0), (C, 1, N * C, d), (k, 0), (1, C, N * C, d), (att, 0), (N, 1, heads * N * N, N * N),
+             batch=(B, heads))
+        _lib.check(_lib.lib().focus_softmax_fwd(_p(att), _p(att), B * heads * N, N, N, scale, _dt(att), _stream()),
+                   "softmax_fwd")
+        out = torch.empty(B, N, C, device=dev, dtype=dt)
+        gemm(N, d, N, (att, 0), (N, 1, heads * N * N, N * N), (v, 0), (C, 1, N * C, d), (out, 0), (C, 1, N * C, d),
+             batch=(B, heads))
+        ctx.save_for_backward(q, k, v, att)
+        ctx.heads, ctx.scale = heads, scale
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        q, k, v, att = ctx.saved_tensors
+        heads, scale = ctx.heads, ctx.scale
+        B, N, C = q.shape
+        d = C // heads
+        dout = dout.contiguous()
+        sa = (N, 1, heads * N * N, N * N)
+        sx = (C, 1, N * C, d)
+        datt = torch.empty_like(att)
+        # dA = dout . v^T ; dV = A^T . dout
+        gemm(N, N, d, (dout, 0), sx, (v, 0), (1, C, N * C, d), (datt, 0), sa, batch=(B, heads))
+        dv = torch.empty_like(v)
+        gemm(N, d, N, (att, 0), (1, N, heads * N * N, N * N), (dout, 0), sx, (dv, 0), sx, batch=(B, heads))
+        _lib.check(_lib.lib().focus_softmax_bwd(_p(datt), _p(att), _p(datt), B * heads * N, N, N, scale, _dt(att),
+                                                _stream()), "softmax_bwd")
+        dq, dk = torch.empty_like(q), torch.empty_like(k)
+        gemm(N, d, N, (datt, 0), sa, (k, 0), sx, (dq, 0), sx, batch=(B, heads))
+        gemm(N, d, N, (datt, 0), (1, N, heads * N * N, N * N), (q, 0), sx, (dk, 0), sx, batch=(B, heads))
+        return dq, dk, dv, None, None
+
+
+def small_attention(q, k, v, heads, scale):
+    return _SmallAttnFn.apply(q, k, v, heads, scale)
+
+
+# --------------------------------------------------------------------------------------------------
+# RoIAlign, per-RoI max, box layout
+# --------------------------------------------------------------------------------------------------
+class _RoiAlignFn(torch.autograd.Function):
+    """feat_tokens [NI, H*W, C] channels-last (a contiguous tensor); rois [K,4] fp32 xyxy pixels."""
+
+    @staticmethod
+    def forward(ctx, feat, rois, roi_img, H, W, PH, PW, scale, sampling_ratio, aligned):
+        _need_gpu(feat, rois, roi_img)
+        feat = feat.contiguous()
+        NI, HW, C = feat.shape
+        assert HW == H * W
+        K = rois.shape[0]
+        out = torch.empty(K, PH * PW, C, device=feat.device, dtype=feat.dtype)
+        _lib.check(_lib.lib().focus_roi_align_fwd(_p(feat), HW * C, _p(rois), _p(roi_img), _p(out), NI, C, H, W, K, PH,
+                                                  PW, scale, sampling_ratio, int(aligned), _dt(feat), _stream()),
+                   "roi_align_fwd")
+        ctx.save_for_backward(rois, roi_img)
+        ctx.args = (NI, C, H, W, K, PH, PW, scale, sampling_ratio, int(aligned), feat.dtype)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        rois, roi_img = ctx.saved_tensors
+        NI, C, H, W, K, PH, PW, scale, sr, al, dt = ctx.args
+        dout = dout.contiguous()
+        dfeat = torch.zeros(NI, H * W, C, device=dout.device, dtype=torch.float32)
+        _lib.check(_lib.lib().focus_roi_align_bwd(_p(dout), _p(rois), _p(roi_img), _p(dfeat), NI, C, H, W, K, PH, PW,
+                                                  scale, sr, al, _dt(dout), _stream()), "roi_align_bwd")
+        return cast(dfeat, dt), None, None, None, None, None, None, None, None, None
+
+
+def roi_align_tokens(feat, rois, roi_img, H, W, PH, PW, spatial_scale, sampling_ratio=-1, aligned=True):
+    return _RoiAlignFn.apply(feat, rois, roi_img, H, W, PH, PW, float(spatial_scale), sampling_ratio, aligned)
+
+
+def roi_align_indices(rois, H, W, PH, PW, spatial_scale, sampling_ratio=-1, aligned=True):
+    """Integer side of RoIAlign (parity export): grid [K,2], neighbours [K,PH,PW,4] int32."""
+    _need_gpu(rois)
+    K = rois.shape[0]
+    grid = torch.empty(K, 2, device=rois.device, dtype=torch.int32)
+    nbr = torch.empty(K, PH, PW, 4, device=rois.device, dtype=torch.int32)
+    _lib.check(_lib.lib().focus_roi_align_indices(_p(rois), _p(grid), _p(nbr), H, W, K, PH, PW, float(spatial_scale),
+                                                  sampling_ratio, int(aligned), _stream()), "roi_align_indices")
+    return grid, nbr
+
+
+class _CellAmaxFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        _need_gpu(x)
+        x = x.contiguous()
+        K, cells, C = x.shape
+        y = torch.empty(K, C, device=x.device, dtype=x.dtype)
+        arg = torch.empty(K, C, device=x.device, dtype=torch.int32)
+        _lib.check(_lib.lib().focus_cell_amax_fwd(_p(x), _p(y), _p(arg), K, cells, C, _dt(x), _stream()), "cell_amax")
+        ctx.save_for_backward(arg)
+        ctx.cells = cells
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (arg,) = ctx.saved_tensors
+        K, C = arg.shape
+        dy = dy.contiguous()
+        dx = torch.empty(K, ctx.cells, C, device=dy.device, dtype=dy.dtype)
+        _lib.check(_lib.lib().focus_cell_amax_bwd(_p(dy), _p(arg), _p(dx), K, ctx.cells, C, _dt(dy), _stream()),
+                   "cell_amax_bwd")
+        return dx
+
+
+def cell_amax(x):
+    """max over the cells of each RoI: [K, cells, C] -> [K, C]."""
+    return _CellAmaxFn.apply(x)
+
+
+class _BoxLayoutFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, vecs, boxes, H, W):
+        _need_gpu(vecs, boxes)
+        vecs, boxes = vecs.contiguous(), boxes.contiguous().float()
+        NF, O, C = vecs.shape
+        out = torch.empty(NF, H * W, C, device=vecs.device, dtype=vecs.dtype)
+        _lib.check(_lib.lib().focus_box_layout_fwd(_p(vecs), _p(boxes), _p(out), NF, O, C, H, W, _dt(vecs), _stream()),
+                   "box_layout_fwd")
+        ctx.save_for_backward(boxes)
+        ctx.args = (NF, O, C, H, W)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (boxes,) = ctx.saved_tensors
+        NF, O, C, H, W = ctx.args
+        dout = dout.contiguous()
+        dv = torch.empty(NF, O, C, device=dout.device, dtype=dout.dtype)
+        _lib.check(_lib.lib().focus_box_layout_bwd(_p(dout), _p(boxes), _p(dv), NF, O, C, H, W, _dt(dout), _stream()),
+                   "box_layout_bwd")
+        return dv, None, None, None
+
+
+def box_layout(vecs, boxes, H, W):
+    """vecs [NF,O,C], boxes [NF,O,4] cxcywh -> [NF, H*W, C]."""
+    return _BoxLayoutFn.apply(vecs, boxes, H, W)
+
+
+# --------------------------------------------------------------------------------------------------
+# Motionformer embedding / loss
+# --------------------------------------------------------------------------------------------------
+def im2col_patches(x, kt, kh, kw, dtype):
+    _need_gpu(x)
+    x = x.contiguous().float()
+    B, Cin, T, H, W = x.shape
+    rows = B * (T // kt) * (H // kh) * (W // kw)
+    cols = torch.empty(rows, Cin * kt * kh * kw, device=x.device, dtype=dtype)
+    _lib.check(_lib.lib().focus_im2col_patches(_p(x), _p(cols), B, Cin, T, H, W, kt, kh, kw, _dt(cols), _stream()),
+               "im2col")
+    return cols
+
+
+class _EmbedAssembleFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, patch, cls, pos, temp):
+        _need_gpu(patch, cls, pos, temp)
+        B, S, C = patch.shape
+        T = temp.shape[0]
+        P = S // T
+        patch = patch.contiguous()
+        tok = torch.empty(B, 1 + S, C, device=patch.device, dtype=patch.dtype)
+        _lib.check(_lib.lib().focus_embed_assemble(_p(patch), _p(cls), _p(pos), _p(temp), _p(tok), B, T, P, C,
+                                                   _dt(patch), _stream()), "embed_assemble")
+        ctx.dims = (B, T, P, C)
+        return tok
+
+    @staticmethod
+    def backward(ctx, dtok):
+        # adjoint = slices and small reductions over the batch: parameter-gradient plumbing
+        B, T, P, C = ctx.dims
+        g = dtok.float()
+        gp = g[:, 1:].reshape(B, T, P, C)
+        dcls = g[:, 0].sum(0)
+        dpos = torch.cat([dcls[None], gp.sum((0, 1))], 0)
+        dtemp = gp.sum((0, 2))
+        return dtok[:, 1:], dcls, dpos, dtemp
+
+
+def embed_assemble(patch, cls, pos, temp):
+    """cls [C], pos [1+P,C], temp [T,C] fp32 parameters."""
+    return _EmbedAssembleFn.apply(patch, cls.contiguous(), pos.contiguous(), temp.contiguous())
+
+
+class _XentLsFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, target, smoothing):
+        _need_gpu(logits, target)
+        logits = logits.float().contiguous()
+        R, Ncls = logits.shape
+        loss_rows = torch.empty(R, device=logits.device, dtype=torch.float32)
+        dlog = torch.empty_like(logits)
+        _lib.check(_lib.lib().focus_xent_ls(_p(logits), _p(target.contiguous()), _p(loss_rows), _p(dlog), R, Ncls,
+                                            smoothing, _stream()), "xent_ls")
+        ctx.save_for_backward(dlog)
+        return loss_rows.mean()
+
+    @staticmethod
+    def backward(ctx, g):
+        (dlog,) = ctx.saved_tensors
+        return dlog * g, None, None
+
+
+def label_smoothing_ce(logits, target, smoothing=0.1):
+    return _XentLsFn.apply(logits, target, smoothing)
+
+
+# --------------------------------------------------------------------------------------------------
+# Slot attention
+# --------------------------------------------------------------------------------------------------
+class _SlotAttnFn(torch.autograd.Function):
+    """One corrector iteration of steve.py:76-83 on one frame.  k_t, v_t [B,N,D]; q [B,K,D]."""
+
+    @staticmethod
+    def forward(ctx, k_t, v_t, q, eps):
+        _need_gpu(k_t, v_t, q)
+        k_t, v_t, q = k_t.contiguous(), v_t.contiguous(), q.contiguous()
+        B, N, D = k_t.shape
+        K = q.shape[1]
+        dev, dt = k_t.device, k_t.dtype
+        attn = torch.empty(B, N, K, device=dev, dtype=dt)
+        upd = torch.empty(B, K, D, device=dev, dtype=dt)
+        cs = torch.empty(B, K, device=dev, dtype=torch.float32)
+        L = _lib.lib()
+        nb = L.focus_slot_attn_workspace_bytes(B, N, K, D)
+        ws = torch.empty(nb, device=dev, dtype=torch.uint8)
+        _lib.check(L.focus_slot_attn_fwd(_p(k_t), _p(v_t), N * D, _p(q), _p(attn), N * K, _p(upd), _p(cs), _p(ws), nb,
+                                         B, N, K, D, eps, _dt(k_t), _stream()), "slot_attn_fwd")
+        ctx.save_for_backward(k_t, v_t, q, attn, cs, upd)
+        ctx.eps = eps
+        return upd, attn
+
+    @staticmethod
+    def backward(ctx, dupd, dattn):
+        k_t, v_t, q, attn, cs, upd = ctx.saved_tensors
+        B, N, D = k_t.shape
+        K = q.shape[1]
+        dupd = dupd.contiguous()
+        dattn = dattn.contiguous() if dattn is not None else None
+        dk, dv, dq = torch.empty_like(k_t), torch.empty_like(v_t), torch.empty_like(q)
+        L = _lib.lib()
+        nb = L.focus_slot_attn_workspace_bytes(B, N, K, D)
+        ws = torch.empty(nb, device=k_t.device, dtype=torch.uint8)
+        _lib.check(L.focus_slot_attn_bwd(_p(k_t), _p(v_t), N * D, _p(q), _p(attn), N * K, _p(cs), _p(upd), _p(dupd),
+                                         _p(dattn), _p(dk), _p(dv), 0, _p(dq), _p(ws), nb, B, N, K, D, ctx.eps,
+                                         _dt(k_t), _stream()), "slot_attn_bwd")
+        return dk, dv, dq, None
+
+
+def slot_attn_step(k_t, v_t, q, eps):
+    """-> (updates [B,K,D], attn_vis [B,N,K])."""
+    return _SlotAttnFn.apply(k_t, v_t, q, eps)
+
+
+class _GruGatesFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, gi, gh, h):
+        _need_gpu(gi, gh, h)
+        gi, gh, h = gi.contiguous(), gh.contiguous(), h.contiguous()
+        R, D = h.shape
+        hn = torch.empty_like(h)
+        _lib.check(_lib.lib().focus_gru_gates_fwd(_p(gi), _p(gh), _p(h), _p(hn), R, D, _dt(h), _stream()), "gru_fwd")
+        ctx.save_for_backward(gi, gh, h)
+        return hn
+
+    @staticmethod
+    def backward(ctx, dhn):
+        gi, gh, h = ctx.saved_tensors
+        R, D = h.shape
+        dhn = dhn.contiguous()
+        dgi, dgh, dh = torch.empty_like(gi), torch.empty_like(gh), torch.empty_like(h)
+        _lib.check(_lib.lib().focus_gru_gates_bwd(_p(gi), _p(gh), _p(h), _p(dhn), _p(dgi), _p(dgh), _p(dh), R, D,
+                                                  _dt(h), _stream()), "gru_bwd")
+        return dgi, dgh, dh
+
+
+def gru_cell(x, h, w_ih, w_hh, b_ih, b_hh):
+    """nn.GRUCell: two Linear GEMMs + fused gate kernel.  x, h [R,D]."""
+    return _GruGatesFn.apply(linear(x, w_ih, b_ih), linear(h, w_hh, b_hh), h)

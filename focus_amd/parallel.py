@@ -1,0 +1,21 @@
+"""Data-parallel wrapper: one process per GPU, gradient all-reduce over RCCL/xGMI (build.py:79-83).
+
+torch's DistributedDataParallel is kept as the reducer (bucketed, overlapped with backward by autograd hooks);
+the custom HIP autograd Functions return ordinary .grad tensors, so its hooks fire unchanged.  Buckets are
+all-reduced in bf16 on GPUs (halves the per-link xGMI bytes: 295 MB instead of 590 MB per step for the
+147.5 M parameter model) and gradients stay views into the buckets."""
+import torch
+import torch.distributed as dist
+
+
+def wrap_ddp(model, device, cfg=None, bucket_cap_mb=64, compress=True):
+    on_gpu = device is not None and device != "cpu" and torch.cuda.is_available()
+    kwargs = dict(bucket_cap_mb=bucket_cap_mb, gradient_as_bucket_view=True, find_unused_parameters=False)
+    if on_gpu:
+        ddp = torch.nn.parallel.DistributedDataParallel(model, device_ids=[device], output_device=device, **kwargs)
+    else:
+        ddp = torch.nn.parallel.DistributedDataParallel(model, **kwargs)
+    if compress and on_gpu:
+        from torch.distributed.algorithms.ddp_comm_hooks import default_hooks
+        ddp.register_comm_hook(dist.group.WORLD, default_hooks.bf16_compress_hook)
+    return ddp

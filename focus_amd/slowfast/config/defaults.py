@@ -1,0 +1,170 @@
+"""Config tree for the hot path (mirror of slowfast/config/defaults.py for the sections the path reads).
+
+fvcore/yacs are not available in the image, so this is a self-contained CfgNode with the same surface
+the reference's callers use: attribute access, merge_from_file (YAML), merge_from_list (KEY VALUE ...),
+clone(), dump(), freeze().  Key names, nesting and default values follow the reference
+(defaults.py:18-97 STEVE/EXP/SLOTS/ORVIT, :128-185 TRAIN, :230-245 MIXUP, :381-413 MODEL, :504-573 MF,
+:602-699 DATA, :710-721 SLOTS_OPTIM, :726-792 SOLVER, :798-822 top level).  YAML files of the reference
+carry many keys for subsystems outside the hot path (AUG, SSV2, TENSORBOARD ...): unknown keys are
+accepted and stored as given instead of being rejected.
+"""
+import ast
+import copy
+
+import yaml
+
+
+class CfgNode(dict):
+    def __init__(self, init=None):
+        super().__init__()
+        object.__setattr__(self, "_frozen", False)
+        for k, v in (init or {}).items():
+            self[k] = CfgNode(v) if isinstance(v, dict) and not isinstance(v, CfgNode) else v
+
+    def __getattr__(self, name):
+        try:
+            return self[name]
+        except KeyError:
+            raise AttributeError(name)
+
+    def __setattr__(self, name, value):
+        if object.__getattribute__(self, "_frozen"):
+            raise AttributeError("attempted to set %s on a frozen CfgNode" % name)
+        self[name] = value
+
+    def freeze(self):
+        object.__setattr__(self, "_frozen", True)
+        for v in self.values():
+            if isinstance(v, CfgNode):
+                v.freeze()
+
+    def defrost(self):
+        object.__setattr__(self, "_frozen", False)
+        for v in self.values():
+            if isinstance(v, CfgNode):
+                v.defrost()
+
+    def clone(self):
+        return copy.deepcopy(self)
+
+    def __deepcopy__(self, memo):
+        out = CfgNode()
+        for k, v in self.items():
+            out[k] = copy.deepcopy(v, memo)
+        return out
+
+    def to_dict(self):
+        return {k: (v.to_dict() if isinstance(v, CfgNode) else v) for k, v in self.items()}
+
+    def dump(self, **kw):
+        return yaml.safe_dump(self.to_dict(), **kw)
+
+    def _merge(self, other):
+        for k, v in other.items():
+            if isinstance(v, dict):
+                if k not in self or not isinstance(self[k], CfgNode):
+                    self[k] = CfgNode()
+                self[k]._merge(v)
+            else:
+                if isinstance(v, str) and isinstance(self.get(k), (int, float)) and not isinstance(self.get(k), bool):
+                    try:                      # PyYAML reads "5e-5" as a string; yacs coerces it the same way
+                        v = ast.literal_eval(v)
+                    except (ValueError, SyntaxError):
+                        pass
+                self[k] = v
+
+    def merge_from_other_cfg(self, other):
+        self._merge(other)
+
+    def merge_from_file(self, path):
+        with open(path) as f:
+            self._merge(yaml.safe_load(f) or {})
+
+    def merge_from_list(self, opts):
+        assert len(opts) % 2 == 0, "override list must be KEY VALUE pairs"
+        for key, val in zip(opts[0::2], opts[1::2]):
+            node = self
+            parts = key.split(".")
+            for p in parts[:-1]:
+                if p not in node:
+                    node[p] = CfgNode()
+                node = node[p]
+            if isinstance(val, str):
+                try:
+                    val = ast.literal_eval(val)
+                except (ValueError, SyntaxError):
+                    pass
+            node[parts[-1]] = val
+
+
+def _defaults():
+    C = CfgNode()
+    C.STEVE = CfgNode(dict(INIT_WEIGHTS=False, O=5, ENABLE=False, LAYERS=[], ADD_LAYERS=[],
+                           USE_MOTION_STREAM=True, MOTION_STREAM_ATTN_TYPE="joint"))
+    C.EXP = CfgNode(dict(NAME="test", PATH=""))
+    C.SLOTS = CfgNode(dict(SIZE=192, DIM=192, NUM_SLOTS=7, HEADS=1, HARD=True, NUM_ITERS=3, IMG_CHANNELS=3,
+                           IMG_SIZE=64, USE_SSL_FEAT=False, USE_PIXEL_RECON=False, SSL_TYPE="dino", TEACHER="r50",
+                           ARCH="steve", CNN_HID_SIZE=64, MLP_HID_SIZE=1024, NUM_PREDICTOR_HEADS=8,
+                           NUM_PREDICTOR_BLOCKS=4, PREDICTOR_DROPOUT=0.0, VOCAB_SIZE=4096, OUT_H=8, OUT_W=14,
+                           DECODER=dict(TYPE="mlp", NUM_BLOCKS=8, NUM_HEADS=4, DIM=2048, DROPOUT=0.1)))
+    C.ORVIT = CfgNode(dict(INIT_WEIGHTS=False, ZERO_INIT_ORVIT=False, LOAD_ORVIT_ATTN_LAYERS_FROM_BB=True, O=5,
+                           ENABLE=False, LAYERS=[], ADD_LAYERS=[], USE_MOTION_STREAM=True,
+                           MOTION_STREAM_ATTN_TYPE="joint", MOTION_STREAM_DIM=-1, MOTION_STREAM_N_HEADS=12,
+                           MOTION_STREAM_SEP_POS_EMB=False, FIXED_TRAJ=False))
+    C.TRAIN = CfgNode(dict(ENABLE=True, METHOD="slots", DATASET="kinetics", BATCH_SIZE=64, NUM_WORKERS=4,
+                           EVAL_PERIOD=10, CHECKPOINT_PERIOD=10, AUTO_RESUME=True, CHECKPOINT_FILE_PATH="",
+                           CHECKPOINT_TYPE="pytorch", CHECKPOINT_INFLATE=False, CHECKPOINT_EPOCH_RESET=False,
+                           CHECKPOINT_CLEAR_NAME_PATTERN=(), CHECKPOINT_REPLACE_NAME_PATTERN=[],
+                           MIXED_PRECISION=False, VAL_ONLY=False, LOG_PATH="", LOG_INTERVAL=2000,
+                           CHECKPOINT_PATH=""))
+    C.MIXUP = CfgNode(dict(ENABLE=False, ALPHA=0.8, CUTMIX_ALPHA=1.0, PROB=1.0, SWITCH_PROB=0.5,
+                           LABEL_SMOOTH_VALUE=0.1))
+    C.TEST = CfgNode(dict(ENABLE=True, DATASET="kinetics", EVAL_TASK="segmentation", BATCH_SIZE=8,
+                          CHECKPOINT_FILE_PATH="", NUM_ENSEMBLE_VIEWS=10, NUM_SPATIAL_CROPS=3,
+                          CHECKPOINT_TYPE="pytorch", SAVE_RESULTS_PATH="", TEST_EPOCH_NUM=-1))
+    C.MODEL = CfgNode(dict(ARCH="slowfast", MODEL_NAME="SlowFast", CNN_NAME="base", NUM_CLASSES=400,
+                           LOSS_FUNC="cross_entropy", DROPOUT_RATE=0.5, DROPCONNECT_RATE=0.0, FC_INIT_STD=0.01,
+                           HEAD_ACT="softmax", LOAD_IN_PRETRAIN=""))
+    C.MF = CfgNode(dict(PATCH_SIZE=16, PATCH_SIZE_TEMP=2, CHANNELS=3, EMBED_DIM=768, DEPTH=12, NUM_HEADS=12,
+                        MLP_RATIO=4, QKV_BIAS=True, VIDEO_INPUT=True, TEMPORAL_RESOLUTION=8, USE_MLP=False, DROP=0.0,
+                        DROP_PATH=0.0, HEAD_DROPOUT=0.0, POS_DROPOUT=0.0, ATTN_DROPOUT=0.0, HEAD_ACT="tanh",
+                        IM_PRETRAINED=True, PRETRAINED_WEIGHTS="vit_1k", POS_EMBED="separate",
+                        ATTN_LAYER="trajectory", APPROX_ATTN_TYPE="none", APPROX_ATTN_DIM=128))
+    C.DATA = CfgNode(dict(PATH_TO_DATA_DIR="", PATH_PREFIX="", NUM_FRAMES=8, SAMPLING_RATE=8, MEAN=[0.45, 0.45, 0.45],
+                          INPUT_CHANNEL_NUM=[3, 3], STD=[0.225, 0.225, 0.225], TRAIN_JITTER_SCALES=[256, 320],
+                          TRAIN_CROP_SIZE=224, TEST_CROP_SIZE=256, RANDOM_FLIP=True, REVERSE_INPUT_CHANNEL=False))
+    C.SLOTS_OPTIM = CfgNode(dict(DVAE=3e-4, ENC=1e-4, DEC=4e-4, HALF_LIFE=100000, WARMUP_STEPS=20000, CLIP=1.0,
+                                 TAU_START=1.0, TAU_FINAL=0.1, TAU_STEPS=30000, STEPS=200000, STEP_INTERVAL=5000))
+    C.SOLVER = CfgNode(dict(BASE_LR=0.1, ORVIT_BASE_LR=-1.0, LR_POLICY="cosine", COSINE_END_LR=0.0, GAMMA=0.1,
+                            STEP_SIZE=1, STEPS=[], LRS=[], MAX_EPOCH=300, MOMENTUM=0.9, DAMPENING=0.0, NESTEROV=True,
+                            WEIGHT_DECAY=1e-4, WARMUP_FACTOR=0.1, WARMUP_EPOCHS=0.0, WARMUP_START_LR=0.01,
+                            OPTIMIZING_METHOD="sgd", BASE_LR_SCALE_NUM_SHARDS=False, COSINE_AFTER_WARMUP=False,
+                            ZERO_WD_1D_PARAM=False, CLIP_GRAD_VAL=None, CLIP_GRAD_L2NORM=0.05))
+    C.DATA_LOADER = CfgNode(dict(NUM_WORKERS=8, PIN_MEMORY=True, ENABLE_MULTI_THREAD_DECODE=False))
+    C.TENSORBOARD = CfgNode(dict(ENABLE=True))
+    C.NUM_GPUS = 1
+    C.NUM_SHARDS = 1
+    C.SHARD_ID = 0
+    C.OUTPUT_DIR = "./tmp"
+    C.RNG_SEED = 1
+    C.LOG_PERIOD = 10
+    C.LOG_MODEL_INFO = False
+    C.DIST_BACKEND = "nccl"
+    return C
+
+
+_C = _defaults()
+
+
+def assert_and_infer_cfg(cfg):
+    """Sanity checks the hot path relies on (subset of defaults.py:1217-1242)."""
+    assert cfg.TRAIN.CHECKPOINT_TYPE in ["pytorch", "caffe2"]
+    assert cfg.NUM_GPUS == 0 or cfg.TRAIN.BATCH_SIZE % cfg.NUM_GPUS == 0
+    assert cfg.NUM_GPUS == 0 or cfg.TEST.BATCH_SIZE % cfg.NUM_GPUS == 0
+    assert cfg.SHARD_ID < cfg.NUM_SHARDS
+    return cfg
+
+
+def get_cfg():
+    """A fresh copy of the default config."""
+    return _C.clone()

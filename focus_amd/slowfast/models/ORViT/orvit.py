@@ -1,0 +1,154 @@
+"""ORViT object-region block (mirror of slowfast/models/ORViT/orvit.py:39-269)."""
+import torch
+from torch import nn
+
+from focus_amd import ops
+from focus_amd.slowfast.models.attention import SeltAttentionBlock, TrajectoryAttention
+
+from ..common import DropPath
+from .utils import Mlp, ObjectsCrops, box2spatial_layout
+
+
+def _relu_pair(seq, x):
+    """nn.Sequential(Linear(no bias), ReLU, Linear(no bias), ReLU): one fused 2-GEMM op + final ReLU."""
+    return torch.relu(ops.mlp(x, seq[0].weight, None, seq[2].weight, None, act=ops.EPI_RELU))
+
+
+class ORViT(nn.Module):
+    def __init__(self, cfg, dim=768, dim_out=None, num_heads=12, attn_type="trajectory", mlp_ratio=4.0,
+                 qkv_bias=False, drop=0.0, attn_drop=0.0, drop_path=0.0, act_layer=nn.GELU, norm_layer=nn.LayerNorm,
+                 use_original_code=False, nb_frames=None):
+        super().__init__()
+        self.cfg = cfg
+        self.in_dim = dim
+        self.dim = dim
+        self.nb_frames = nb_frames
+        self.with_cls_token = True
+        self.with_motion_stream = cfg.ORVIT.USE_MOTION_STREAM
+
+        self.crop_layer = ObjectsCrops(cfg)
+        self.patch_to_d = nn.Sequential(nn.Linear(dim, dim // 2, bias=False), nn.ReLU(inplace=True),
+                                        nn.Linear(dim // 2, dim, bias=False), nn.ReLU())
+        self.box_categories = nn.Parameter(torch.zeros(nb_frames, cfg.ORVIT.O, dim))
+        self.c_coord_to_feature = nn.Sequential(nn.Linear(4, dim // 2, bias=False), nn.ReLU(inplace=True),
+                                                nn.Linear(dim // 2, dim, bias=False), nn.ReLU())
+        mlp_hidden_dim = int(dim * mlp_ratio)
+        self.norm1 = norm_layer(dim)
+        self.norm2 = norm_layer(dim)
+        self.drop_path = DropPath(drop_path) if drop_path > 0.0 else nn.Identity()
+        self.mlp = Mlp(in_features=dim, hidden_features=mlp_hidden_dim, act_layer=act_layer, drop=drop)
+        self.attn = TrajectoryAttention(dim, num_heads=num_heads, qkv_bias=qkv_bias, attn_drop=attn_drop,
+                                        proj_drop=drop)
+        if self.with_motion_stream:
+            self.motion_stream = MotionStream(cfg, dim=dim, num_heads=num_heads,
+                                              attn_type=cfg.ORVIT.MOTION_STREAM_ATTN_TYPE, mlp_ratio=mlp_ratio,
+                                              qkv_bias=qkv_bias, drop=drop, attn_drop=attn_drop, drop_path=drop_path,
+                                              act_layer=act_layer, norm_layer=norm_layer, nb_frames=nb_frames)
+            self.motion_mlp = Mlp(in_features=cfg.ORVIT.MOTION_STREAM_DIM if cfg.ORVIT.MOTION_STREAM_DIM > 0 else dim,
+                                  hidden_features=mlp_hidden_dim, out_features=dim, act_layer=act_layer, drop=drop)
+        if cfg.ORVIT.INIT_WEIGHTS:
+            self.apply(self._init_weights)
+
+    def _init_weights(self, m):
+        if isinstance(m, nn.Linear):
+            nn.init.trunc_normal_(m.weight, std=0.02)
+            if m.bias is not None:
+                nn.init.constant_(m.bias, 0)
+        elif isinstance(m, nn.LayerNorm):
+            nn.init.constant_(m.bias, 0)
+            nn.init.constant_(m.weight, 1.0)
+        else:
+            for p in m.parameters():
+                nn.init.normal_(p, std=0.02)
+
+    def forward(self, x, metadata, thw):
+        box_tensors = metadata["orvit_bboxes"]
+        assert box_tensors is not None
+        BS, _, d = x.shape
+        T, H, W = thw
+        assert T == self.nb_frames
+        Tratio = box_tensors.shape[1] // T
+        box_tensors = box_tensors[:, ::Tratio].float()                     # [BS,T,O,4]
+        O = box_tensors.shape[-2]
+        cls_token, patch_tokens = x[:, :1], x[:, 1:]                      # tokens stay channels-last
+
+        # object tokens: RoIAlign -> patch_to_d -> max over the RoI cells (orvit.py:135-139)
+        crops = self.crop_layer.crop_tokens(patch_tokens, box_tensors, T, H, W)          # [BS*T*O, HW, d]
+        p2d = self.patch_to_d
+        pre = ops.mlp(crops, p2d[0].weight, None, p2d[2].weight, None, act=ops.EPI_RELU)  # last ReLU commutes with max
+        obj = torch.relu(ops.cell_amax(pre)).view(BS, T, O, d)
+        box_emb = _relu_pair(self.c_coord_to_feature, box_tensors)           # 4-d input: kept in fp32
+        obj = obj + (self.box_categories + box_emb).to(x.dtype)                               # :141-143
+
+        all_tokens = torch.cat([patch_tokens.reshape(BS, T, H * W, d), obj], dim=2).flatten(1, 2)
+        all_tokens = torch.cat([cls_token, all_tokens], dim=1)                              # :145-147
+        n1 = self.norm1
+        all_tokens, _ = self.attn(ops.layer_norm(all_tokens, n1.weight, n1.bias, n1.eps), [T, H * W + O, 1])
+        cls_token2, all_tokens = all_tokens[:, :1], all_tokens[:, 1:]
+        new_patch = all_tokens.reshape(BS, T, H * W + O, d)[:, :, :H * W].reshape(BS, T * H * W, d)   # :157
+
+        if self.with_motion_stream:
+            motion_emb = self.motion_stream(box_tensors, H, W, dtype=x.dtype)                # [BS,T*H*W,d]
+            new_patch = self.motion_mlp(motion_emb, residual=new_patch)                      # :162-163
+        new_tokens = torch.cat([cls_token2, new_patch], dim=1)
+        x = x + self.drop_path(new_tokens)                                                   # :169
+        n2 = self.norm2
+        x = x + self.drop_path(self.mlp(ops.layer_norm(x, n2.weight, n2.bias, n2.eps)))     # :170
+        return x, thw
+
+
+class Object2Spatial(nn.Module):
+    def __init__(self, cfg, _type):
+        super().__init__()
+        self.cfg = cfg
+        self._type = _type
+
+    def forward(self, all_features, context, boxes, H, W, t_avg_pooling=False):
+        BS, T, O, d = all_features.shape
+        if self._type != "layout":
+            raise NotImplementedError("%s: only the 'layout' mapping is used (orvit.py:252)" % self._type)
+        ret = box2spatial_layout(boxes, all_features, H, W).permute(0, 2, 3, 4, 1)    # [BS,T,H,W,d]
+        if t_avg_pooling:
+            Tratio = int(T / self.cfg.MF.TEMPORAL_RESOLUTION)
+            if Tratio > 1:
+                ret = ret.reshape(BS, -1, Tratio, H, W, d).mean(2)
+        return ret.flatten(1, 3)
+
+
+class MotionStream(nn.Module):
+    def __init__(self, cfg, dim=768, num_heads=12, attn_type="trajectory", mlp_ratio=4.0, qkv_bias=False, drop=0.0,
+                 attn_drop=0.0, drop_path=0.0, act_layer=nn.GELU, norm_layer=nn.LayerNorm, nb_frames=None):
+        super().__init__()
+        self.cfg = cfg
+        self.in_dim = cfg.ORVIT.MOTION_STREAM_DIM if cfg.ORVIT.MOTION_STREAM_DIM > 0 else dim
+        self.dim = dim
+        self.nb_frames = nb_frames
+        if cfg.ORVIT.MOTION_STREAM_SEP_POS_EMB:
+            self.box_categories_T = nn.Parameter(torch.zeros(nb_frames, 1, self.in_dim))
+            self.box_categories_O = nn.Parameter(torch.zeros(1, cfg.ORVIT.O, self.in_dim))
+        else:
+            self.box_categories = nn.Parameter(torch.zeros(nb_frames, cfg.ORVIT.O, self.in_dim))
+        self.c_coord_to_feature = nn.Sequential(nn.Linear(4, self.in_dim // 2, bias=False), nn.ReLU(inplace=True),
+                                                nn.Linear(self.in_dim // 2, self.in_dim, bias=False), nn.ReLU())
+        self.attn_type = attn_type
+        if attn_type != "joint":
+            raise NotImplementedError("ORVIT.MOTION_STREAM_ATTN_TYPE must be 'joint' (orvit.py:238)")
+        self.attn = SeltAttentionBlock(dim=self.in_dim, num_heads=num_heads, mlp_ratio=mlp_ratio, qkv_bias=qkv_bias,
+                                       drop_rate=attn_drop, drop_path=drop_path, act_layer=act_layer,
+                                       norm_layer=norm_layer)
+        self.obj2spatial = Object2Spatial(cfg, _type="layout")
+
+    def forward(self, box_tensors, H, W, dtype=None):
+        BS = box_tensors.shape[0]
+        dtype = dtype or box_tensors.dtype
+        box_emb = _relu_pair(self.c_coord_to_feature, box_tensors.float())   # 4-d input: kept in fp32
+        if self.cfg.ORVIT.MOTION_STREAM_SEP_POS_EMB:
+            shape = (self.nb_frames, self.cfg.ORVIT.O, self.in_dim)
+            cat = self.box_categories_T.expand(shape) + self.box_categories_O.expand(shape)
+        else:
+            cat = self.box_categories
+        box_emb = (cat.unsqueeze(0) + box_emb).to(dtype)                    # [BS,T,O,d]
+        oshape = box_emb.shape
+        box_emb, _ = self.attn(box_emb.flatten(1, -2), None, None)
+        box_emb = box_emb.reshape(oshape)
+        return self.obj2spatial(box_emb, None, box_tensors, H, W, t_avg_pooling=True)   # [BS,T*H*W,d]

@@ -1,0 +1,159 @@
+"""Motionformer backbone with ORViT blocks (mirror of slowfast/models/video_model_builder.py:1103-1353).
+Only the Motionformer family is on the hot path; SlowFast/ResNet/X3D/MViT builders are out of scope."""
+import math
+from collections import OrderedDict
+from functools import partial
+
+import torch
+import torch.nn as nn
+from torch.nn.init import trunc_normal_
+
+from focus_amd import ops
+
+from . import stem_helper
+from .attention import TrajectoryAttentionBlock
+from .build import MODEL_REGISTRY
+from .ORViT import ORViT
+
+
+@MODEL_REGISTRY.register()
+class Motionformer(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        self.cfg = cfg
+        self.img_size = cfg.DATA.TRAIN_CROP_SIZE
+        self.patch_size = cfg.MF.PATCH_SIZE
+        self.in_chans = cfg.MF.CHANNELS
+        self.num_classes = [97, 300] if cfg.TRAIN.DATASET == "epickitchens" else cfg.MODEL.NUM_CLASSES
+        self.embed_dim = cfg.MF.EMBED_DIM
+        self.depth = cfg.MF.DEPTH
+        self.num_heads = cfg.MF.NUM_HEADS
+        self.mlp_ratio = cfg.MF.MLP_RATIO
+        self.qkv_bias = cfg.MF.QKV_BIAS
+        self.drop_rate = cfg.MF.DROP
+        self.drop_path_rate = cfg.MF.DROP_PATH
+        self.head_dropout = cfg.MF.HEAD_DROPOUT
+        self.video_input = cfg.MF.VIDEO_INPUT
+        self.temporal_resolution = cfg.MF.TEMPORAL_RESOLUTION
+        self.use_mlp = cfg.MF.USE_MLP
+        self.num_features = self.embed_dim
+        self.attn_drop_rate = cfg.MF.ATTN_DROPOUT
+        self.head_act = cfg.MF.HEAD_ACT
+        norm_layer = partial(nn.LayerNorm, eps=1e-6)
+        if not self.video_input or cfg.MF.POS_EMBED != "separate":
+            raise NotImplementedError("hot path = video input with separate space/time position embeddings")
+        # bf16 storage + fp32 accumulation when TRAIN.MIXED_PRECISION (the reference autocasts to fp16)
+        self.compute_dtype = torch.bfloat16 if cfg.TRAIN.MIXED_PRECISION else torch.float32
+
+        k = [cfg.MF.PATCH_SIZE_TEMP, self.patch_size, self.patch_size]
+        self.patch_embed_3d = stem_helper.PatchEmbed(dim_in=self.in_chans, dim_out=self.embed_dim, kernel=k, stride=k,
+                                                     padding=0, conv_2d=False)
+        self.patch_embed_3d.compute_dtype = self.compute_dtype
+        self.patch_embed_3d.num_patches = (224 // self.patch_size) ** 2
+        self.patch_embed_3d.proj.weight.data = torch.zeros_like(self.patch_embed_3d.proj.weight.data)
+        self.num_patches = self.patch_embed_3d.num_patches * self.temporal_resolution
+
+        self.cls_token = nn.Parameter(torch.zeros(1, 1, self.embed_dim))
+        trunc_normal_(self.cls_token, std=0.02)
+        self.pos_embed = nn.Parameter(torch.zeros(1, self.patch_embed_3d.num_patches + 1, self.embed_dim))
+        self.pos_drop = nn.Dropout(p=cfg.MF.POS_DROPOUT)
+        trunc_normal_(self.pos_embed, std=0.02)
+        self.temp_embed = nn.Parameter(torch.zeros(1, self.temporal_resolution, self.embed_dim))
+
+        dpr = [x.item() for x in torch.linspace(0, self.drop_path_rate, self.depth)]
+        blocks = []
+        for i in range(self.depth):
+            if i in cfg.ORVIT.LAYERS:
+                blocks.append(ORViT(cfg=cfg, dim=self.embed_dim, num_heads=self.num_heads, mlp_ratio=self.mlp_ratio,
+                                    qkv_bias=self.qkv_bias, drop=self.drop_rate, attn_drop=self.attn_drop_rate,
+                                    norm_layer=norm_layer, nb_frames=self.temporal_resolution))
+            else:
+                blocks.append(TrajectoryAttentionBlock(cfg=cfg, dim=self.embed_dim, num_heads=self.num_heads,
+                                                       mlp_ratio=self.mlp_ratio, qkv_bias=self.qkv_bias,
+                                                       drop=self.drop_rate, attn_drop=self.attn_drop_rate,
+                                                       drop_path=dpr[i], norm_layer=norm_layer))
+        self.blocks = nn.ModuleList(blocks)
+        self.norm = norm_layer(self.embed_dim)
+
+        if self.use_mlp:
+            act = {"tanh": nn.Tanh, "gelu": nn.GELU}.get(self.head_act, nn.ReLU)()
+            self.pre_logits = nn.Sequential(OrderedDict([("fc", nn.Linear(self.embed_dim, self.embed_dim)),
+                                                         ("act", act)]))
+        else:
+            self.pre_logits = nn.Identity()
+        self.head_drop = nn.Dropout(p=self.head_dropout)
+        if isinstance(self.num_classes, list) and len(self.num_classes) > 1:
+            for a, n in enumerate(self.num_classes):
+                setattr(self, "head%d" % a, nn.Linear(self.embed_dim, n))
+        else:
+            self.head = nn.Linear(self.embed_dim, self.num_classes) if self.num_classes > 0 else nn.Identity()
+
+        self.init_weights()
+        self.apply(self._init_weights)
+
+    def init_weights(self):
+        for _, p in self.named_parameters():
+            if p.dim() > 1:
+                nn.init.xavier_uniform_(p)
+
+    def _init_weights(self, m):
+        if isinstance(m, nn.Linear):
+            trunc_normal_(m.weight, std=0.02)
+            if m.bias is not None:
+                nn.init.constant_(m.bias, 0)
+        elif isinstance(m, nn.LayerNorm):
+            nn.init.constant_(m.bias, 0)
+            nn.init.constant_(m.weight, 1.0)
+
+    @torch.jit.ignore
+    def no_weight_decay(self):
+        return {"pos_embed", "cls_token", "temp_embed"}
+
+    def get_classifier(self):
+        return self.head
+
+    def reset_classifier(self, num_classes, global_pool=""):
+        self.num_classes = num_classes
+        self.head = nn.Linear(self.embed_dim, num_classes) if num_classes > 0 else nn.Identity()
+
+    def _spatial_pos(self, npatch):
+        """pos_embed[:,1:] resampled bicubically when the crop is not 224 (:1285-1300)."""
+        pos = self.pos_embed
+        n0 = pos.shape[1] - 1
+        if self.cfg.DATA.TRAIN_CROP_SIZE == 224:
+            return pos[0]
+        g = int(math.sqrt(n0))
+        sp = pos[:, 1:].reshape(1, g, g, -1).permute(0, 3, 1, 2)
+        sp = torch.nn.functional.interpolate(sp, scale_factor=math.sqrt(npatch / n0), mode="bicubic")
+        sp = sp.permute(0, 2, 3, 1).reshape(-1, pos.shape[-1])
+        return torch.cat([pos[0, :1], sp], dim=0)
+
+    def forward_features(self, x, metadata):
+        x = x[0]
+        tok = self.patch_embed_3d(x)                                         # [B, T*H*W, D]  K1
+        npatch = tok.shape[1] // self.temporal_resolution
+        x = ops.embed_assemble(tok, self.cls_token.view(-1), self._spatial_pos(npatch), self.temp_embed[0])  # K2
+        if self.pos_drop.p > 0:
+            x = self.pos_drop(x)
+        side = int(npatch ** 0.5)
+        thw = [self.temporal_resolution, side, side]
+        for blk in self.blocks:
+            x, _ = blk(x, metadata, thw)
+        n = self.norm
+        x = ops.layer_norm(x[:, 0].contiguous(), n.weight, n.bias, n.eps)    # LN is per token: only cls is needed
+        if self.use_mlp:
+            x = self.pre_logits.act(ops.linear(x, self.pre_logits.fc.weight, self.pre_logits.fc.bias))
+        return x
+
+    def forward(self, x, metadata):
+        x = self.forward_features(x, metadata)
+        x = self.head_drop(x)
+        if isinstance(self.num_classes, list) and len(self.num_classes) > 1:
+            output = []
+            for hd in range(len(self.num_classes)):
+                m = getattr(self, "head%d" % hd)
+                o = ops.linear(x, m.weight, m.bias).float()
+                output.append(o if self.training else torch.softmax(o, dim=-1))
+            return output[0], {"verb": output[0], "noun": output[1]}
+        x = ops.linear(x, self.head.weight, self.head.bias).float()
+        return x if self.training else torch.softmax(x, dim=-1)

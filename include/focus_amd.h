@@ -1,0 +1,234 @@
+/*
+ * include/focus_amd.h -- C ABI of libfocus_amd.so (MI355X / gfx950 hot path of srv902/FOCUS).
+ *
+ * The reference has no FFI: its operator surface is the Python module API.
+ * Each entry point below replaces the device work done by the cited reference call site; the
+ * Python host mirror (focus_amd/slowfast/...) keeps the reference's signatures and calls these
+ * through ctypes (INTEGRATION.md shows the binding).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller (PyTorch); nothing here allocates,
+ *     frees or synchronises; kernels are enqueued on `stream` (a hipStream_t, may be NULL);
+ *   - tensors are dense row-major in the documented shape unless strides are passed;
+ *   - `dtype` selects activation/weight storage: FOCUS_F32 or FOCUS_BF16 (accumulation, softmax and
+ *     normalisation statistics are always fp32); LayerNorm affine parameters, biases and all
+ *     parameter gradients are fp32 in both modes;
+ *   - return value: 0 on success, negative focus_status on error (focus_strerror() names it).
+ */
+#ifndef FOCUS_AMD_H
+#define FOCUS_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum focus_dtype { FOCUS_F32 = 0, FOCUS_BF16 = 1 };
+
+enum focus_status {
+    FOCUS_OK = 0,
+    FOCUS_ERR_SHAPE = -1,      /* inconsistent or unsupported shape            */
+    FOCUS_ERR_DTYPE = -2,      /* unsupported dtype combination                */
+    FOCUS_ERR_ALIGN = -3,      /* pointer / stride alignment not met           */
+    FOCUS_ERR_LAUNCH = -4,     /* hipGetLastError() reported a launch failure  */
+    FOCUS_ERR_NULL = -5,       /* required pointer is NULL                     */
+    FOCUS_ERR_WORKSPACE = -6   /* workspace too small                          */
+};
+
+const char* focus_strerror(int status);
+/* ABI version of this library (bumped on any signature change). */
+int focus_abi_version(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * GEMM with fused epilogue:  C = epi(alpha * A.B [+ bias]) [+ residual]      (fp32 accumulate)
+ * Replaces every nn.Linear / bmm / einsum contraction on the path (attention.py:506,524-529,536-537,
+ * 555; common.py:26-34; orvit.py:59-72; steve.py:61-62,75-76,83; stem_helper.py:318 as im2col GEMM)
+ * and their autograd backward.  A is [M,K], B is [K,N], C is [M,N]; all three are addressed by
+ * element strides (rs = row stride, cs = column stride) and a two-level batch (batch0 x batch1).
+ * The MFMA path is taken when dtype is bf16 and both A and B are contiguous along K (csA==1,
+ * rsB==1), 16-byte aligned; everything else runs the generic tiled kernel.
+ * ----------------------------------------------------------------------------------------------*/
+enum focus_epilogue {
+    FOCUS_EPI_NONE = 0,
+    FOCUS_EPI_GELU = 1,    /* C = gelu_erf(v); if aux != NULL the pre-activation v is stored in aux */
+    FOCUS_EPI_RELU = 2,
+    FOCUS_EPI_TANH = 3,
+    FOCUS_EPI_DGELU = 4,   /* C = v * gelu'(aux)      aux = saved pre-activation                    */
+    FOCUS_EPI_DRELU = 5,   /* C = v * (aux > 0)       aux = saved output                            */
+    FOCUS_EPI_DTANH = 6    /* C = v * (1 - aux^2)     aux = saved output                            */
+};
+
+typedef struct focus_gemm_desc {
+    int32_t M, N, K;
+    int32_t batch0, batch1;
+    const void* A; int64_t rsA, csA, bsA0, bsA1;
+    const void* B; int64_t rsB, csB, bsB0, bsB1;
+    void* C;       int64_t rsC, csC, bsC0, bsC1;
+    const float* bias;        /* [N] fp32 or NULL (applied before the activation)                   */
+    const void* residual;     /* same dtype/strides as C, added after the activation, or NULL       */
+    void* aux;                /* same dtype/strides as C; see focus_epilogue                        */
+    float alpha;
+    int32_t accumulate;       /* 1: C += result (C must be fp32)                                    */
+    int32_t epilogue;         /* enum focus_epilogue                                                */
+    int32_t dtype_ab;         /* storage of A and B                                                 */
+    int32_t dtype_c;          /* storage of C, residual and aux                                     */
+} focus_gemm_desc;
+
+int focus_gemm(const focus_gemm_desc* desc, void* stream);
+
+/* y[M,N] = act(x[M,K] . w[N,K]^T + bias) + residual -- nn.Linear forward (thin wrapper over focus_gemm). */
+int focus_linear_fwd(const void* x, const void* w, const float* bias, const void* residual, void* y,
+                     void* aux, int M, int N, int K, int epilogue, int dtype, void* stream);
+
+/* out[n] (+)= sum_m x[m,n]   (bias gradients)  x is `dtype`, out fp32.  */
+int focus_colsum(const void* x, float* out, int M, int N, int64_t row_stride, int accumulate, int dtype,
+                 void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * LayerNorm over the last axis (video_model_builder.py:1129 eps 1e-6; steve.py:35-37 eps 1e-5).
+ * ----------------------------------------------------------------------------------------------*/
+int focus_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean,
+                        float* rstd, int rows, int D, float eps, int dtype, void* stream);
+/* dgamma/dbeta are written (not accumulated); `partial` is a [2, nblk, D] fp32 scratch with
+ * nblk = focus_layernorm_bwd_blocks(rows). */
+int focus_layernorm_bwd_blocks(int rows);
+int focus_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean,
+                        const float* rstd, void* dx, float* dgamma, float* dbeta, float* partial,
+                        int rows, int D, int dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Row softmax over segments:  x viewed as [rows, L] with row stride `stride`; in place allowed.
+ * bwd: dx = y * (dy - sum(dy*y)).   Used by the fp32 (unfused) attention path, the motion-stream
+ * joint attention (attention.py:380-381), the cls row (attention.py:436-440) and the slot predictor
+ * (transformer.py:44).
+ * ----------------------------------------------------------------------------------------------*/
+int focus_softmax_fwd(const void* x, void* y, int64_t rows, int L, int64_t stride, float scale, int dtype,
+                      void* stream);
+int focus_softmax_bwd(const void* dy, const void* y, void* dx, int64_t rows, int L, int64_t stride,
+                      float scale, int dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Trajectory attention (attention.py:499-557).  qkv is the output of the fused qkv Linear,
+ * [B, N, 3C] with N = 1 + F*P, channel order (q|k|v) x (head, d).
+ *   space step (:514-535): cls_out [B,C]; xt = x~ [B,S,F,C]; xdiag [B,S,C]; lse [B,h,S,F] and
+ *   cls_lse [B,h] (fp32, saved for backward).
+ *   time step (:538-549, use_original_code=True): q2 [B,S,C] (un-scaled proj_q output),
+ *   k2 [B,S,F,C], xt -> out [B,S,C]; attn2 [B,h,S,F] fp32 saved for backward.
+ * Workspace sizes are returned by the *_workspace_bytes queries (0 when none is needed).
+ * ----------------------------------------------------------------------------------------------*/
+size_t focus_traj_space_workspace_bytes(int B, int F, int P, int heads, int d, int dtype, int backward);
+int focus_traj_space_fwd(const void* qkv, void* xt, void* xdiag, void* cls_out, float* lse, float* cls_lse,
+                         void* workspace, size_t workspace_bytes, int B, int F, int P, int heads, int d,
+                         int dtype, void* stream);
+/* dqkv [B,N,3C] is fully written. dxt / dxdiag / dcls are the cotangents of xt / xdiag / cls_out. */
+int focus_traj_space_bwd(const void* qkv, const void* xt, const void* cls_out, const float* lse,
+                         const float* cls_lse, const void* dxt, const void* dxdiag, const void* dcls,
+                         void* dqkv, void* workspace, size_t workspace_bytes, int B, int F, int P,
+                         int heads, int d, int dtype, void* stream);
+int focus_traj_time_fwd(const void* q2, const void* k2, const void* xt, void* out, float* attn2, int B,
+                        int S, int F, int heads, int d, int dtype, void* stream);
+/* dxt_accum: 1 => dxt += (it already holds another cotangent of xt), 0 => dxt is overwritten. */
+int focus_traj_time_bwd(const void* q2, const void* k2, const void* xt, const float* attn2,
+                        const void* dout, void* dq2, void* dk2, void* dxt, int dxt_accum, int B, int S,
+                        int F, int heads, int d, int dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * RoIAlign over patch-token feature maps (ORViT/utils.py:58-75 -> torchvision.ops.roi_align with
+ * output_size=(H,W), sampling_ratio=-1, aligned=True).  Channels-last on both sides:
+ *   feat  [NI, H*W, C] with image stride `img_stride` elements (tokens are read in place from the
+ *         residual stream [B,1+T*H*W,C]; the caller passes the pointer to token 1);
+ *   rois  [K,4] fp32 xyxy in input pixels, roi_img [K] int32 image index;
+ *   out   [K, PH*PW, C].
+ * The integer side (sampling grid size, neighbour indices) is bit-exact with oracle/roi_align_ref.c.
+ * ----------------------------------------------------------------------------------------------*/
+int focus_roi_align_fwd(const void* feat, int64_t img_stride, const float* rois, const int32_t* roi_img,
+                        void* out, int NI, int C, int H, int W, int K, int PH, int PW, float spatial_scale,
+                        int sampling_ratio, int aligned, int dtype, void* stream);
+/* dfeat [NI, H*W, C] fp32 dense, must be zeroed by the caller (atomic accumulation). */
+int focus_roi_align_bwd(const void* dout, const float* rois, const int32_t* roi_img, float* dfeat, int NI,
+                        int C, int H, int W, int K, int PH, int PW, float spatial_scale, int sampling_ratio,
+                        int aligned, int dtype, void* stream);
+/* Debug/parity export of the integer side: grid [K,2], nbr [K,PH,PW,4] (int32). */
+int focus_roi_align_indices(const float* rois, int32_t* grid, int32_t* nbr, int H, int W, int K, int PH,
+                            int PW, float spatial_scale, int sampling_ratio, int aligned, void* stream);
+
+/* max over the cells of each RoI (orvit.py:138): x [K, cells, C] -> y [K, C], arg [K, C] int32. */
+int focus_cell_amax_fwd(const void* x, void* y, int32_t* arg, int K, int cells, int C, int dtype,
+                        void* stream);
+/* dx [K, cells, C] is fully written (zeros except the arg-max cell). */
+int focus_cell_amax_bwd(const void* dy, const int32_t* arg, void* dx, int K, int cells, int C, int dtype,
+                        void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Box layout (ORViT/utils.py:8-28 -> layout.py:28-63,98-130,205-237), closed form of SURVEY.md A4:
+ *   out[n,y,x,:] = sum_o keep_o * vecs[n,o,:] * w((lin_y - y0_o)/y1_o) * w((lin_x - x0_o)/x1_o)
+ * boxes [NF,O,4] fp32 cxcywh; vecs [NF,O,C]; out [NF,H*W,C].   NF = B*T frames.
+ * ----------------------------------------------------------------------------------------------*/
+int focus_box_layout_fwd(const void* vecs, const float* boxes, void* out, int NF, int O, int C, int H,
+                         int W, int dtype, void* stream);
+int focus_box_layout_bwd(const void* dout, const float* boxes, void* dvecs, int NF, int O, int C, int H,
+                         int W, int dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Slot-attention inverted softmax + weighted mean (steve.py:76-83) for one frame t, one iteration:
+ *   logits[b,n,k] = k_t[b,n,:].q[b,k,:]; attn_vis = softmax_k; a = (attn_vis+eps)/sum_n; upd = a^T v_t
+ * k_t, v_t [B,N,D] with batch stride `kv_bstride` elements (frame t of [B,T,N,D] read in place);
+ * q [B,K,D]; attn_vis [B,N,K] (stride attn_bstride); upd [B,K,D]; colsum [B,K] fp32 (saved).
+ * K <= 32, D <= 256.  partial: fp32 scratch of focus_slot_attn_workspace_bytes().
+ * ----------------------------------------------------------------------------------------------*/
+size_t focus_slot_attn_workspace_bytes(int B, int N, int K, int D);
+int focus_slot_attn_fwd(const void* k_t, const void* v_t, int64_t kv_bstride, const void* q, void* attn_vis,
+                        int64_t attn_bstride, void* upd, float* colsum, void* partial, size_t partial_bytes,
+                        int B, int N, int K, int D, float eps, int dtype, void* stream);
+/* dattn_vis may be NULL (no cotangent on the visualised attention).  dk_t/dv_t written at the same
+ * strides as k_t/v_t (accumulate=1: added to the existing contents). */
+int focus_slot_attn_bwd(const void* k_t, const void* v_t, int64_t kv_bstride, const void* q,
+                        const void* attn_vis, int64_t attn_bstride, const float* colsum, const void* upd,
+                        const void* dupd,
+                        const void* dattn_vis, void* dk_t, void* dv_t, int accumulate, void* dq, void* partial,
+                        size_t partial_bytes, int B, int N, int K, int D, float eps, int dtype, void* stream);
+
+/* nn.GRUCell gate math (STEVE/utils.py:107-118): gi, gh [R,3D] (bias already added), h [R,D] -> hn. */
+int focus_gru_gates_fwd(const void* gi, const void* gh, const void* h, void* hn, int R, int D, int dtype,
+                        void* stream);
+int focus_gru_gates_bwd(const void* gi, const void* gh, const void* h, const void* dhn, void* dgi, void* dgh,
+                        void* dh, int R, int D, int dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Patch embedding as GEMM (stem_helper.py:317-320): im2col of x [B,Cin,T,H,W] fp32 (loader output)
+ * for a kernel == stride patch (kt,kh,kw) -> cols [B*T'*H'*W', Cin*kt*kh*kw] in `dtype`,
+ * rows in (t,h,w) token order, columns in Conv3d weight order (c,dt,dh,dw).
+ * ----------------------------------------------------------------------------------------------*/
+int focus_im2col_patches(const float* x, void* cols, int B, int Cin, int T, int H, int W, int kt, int kh,
+                         int kw, int dtype, void* stream);
+
+/* tokens[b,0,:] = cls + pos[0]; tokens[b,1+t*P+p,:] = patch[b,t*P+p,:] + pos[1+p] + temp[t]
+ * (video_model_builder.py:1281-1320). cls [C], pos [1+P,C], temp [T,C] fp32. */
+int focus_embed_assemble(const void* patch, const float* cls, const float* pos, const float* temp,
+                         void* tokens, int B, int T, int P, int C, int dtype, void* stream);
+
+/* Label-smoothing cross entropy (losses.py:53-59): loss_rows [R] fp32, dlogits [R,Ncls] fp32
+ * (= d mean-loss / d logits).  logits fp32. */
+int focus_xent_ls(const float* logits, const int64_t* target, float* loss_rows, float* dlogits, int R,
+                  int Ncls, float smoothing, void* stream);
+
+/* dst[c, r] = src[r, c] for src [R, Cc] with row stride src_ld; dst has row stride dst_ld >= R and
+ * columns R..dst_ld-1 are zero-filled (so a transposed operand can feed the K-contiguous MFMA GEMM).
+ * src may be fp32 or bf16 (src_dtype); dst is `dst_dtype`. Batched over `batch` with the given strides. */
+int focus_transpose_pad(const void* src, int src_dtype, int64_t src_ld, int64_t src_bstride, void* dst,
+                        int dst_dtype, int64_t dst_ld, int64_t dst_bstride, int R, int Cc, int batch,
+                        void* stream);
+
+/* xdiag[b,s,:] = xt[b,s,s/P,:] (attention.py:533-535) and its adjoint dxt[b,s,s/P,:] += dxdiag[b,s,:]. */
+int focus_diag_gather(const void* xt, void* xdiag, int B, int S, int F, int C, int dtype, void* stream);
+int focus_diag_scatter_add(const void* dxdiag, void* dxt, int B, int S, int F, int C, int dtype, void* stream);
+
+/* dtype conversion (weights shadow copies, gradient casts): n elements. */
+int focus_cast(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t n, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FOCUS_AMD_H */

@@ -1,0 +1,99 @@
+"""CPU-side checks of the boundary: the C-ABI library loads, exports every symbol include/focus_amd.h
+declares, refuses CPU tensors (no fallback), and the host mirror keeps the reference's surface."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT
+
+
+@pytest.fixture(scope="module")
+def built():
+    from focus_amd.build import build
+    return build(verbose=False)
+
+
+def test_library_exports_every_declared_symbol(built):
+    from focus_amd import _lib
+    decl = _lib.parse_header()
+    assert len(decl) >= 30
+    L = ctypes.CDLL(built)
+    for name in decl:
+        assert hasattr(L, name), "missing export: " + name
+    lib = _lib.lib()
+    assert lib.focus_abi_version() == 1
+    assert lib.focus_strerror(-1) == b"bad shape" and lib.focus_strerror(0) == b"ok"
+    # pure host-side queries work without a GPU
+    assert lib.focus_layernorm_bwd_blocks(10) == 3
+    assert lib.focus_traj_space_workspace_bytes(1, 8, 196, 12, 64, 1, 0) >= 12 * 1568 * 1568 * 2
+    assert lib.focus_slot_attn_workspace_bytes(2, 4096, 11, 192) == 2 * 16 * 11 * 193 * 4
+
+
+def test_gemm_desc_layout_matches_header():
+    from focus_amd._lib import GemmDesc
+    assert ctypes.sizeof(GemmDesc) == 192       # 5 int32 (+pad) | 3 x (ptr + 4 int64) | 3 ptr | f32 + 4 int32 (+pad)
+    assert GemmDesc.A.offset == 24 and GemmDesc.bias.offset == 144 and GemmDesc.alpha.offset == 168
+
+
+def test_hot_path_has_no_cpu_fallback(built):
+    from focus_amd import ops
+    x = torch.randn(4, 8)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ops.linear(x, torch.randn(8, 8), None)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ops.layer_norm(x, torch.ones(8), torch.zeros(8), 1e-6)
+
+
+def test_config_and_registry_surface():
+    from focus_amd.slowfast.config.defaults import assert_and_infer_cfg, get_cfg
+    from focus_amd.slowfast.models import MODEL_REGISTRY, build_model
+    cfg = get_cfg()
+    assert cfg.ORVIT.O == 5 and cfg.MF.TEMPORAL_RESOLUTION == 8 and cfg.SOLVER.CLIP_GRAD_L2NORM == 0.05
+    assert cfg.TRAIN.METHOD == "slots" and cfg.DIST_BACKEND == "nccl" and cfg.SLOTS.NUM_ITERS == 3
+    cfg.merge_from_list(["ORVIT.LAYERS", "[1,6,10]", "NUM_GPUS", "0", "MODEL.MODEL_NAME", "Motionformer",
+                         "ORVIT.ENABLE", "True", "ORVIT.O", 4, "TRAIN.DATASET", "Ssv2", "MF.USE_MLP", True,
+                         "MODEL.NUM_CLASSES", 174, "DATA.NUM_FRAMES", 16])
+    assert cfg.ORVIT.LAYERS == [1, 6, 10] and cfg.NUM_GPUS == 0 and cfg.ORVIT.ENABLE is True
+    assert_and_infer_cfg(cfg)
+    assert "Motionformer" in MODEL_REGISTRY
+    with pytest.raises(KeyError):
+        MODEL_REGISTRY.get("SlowFast")
+    model = build_model(cfg)
+    sd = model.state_dict()
+    z = np.load(os.path.join(ROOT, "tests", "golden", "motionformer_224_keys.npz"))
+    names = sorted(sd.keys())
+    assert names == list(z["names"])
+    assert [",".join(map(str, sd[k].shape)) for k in names] == list(z["shapes"])
+    assert sum(p.numel() for p in model.parameters()) == int(z["nparams"]) == 147506862
+    assert model.no_weight_decay() == {"pos_embed", "cls_token", "temp_embed"}
+    c2 = cfg.clone()
+    c2.MF.DEPTH = 1
+    assert cfg.MF.DEPTH == 12
+    cfg.freeze()
+    with pytest.raises(AttributeError):
+        cfg.NUM_GPUS = 3
+
+
+def test_yaml_configs_of_the_reference_shape_load(tmp_path):
+    """A YAML with the reference's ORViT keys plus keys for out-of-scope subsystems merges cleanly."""
+    from focus_amd.slowfast.config.defaults import get_cfg
+    y = tmp_path / "c.yaml"
+    y.write_text("ORVIT:\n  ENABLE: True\n  O: 4\n  LAYERS: [1,6,10]\nAUG:\n  ENABLE: True\n"
+                 "MF:\n  DROP_PATH: 0.2\n  USE_MLP: True\nSOLVER:\n  BASE_LR: 5e-5\n  OPTIMIZING_METHOD: adamw\n"
+                 "NUM_GPUS: 8\n")
+    cfg = get_cfg()
+    cfg.merge_from_file(str(y))
+    assert cfg.ORVIT.LAYERS == [1, 6, 10] and cfg.AUG.ENABLE is True and cfg.MF.DROP_PATH == 0.2
+    assert cfg.SOLVER.BASE_LR == 5e-5
+
+
+def test_slot_module_surface():
+    from focus_amd.slowfast.models.STEVE.steve import SlotAttentionVideo
+    from conftest import load_golden
+    _, p = load_golden("slot_attention")
+    m = SlotAttentionVideo(3, 3, 12, 8, 16, num_predictor_blocks=2, num_predictor_heads=2, dropout=0.0)
+    assert sorted(m.state_dict().keys()) == sorted(p.keys())
+    m.load_state_dict({k: v.float() for k, v in p.items()})

@@ -1,0 +1,344 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle and the reference-generated fixtures.
+fp32 mode is held to the north-star tolerance 1e-3 (relative to the tensor's max magnitude);
+bf16 mode (bf16 storage, fp32 accumulation) to 3e-2.  RoI bin indices are compared bit-exactly."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+TOL = {torch.float32: 1e-3, torch.bfloat16: 3e-2}
+DTYPES = [torch.float32, torch.bfloat16]
+
+
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need the MI355X"
+    return torch.device("cuda:0")
+
+
+def T(a, dtype=torch.float32, grad=False):
+    t = torch.from_numpy(np.asarray(a)).to(dtype)
+    return t.requires_grad_(grad)
+
+
+def rel(a, b):
+    a = a.detach().float().cpu().numpy() if isinstance(a, torch.Tensor) else np.asarray(a, dtype=np.float32)
+    b = b.detach().float().cpu().numpy() if isinstance(b, torch.Tensor) else np.asarray(b, dtype=np.float32)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    assert np.isfinite(a).all()
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-3))
+
+
+def close(a, b, tol, what=""):
+    e = rel(a, b)
+    assert e < tol, "%s rel err %.3e >= %.1e" % (what, e, tol)
+
+
+def load_module(mod, params, dtype=None):
+    mod.load_state_dict({k: v.float() for k, v in params.items()})
+    return mod.to(dev())
+
+
+def check_param_grads(mod, arrs, tol, scale=1.0):
+    named = dict(mod.named_parameters())
+    for k, g in arrs.items():
+        if k.startswith("grad."):
+            close(named[k[5:]].grad * scale, g, tol, k)
+
+
+# ------------------------------------------------------------------------------------------------
+# building blocks
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("shape", [(70, 96, 128), (257, 174, 768), (300, 384, 64), (5, 12, 4)])
+def test_linear_and_mlp(oracle, dtype, shape):
+    from focus_amd import ops
+    M, N, K = shape
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(M, K, generator=g)
+    w1, b1 = torch.randn(N, K, generator=g) * K ** -0.5, torch.randn(N, generator=g)
+    w2, b2 = torch.randn(K, N, generator=g) * N ** -0.5, torch.randn(K, generator=g)
+    ct = torch.randn(M, K, generator=g)
+    p = {"m.fc1.weight": w1.clone().requires_grad_(), "m.fc1.bias": b1.clone().requires_grad_(),
+         "m.fc2.weight": w2.clone().requires_grad_(), "m.fc2.bias": b2.clone().requires_grad_()}
+    xr = x.clone().requires_grad_()
+    ref = xr + oracle.mlp(p, "m", xr)
+    (ref * ct).sum().backward()
+    d = dev()
+    xg = x.to(d, dtype).requires_grad_()
+    P = {k: v.detach().to(d).requires_grad_() for k, v in p.items()}
+    out = ops.mlp(xg, P["m.fc1.weight"], P["m.fc1.bias"], P["m.fc2.weight"], P["m.fc2.bias"], residual=xg)
+    (out.float() * ct.to(d)).sum().backward()
+    tol = TOL[dtype]
+    close(out, ref, tol, "mlp out")
+    close(xg.grad, xr.grad, tol, "dx")
+    for k in p:
+        close(P[k].grad, p[k].grad, tol, k)
+    # plain linear with the head-like odd N
+    y = ops.linear(xg.detach(), P["m.fc1.weight"].detach(), P["m.fc1.bias"].detach())
+    close(y, x @ w1.t() + b1, tol, "linear")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("rows,D", [(37, 64), (1569, 768), (3, 192), (50, 12)])
+def test_layernorm(oracle, dtype, rows, D):
+    from focus_amd import ops
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(rows, D, generator=g) * 2 + 0.5
+    w, b = 1 + 0.1 * torch.randn(D, generator=g), 0.1 * torch.randn(D, generator=g)
+    ct = torch.randn(rows, D, generator=g)
+    p = {"n.weight": w.clone().requires_grad_(), "n.bias": b.clone().requires_grad_()}
+    xr = x.clone().requires_grad_()
+    ref = oracle.layer_norm(p, "n", xr, 1e-6)
+    (ref * ct).sum().backward()
+    d = dev()
+    xg = x.to(d, dtype).requires_grad_()
+    wg, bg = w.to(d).requires_grad_(), b.to(d).requires_grad_()
+    out = ops.layer_norm(xg, wg, bg, 1e-6)
+    (out.float() * ct.to(d)).sum().backward()
+    tol = TOL[dtype]
+    close(out, ref, tol, "y")
+    close(xg.grad, xr.grad, tol * 2, "dx")
+    close(wg.grad, p["n.weight"].grad, tol * 2, "dgamma")
+    close(bg.grad, p["n.bias"].grad, tol * 2, "dbeta")
+
+
+# ------------------------------------------------------------------------------------------------
+# trajectory attention and blocks against the reference-generated fixtures
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("fx", ["traj_attn", "traj_attn_p21"])
+def test_trajectory_attention_golden(dtype, fx):
+    from focus_amd.slowfast.models.attention import TrajectoryAttention
+    a, p = load_golden(fx)
+    C = a["x"].shape[-1]
+    m = load_module(TrajectoryAttention(C, num_heads=int(a["heads"]), qkv_bias=True), p)
+    x = T(a["x"]).to(dev(), dtype).requires_grad_()
+    y, _ = m(x, [int(v) for v in a["thw"]])
+    (y.float() * T(a["ct"]).to(dev())).sum().backward()
+    tol = TOL[dtype]
+    close(y, a["y"], tol, "y")
+    close(x.grad, a["dx"], tol, "dx")
+    check_param_grads(m, a, tol)
+    assert float(m.proj_kv.weight.grad[C:].abs().max()) == 0.0      # dead v2 half
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_blocks_golden(dtype):
+    from functools import partial
+    from focus_amd.slowfast.models.attention import SeltAttentionBlock, TrajectoryAttentionBlock
+    ln = partial(torch.nn.LayerNorm, eps=1e-6)
+    tol = TOL[dtype]
+    a, p = load_golden("traj_block")
+    m = load_module(TrajectoryAttentionBlock(dim=64, num_heads=4, qkv_bias=True, norm_layer=ln), p)
+    x = T(a["x"]).to(dev(), dtype).requires_grad_()
+    y, _ = m(x, None, [2, 4, 4])
+    (y.float() * T(a["ct"]).to(dev())).sum().backward()
+    close(y, a["y"], tol, "block y")
+    close(x.grad, a["dx"], tol, "block dx")
+    check_param_grads(m, a, tol)
+    a, p = load_golden("joint_block")
+    m = load_module(SeltAttentionBlock(dim=64, num_heads=4, qkv_bias=True, norm_layer=ln), p)
+    x = T(a["x"]).to(dev(), dtype).requires_grad_()
+    y, _ = m(x, None, None)
+    (y.float() * T(a["ct"]).to(dev())).sum().backward()
+    close(y, a["y"], tol, "joint y")
+    close(x.grad, a["dx"], tol, "joint dx")
+    check_param_grads(m, a, tol)
+
+
+def _small_cfg(mixed):
+    from focus_amd.slowfast.config.defaults import get_cfg
+    cfg = get_cfg()
+    cfg.merge_from_list(["ORVIT.ENABLE", True, "ORVIT.O", 3, "ORVIT.LAYERS", [1], "DATA.TRAIN_CROP_SIZE", 64,
+                         "DATA.NUM_FRAMES", 4, "MF.EMBED_DIM", 64, "MF.DEPTH", 3, "MF.NUM_HEADS", 4,
+                         "MF.TEMPORAL_RESOLUTION", 2, "MF.USE_MLP", True, "MODEL.NUM_CLASSES", 10,
+                         "MODEL.MODEL_NAME", "Motionformer", "TRAIN.DATASET", "Ssv2", "NUM_GPUS", 1,
+                         "TRAIN.MIXED_PRECISION", mixed, "MODEL.LOSS_FUNC", "label_smoothing_cross_entropy"])
+    return cfg
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_orvit_block_golden(dtype):
+    from functools import partial
+    from focus_amd.slowfast.models.ORViT import ORViT
+    a, p = load_golden("orvit_block")
+    cfg = _small_cfg(dtype == torch.bfloat16)
+    m = load_module(ORViT(cfg=cfg, dim=64, num_heads=4, mlp_ratio=4, qkv_bias=True,
+                          norm_layer=partial(torch.nn.LayerNorm, eps=1e-6), nb_frames=2), p)
+    x = T(a["x"]).to(dev(), dtype).requires_grad_()
+    y, _ = m(x, {"orvit_bboxes": T(a["boxes"]).to(dev())}, [2, 4, 4])
+    (y.float() * T(a["ct"]).to(dev())).sum().backward()
+    tol = TOL[dtype]
+    close(y, a["y"], tol, "orvit y")
+    close(x.grad, a["dx"], tol * 2, "orvit dx")
+    check_param_grads(m, a, tol * 2)
+
+
+@pytest.mark.parametrize("mixed", [False, True])
+def test_motionformer_small_golden(mixed):
+    from focus_amd.slowfast.models import build_model
+    from focus_amd.slowfast.models.losses import get_loss_func
+    a, p = load_golden("motionformer_small")
+    cfg = _small_cfg(mixed)
+    m = build_model(cfg)
+    m.load_state_dict({k: v.float() for k, v in p.items()})
+    m.train()
+    logits = m([T(a["x"]).to(dev())], {"orvit_bboxes": T(a["boxes"]).to(dev())})
+    tol = 3e-2 if mixed else 1e-3
+    close(logits, a["logits"], tol, "logits")
+    loss = get_loss_func(cfg)(reduction="mean")(logits, torch.from_numpy(a["labels"]).to(dev()))
+    assert abs(float(loss) - float(a["loss"])) < tol * max(1.0, abs(float(a["loss"])))
+    loss.backward()
+    check_param_grads(m, a, tol * (3 if mixed else 2))
+
+
+def test_state_dict_abi_224():
+    """Checkpoint ABI: parameter names/shapes of the full-size model equal the reference's (fixture)."""
+    from focus_amd.slowfast.config.defaults import get_cfg
+    from focus_amd.slowfast.models import build_model
+    import os
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "motionformer_224_keys.npz"))
+    cfg = get_cfg()
+    cfg.merge_from_list(["ORVIT.ENABLE", True, "ORVIT.O", 4, "ORVIT.LAYERS", [1, 6, 10], "MF.USE_MLP", True,
+                         "MODEL.NUM_CLASSES", 174, "MODEL.MODEL_NAME", "Motionformer", "DATA.NUM_FRAMES", 16,
+                         "TRAIN.DATASET", "Ssv2", "NUM_GPUS", 1])
+    sd = build_model(cfg).state_dict()
+    names = sorted(sd.keys())
+    assert names == list(z["names"])
+    assert [",".join(map(str, sd[k].shape)) for k in names] == list(z["shapes"])
+
+
+# ------------------------------------------------------------------------------------------------
+# RoIAlign / layout
+# ------------------------------------------------------------------------------------------------
+def _rand_rois(g, K, size):
+    c = torch.rand(K, 2, generator=g) * size
+    wh = torch.rand(K, 2, generator=g) * size * 0.6
+    r = torch.cat([c - wh / 2, c + wh / 2], dim=1)
+    r[0] = 0                                   # empty box
+    r[1] = torch.tensor([0.0, 0.0, size, size])  # full frame
+    r[2] = torch.tensor([-20.0, -30.0, size + 25.0, size + 10.0])  # beyond the borders
+    return r
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_roi_align_values_and_indices(oracle, dtype):
+    from focus_amd import ops
+    g = torch.Generator().manual_seed(3)
+    NI, C, H, W, K = 6, 32, 14, 14, 24
+    feat = torch.randn(NI, C, H, W, generator=g)
+    if dtype == torch.bfloat16:
+        feat = feat.bfloat16().float()
+    rois = _rand_rois(g, K, 224.0)
+    img = torch.randint(0, NI, (K,), generator=g, dtype=torch.int32)
+    for (PH, PW, scale, sr) in [(14, 14, 1 / 16, -1), (7, 5, 1 / 16, -1), (3, 3, 1 / 4, -1), (4, 4, 1 / 16, 2)]:
+        fr = feat.clone().requires_grad_()
+        ref = oracle.roi_align(fr, rois, img, (PH, PW), scale, sr, True)
+        ct = torch.randn(ref.shape, generator=g)
+        (ref * ct).sum().backward()
+        d = dev()
+        ft = feat.permute(0, 2, 3, 1).reshape(NI, H * W, C).to(d, dtype).requires_grad_()
+        out = ops.roi_align_tokens(ft, rois.to(d), img.to(d), H, W, PH, PW, scale, sr, True)
+        out_nchw = out.view(K, PH, PW, C).permute(0, 3, 1, 2)
+        (out_nchw.float() * ct.to(d)).sum().backward()
+        tol = 1e-5 if dtype == torch.float32 else 1e-2
+        close(out_nchw, ref, tol, "roi out")
+        close(ft.grad.view(NI, H, W, C).permute(0, 3, 1, 2), fr.grad, 1e-4 if dtype == torch.float32 else 2e-2, "dfeat")
+        grid_o, nbr_o = oracle.roi_align_indices(rois, H, W, (PH, PW), scale, sr, True)
+        grid_g, nbr_g = ops.roi_align_indices(rois.to(d), H, W, PH, PW, scale, sr, True)
+        assert np.array_equal(grid_g.cpu().numpy(), grid_o)       # bit-exact integer side
+        assert np.array_equal(nbr_g.cpu().numpy(), nbr_o)
+
+
+def test_roi_align_hot_path_boxes_bit_exact(oracle):
+    """The hot-path geometry itself: normalised cxcywh boxes -> pixels -> 14x14 bins on a 14x14 map."""
+    from focus_amd import ops
+    from focus_amd.slowfast.models.ORViT.utils import ObjectsCrops
+    from focus_amd.slowfast.config.defaults import get_cfg
+    g = torch.Generator().manual_seed(5)
+    boxes = torch.rand(4, 8, 4, 4, generator=g)
+    boxes[..., 2:] = 0.05 + 0.9 * boxes[..., 2:]
+    boxes[1, :, 3] = 0
+    oc = ObjectsCrops(get_cfg())
+    rois, img = oc.rois(boxes.to(dev()))
+    ref_rois = oracle.cxcywh_to_xyxy(boxes.reshape(-1, 4)).float() * 224.0
+    assert torch.equal(rois.cpu(), ref_rois)
+    grid_o, nbr_o = oracle.roi_align_indices(ref_rois, 14, 14, (14, 14), 14 / 224)
+    grid_g, nbr_g = ops.roi_align_indices(rois, 14, 14, 14, 14, 14 / 224)
+    assert np.array_equal(grid_g.cpu().numpy(), grid_o) and np.array_equal(nbr_g.cpu().numpy(), nbr_o)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_box_layout(oracle, dtype):
+    from focus_amd import ops
+    a, _ = load_golden("box_layout")
+    vecs, boxes = T(a["vecs"]), T(a["boxes"])
+    B, Tn, O, C = vecs.shape
+    H = W = a["out"].shape[-1]
+    d = dev()
+    vg = vecs.to(d, dtype).reshape(B * Tn, O, C).requires_grad_()
+    out = ops.box_layout(vg, boxes.to(d).reshape(B * Tn, O, 4), H, W)          # [NF, HW, C]
+    out5 = out.view(B, Tn, H, W, C).permute(0, 4, 1, 2, 3)
+    (out5.float() * T(a["ct"]).to(d)).sum().backward()
+    tol = TOL[dtype]
+    close(out5, a["out"], tol, "layout")
+    close(vg.grad.view(B, Tn, O, C), a["dvecs"], tol, "dvecs")
+    # larger random case against the oracle's grid_sample restatement (14x14, 4 objects, one empty)
+    g = torch.Generator().manual_seed(9)
+    bx = torch.rand(3, 2, 4, 4, generator=g) * 0.5 + 0.25
+    bx[0, 1, 2] = 0
+    vv = torch.randn(3, 2, 4, 16, generator=g)
+    ref = oracle.box_layout(vv, bx, 14, 14)
+    got = ops.box_layout(vv.to(d, dtype).reshape(6, 4, 16), bx.to(d).reshape(6, 4, 4), 14, 14)
+    close(got.view(3, 2, 14, 14, 16), ref, tol, "layout 14x14")
+
+
+# ------------------------------------------------------------------------------------------------
+# STEVE slot attention
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_slot_attention_golden(dtype):
+    from focus_amd.slowfast.models.STEVE.steve import SlotAttentionVideo
+    a, p = load_golden("slot_attention")
+    m = load_module(SlotAttentionVideo(num_iterations=int(a["iters"]), num_slots=3, input_size=12, slot_size=8,
+                                       mlp_hidden_size=16, num_predictor_blocks=int(a["pred_blocks"]),
+                                       num_predictor_heads=int(a["pred_heads"]), dropout=0.0), p)
+    d = dev()
+    inp = T(a["inputs"]).to(d, dtype).requires_grad_()
+    slots, attns = m(inp, noise=T(a["noise"]).to(d))
+    ((slots.float() * T(a["ct_slots"]).to(d)).sum() + (attns.float() * T(a["ct_attns"]).to(d)).sum()).backward()
+    tol = TOL[dtype] * (1 if dtype == torch.float32 else 3)
+    close(slots, a["slots"], tol, "slots")
+    close(attns, a["attns"], tol, "attns")
+    close(inp.grad, a["dinputs"], tol * 3, "dinputs")
+    check_param_grads(m, a, tol * 3)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_slot_attention_step_vs_oracle(oracle, dtype):
+    """BASELINE-shaped slot step (K=11, D=192) at reduced N, ragged N (not a multiple of the row chunk)."""
+    from focus_amd import ops
+    g = torch.Generator().manual_seed(11)
+    B, N, K, D = 3, 700, 11, 192
+    k = torch.randn(B, N, D, generator=g) * D ** -0.5
+    v = torch.randn(B, N, D, generator=g)
+    q = torch.randn(B, K, D, generator=g)
+    cu, ca = torch.randn(B, K, D, generator=g), torch.randn(B, N, K, generator=g)
+    kr, vr, qr = (t.clone().requires_grad_() for t in (k, v, q))
+    av = torch.softmax(kr @ qr.transpose(-1, -2), dim=-1)
+    aa = av + 1e-8
+    upd = (aa / aa.sum(dim=-2, keepdim=True)).transpose(-1, -2) @ vr
+    ((upd * cu).sum() + (av * ca).sum()).backward()
+    d = dev()
+    kg, vg, qg = (t.to(d, dtype).requires_grad_() for t in (k, v, q))
+    u2, a2 = ops.slot_attn_step(kg, vg, qg, 1e-8)
+    ((u2.float() * cu.to(d)).sum() + (a2.float() * ca.to(d)).sum()).backward()
+    tol = TOL[dtype]
+    close(u2, upd, tol, "upd")
+    close(a2, av, tol, "attn")
+    close(kg.grad, kr.grad, tol * 2, "dk")
+    close(vg.grad, vr.grad, tol * 2, "dv")
+    close(qg.grad, qr.grad, tol * 2, "dq")
