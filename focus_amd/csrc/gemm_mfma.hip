@@ -1,13 +1,18 @@
 // gemm_mfma.hip -- bf16 MFMA GEMM for gfx950:  C[M,N] = epi(alpha * A[M,K] . B[N,K]^T)  (fp32 accumulate)
 //
 // Both operands are contiguous along K (the nn.Linear forward layout: activations [M,K], weight [N,K]).
-// Tile 128(M) x 128(N) x 64(K), 256 threads = 4 waves (2x2), each wave 64x64 = 4x4 tiles of
-// v_mfma_f32_16x16x32_bf16.  Global->register->LDS staging with the next K-tile's loads issued before
-// the current tile's MFMAs (cdna_hip_programming.md T14), double-buffered LDS, one barrier per K-step,
-// XOR-swizzled 128-byte LDS rows so the ds_read_b128 fragment reads spread over 8 slots (T2).
-// The MFMA is issued "swapped" (weight fragment as A, activation fragment as B) so each lane ends up
-// with 4 consecutive output columns of one row: 8-byte (bf16) / 16-byte (fp32) stores.
-// Workgroup ids are remapped so that each XCD (private L2) walks a contiguous band of M-tiles (T1).
+//   * tiles BM x BN x 64: 256x256 (8 waves, 2x4, each wave 128x64) for large grids, 128x128 (4 waves, 2x2,
+//     each wave 64x64) when the 256-tile grid would leave CUs idle; v_mfma_f32_16x16x32_bf16;
+//   * operands go global -> LDS directly (global_load_lds_dwordx4, 1 KiB per wave instruction = 8 tile rows
+//     of 128 B), double-buffered, the next K-tile's DMA issued before the current tile's MFMAs and drained
+//     once per K-step (cdna_hip_programming.md "Minimum 2-phase"); no register staging, no ds_write;
+//   * 128-byte LDS rows are XOR-swizzled by 16-B chunk (chunk ^= row & 7); the DMA writes LDS linearly, so the
+//     swizzle is applied to the per-lane SOURCE address and again on the ds_read_b128 fragment reads (rule 21);
+//   * the MFMA is issued "swapped" (weight fragment as A operand, activation fragment as B operand) so each lane
+//     ends up with 4 consecutive output columns of one row: 8-byte (bf16) / 16-byte (fp32) epilogue accesses;
+//   * optional split-K (weight-gradient GEMMs: tiny M x N, huge K): partial sums are added with fp32 atomics
+//     into a zero-initialised C;
+//   * workgroup ids are remapped so that each XCD (private L2) walks a contiguous band of tiles (T1).
 #include "focus_common.h"
 #include "gemm_internal.h"
 
@@ -15,39 +20,35 @@ namespace {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((address_space(1))) const void gvoid_t;
+typedef __attribute__((address_space(3))) void lvoid_t;
 
-constexpr int BM = 128, BN = 128, BK = 64;
-constexpr int TILE_BYTES = BM * BK * 2;  // 16 KiB per operand per stage
+constexpr int BK = 64;
 
 __device__ __forceinline__ int swz(int row, int chunk) { return row * 128 + ((chunk ^ (row & 7)) << 4); }
 
-template <typename TC>
-__device__ __forceinline__ float epi_one(const focus_gemm_desc& d, float v, int n, const TC* X, int64_t off) {
-    v *= d.alpha;
-    if (d.bias) v += d.bias[n];
-    switch (d.epilogue) {
-        case FOCUS_EPI_GELU: v = gelu_erf(v); break;  // aux (pre-activation) handled by the caller
-        case FOCUS_EPI_RELU: v = fmaxf(v, 0.f); break;
-        case FOCUS_EPI_TANH: v = tanhf(v); break;
-        case FOCUS_EPI_DGELU: v *= dgelu_erf(ld<TC>(X + off)); break;
-        case FOCUS_EPI_DRELU: v = ld<TC>(X + off) > 0.f ? v : 0.f; break;
-        case FOCUS_EPI_DTANH: { float y = ld<TC>(X + off); v *= (1.f - y * y); } break;
-        default: break;
-    }
-    return v;
-}
+template <int BM, int BN, int WAVES_M, int WAVES_N, typename TC>
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_nt_kernel(const focus_gemm_desc d, int tiles_m,
+                                                                         int tiles_n, int splits, int k_per_split) {
+    constexpr int NW = WAVES_M * WAVES_N;
+    constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;   // per-wave output tile
+    constexpr int TM = WTM / 16, TN = WTN / 16;
+    constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
+    constexpr int GA = BM / 8 / NW, GB = BN / 8 / NW;       // DMA instructions per wave per K-step
+    static_assert(GA >= 1 && GB >= 1, "tile too small for the wave count");
+    extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 stages][A | B]
 
-template <typename TC>
-__global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const focus_gemm_desc d, int tiles_m, int tiles_n) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 stages][A 16K | B 16K]
-
-    // ---- XCD-aware tile assignment (bijective for any grid size) ----
-    const int nwg = tiles_m * tiles_n;
+    // ---- XCD-aware work assignment (bijective for any grid size) ----
+    const int nwg = tiles_m * tiles_n * splits;
     const int bid = blockIdx.x;
     const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
     const int lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-    const int tm = lid / tiles_n, tn = lid % tiles_n;
+    const int split = lid % splits, tile = lid / splits;
+    const int tm = tile / tiles_n, tn = tile % tiles_n;
     const int m0 = tm * BM, n0 = tn * BN;
+    const int k_begin = split * k_per_split;
+    const int k_end = min(d.K, k_begin + k_per_split);
+    const int nk = (k_end - k_begin) / BK;
 
     const int z = blockIdx.y;
     const int b0 = z / d.batch1, b1 = z % d.batch1;
@@ -59,125 +60,143 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const focus_gemm_desc d
     TC* X = d.aux ? static_cast<TC*>(d.aux) + coff : nullptr;
     const int64_t lda = d.rsA, ldb = d.csB;  // B is described as [K,N]: csB = stride between its N rows
 
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int wm = w >> 1, wn = w & 1;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = w / WAVES_N, wn = w % WAVES_N;
 
-    // staging map: chunk e = tid + i*256 -> (row = e>>3, chunk = e&7); 8 threads cover one 128-B row
-    uint4 ra[4], rb[4];
-    auto g_load = [&](int kt) {
+    // DMA source addresses: instruction g of this wave fills tile rows (w*G + g)*8 .. +7; lane -> (row, chunk).
+    // Rows past M/N are clamped to the last valid row (their products are never stored).
+    const int lrow = lane >> 3, cpos = lane & 7, csrc = (cpos ^ lrow) * 8;
+    const bf16_t* a_src[GA];
+    const bf16_t* b_src[GB];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int e = tid + i * 256, row = e >> 3, c = e & 7;
-            const int gm = m0 + row, gn = n0 + row;
-            const int64_t ko = (int64_t)kt * BK + c * 8;
-            ra[i] = gm < d.M ? *reinterpret_cast<const uint4*>(A + gm * lda + ko) : make_uint4(0, 0, 0, 0);
-            rb[i] = gn < d.N ? *reinterpret_cast<const uint4*>(B + gn * ldb + ko) : make_uint4(0, 0, 0, 0);
-        }
+    for (int g = 0; g < GA; ++g) {
+        const int row = min(m0 + (w * GA + g) * 8 + lrow, d.M - 1);
+        a_src[g] = A + row * lda + k_begin + csrc;
+    }
+#pragma unroll
+    for (int g = 0; g < GB; ++g) {
+        const int row = min(n0 + (w * GB + g) * 8 + lrow, d.N - 1);
+        b_src[g] = B + row * ldb + k_begin + csrc;
+    }
+    auto stage = [&](int st, int kt) {
+        char* sa = smem + st * STAGE;
+        char* sb = sa + A_BYTES;
+#pragma unroll
+        for (int g = 0; g < GA; ++g)
+            __builtin_amdgcn_global_load_lds((gvoid_t*)(a_src[g] + kt * BK), (lvoid_t*)(sa + (w * GA + g) * 1024), 16, 0, 0);
+#pragma unroll
+        for (int g = 0; g < GB; ++g)
+            __builtin_amdgcn_global_load_lds((gvoid_t*)(b_src[g] + kt * BK), (lvoid_t*)(sb + (w * GB + g) * 1024), 16, 0, 0);
     };
-    auto s_store = [&](int stage) {
-        char* sa = smem + stage * 2 * TILE_BYTES;
-        char* sb = sa + TILE_BYTES;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int e = tid + i * 256, row = e >> 3, c = e & 7;
-            *reinterpret_cast<uint4*>(sa + swz(row, c)) = ra[i];
-            *reinterpret_cast<uint4*>(sb + swz(row, c)) = rb[i];
-        }
-    };
 
-    f32x4 acc[4][4];
+    f32x4 acc[TM][TN];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-    const int nk = d.K / BK;
-    g_load(0);
-    s_store(0);
-    __syncthreads();
+        for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     const int frow = lane & 15, fq = lane >> 4;
-    for (int kt = 0; kt < nk; ++kt) {
-        const int stage = kt & 1;
-        if (kt + 1 < nk) g_load(kt + 1);
-        const char* sa = smem + stage * 2 * TILE_BYTES;
-        const char* sb = sa + TILE_BYTES;
+    auto compute = [&](int st) {
+        const char* sa = smem + st * STAGE;
+        const char* sb = sa + A_BYTES;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            bf16x8 fa[4], fb[4];
+            bf16x8 fa[TM], fb[TN];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int row = wm * 64 + i * 16 + frow;
-                fa[i] = *reinterpret_cast<const bf16x8*>(sa + swz(row, ks * 4 + fq));
-            }
+            for (int i = 0; i < TM; ++i)
+                fa[i] = *reinterpret_cast<const bf16x8*>(sa + swz(wm * WTM + i * 16 + frow, ks * 4 + fq));
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int row = wn * 64 + j * 16 + frow;
-                fb[j] = *reinterpret_cast<const bf16x8*>(sb + swz(row, ks * 4 + fq));
-            }
+            for (int j = 0; j < TN; ++j)
+                fb[j] = *reinterpret_cast<const bf16x8*>(sb + swz(wn * WTN + j * 16 + frow, ks * 4 + fq));
+            __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
+                for (int j = 0; j < TN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
         }
-        if (kt + 1 < nk) s_store(stage ^ 1);
+    };
+
+    if (nk > 0) {
+        stage(0, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+        // two K-steps per iteration so that both LDS stage offsets are compile-time constants
+        int kt = 0;
+        for (; kt + 1 < nk; kt += 2) {
+            stage(1, kt + 1);
+            compute(0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (kt + 2 < nk) stage(0, kt + 2);
+            compute(1);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+        if (kt < nk) compute(0);
     }
 
-    // ---- epilogue: acc[i][j][r] = D[n = n0+wn*64+j*16+fq*4+r][m = m0+wm*64+i*16+frow] ----
+    // ---- epilogue: acc[i][j][r] = D[n = n0+wn*WTN+j*16+fq*4+r][m = m0+wm*WTM+i*16+frow] ----
     const size_t va = 4 * sizeof(TC);
     const bool vec_ok = (d.csC == 1) && ((d.rsC & 3) == 0) && (reinterpret_cast<uintptr_t>(C) % va == 0) &&
                         (!R || reinterpret_cast<uintptr_t>(R) % va == 0) &&
                         (!X || reinterpret_cast<uintptr_t>(X) % va == 0);
+    const bool atomic = splits > 1;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int gm = m0 + wm * 64 + i * 16 + frow;
+    for (int i = 0; i < TM; ++i) {
+        const int gm = m0 + wm * WTM + i * 16 + frow;
         if (gm >= d.M) continue;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int gn = n0 + wn * 64 + j * 16 + fq * 4;
+        for (int j = 0; j < TN; ++j) {
+            const int gn = n0 + wn * WTN + j * 16 + fq * 4;
             if (gn >= d.N) continue;
             const int64_t off = gm * d.rsC + (int64_t)gn * d.csC;
-            float v[4];
-            if (vec_ok && gn + 3 < d.N) {
-                if (d.epilogue == FOCUS_EPI_GELU && X) {
-                    f4 pre;
-                    pre.x = d.alpha * acc[i][j][0] + (d.bias ? d.bias[gn] : 0.f);
-                    pre.y = d.alpha * acc[i][j][1] + (d.bias ? d.bias[gn + 1] : 0.f);
-                    pre.z = d.alpha * acc[i][j][2] + (d.bias ? d.bias[gn + 2] : 0.f);
-                    pre.w = d.alpha * acc[i][j][3] + (d.bias ? d.bias[gn + 3] : 0.f);
-                    st4<TC>(X + off, pre);
-                }
-                f4 xa = {0.f, 0.f, 0.f, 0.f};
-                if (d.epilogue >= FOCUS_EPI_DGELU) xa = ld4<TC>(X + off);
-                const float xs[4] = {xa.x, xa.y, xa.z, xa.w};
+            if (atomic) {
+                if constexpr (sizeof(TC) == 4) {
 #pragma unroll
-                for (int r4 = 0; r4 < 4; ++r4) {
-                    float t = d.alpha * acc[i][j][r4];
-                    if (d.bias) t += d.bias[gn + r4];
-                    switch (d.epilogue) {
-                        case FOCUS_EPI_GELU: t = gelu_erf(t); break;
-                        case FOCUS_EPI_RELU: t = fmaxf(t, 0.f); break;
-                        case FOCUS_EPI_TANH: t = tanhf(t); break;
-                        case FOCUS_EPI_DGELU: t *= dgelu_erf(xs[r4]); break;
-                        case FOCUS_EPI_DRELU: t = xs[r4] > 0.f ? t : 0.f; break;
-                        case FOCUS_EPI_DTANH: t *= (1.f - xs[r4] * xs[r4]); break;
-                        default: break;
-                    }
-                    v[r4] = t;
+                    for (int r4 = 0; r4 < 4; ++r4)
+                        if (gn + r4 < d.N) atomicAdd(reinterpret_cast<float*>(C) + off + (int64_t)r4 * d.csC, d.alpha * acc[i][j][r4]);
                 }
-                if (R) { f4 rr = ld4<TC>(R + off); v[0] += rr.x; v[1] += rr.y; v[2] += rr.z; v[3] += rr.w; }
-                if (d.accumulate) { f4 cc = ld4<TC>(C + off); v[0] += cc.x; v[1] += cc.y; v[2] += cc.z; v[3] += cc.w; }
+                continue;
+            }
+            float v[4];
+            const bool full = vec_ok && gn + 3 < d.N;
+            float xs[4] = {0.f, 0.f, 0.f, 0.f};
+            if (d.epilogue >= FOCUS_EPI_DGELU) {
+                if (full) { const f4 xa = ld4<TC>(X + off); xs[0] = xa.x; xs[1] = xa.y; xs[2] = xa.z; xs[3] = xa.w; }
+                else
+                    for (int r4 = 0; r4 < 4; ++r4) if (gn + r4 < d.N) xs[r4] = ld<TC>(X + off + (int64_t)r4 * d.csC);
+            }
+            float pre[4];
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+                float t = d.alpha * acc[i][j][r4];
+                if (d.bias && gn + r4 < d.N) t += d.bias[gn + r4];
+                pre[r4] = t;
+                switch (d.epilogue) {
+                    case FOCUS_EPI_GELU: t = gelu_erf(t); break;
+                    case FOCUS_EPI_RELU: t = fmaxf(t, 0.f); break;
+                    case FOCUS_EPI_TANH: t = tanhf(t); break;
+                    case FOCUS_EPI_DGELU: t *= dgelu_erf(xs[r4]); break;
+                    case FOCUS_EPI_DRELU: t = xs[r4] > 0.f ? t : 0.f; break;
+                    case FOCUS_EPI_DTANH: t *= (1.f - xs[r4] * xs[r4]); break;
+                    default: break;
+                }
+                v[r4] = t;
+            }
+            if (full) {
+                if (d.epilogue == FOCUS_EPI_GELU && X) st4<TC>(X + off, (f4){pre[0], pre[1], pre[2], pre[3]});
+                if (R) { const f4 rr = ld4<TC>(R + off); v[0] += rr.x; v[1] += rr.y; v[2] += rr.z; v[3] += rr.w; }
+                if (d.accumulate) { const f4 cc = ld4<TC>(C + off); v[0] += cc.x; v[1] += cc.y; v[2] += cc.z; v[3] += cc.w; }
                 st4<TC>(C + off, (f4){v[0], v[1], v[2], v[3]});
             } else {
-#pragma unroll
                 for (int r4 = 0; r4 < 4; ++r4) {
                     if (gn + r4 >= d.N) break;
                     const int64_t o = off + (int64_t)r4 * d.csC;
-                    if (d.epilogue == FOCUS_EPI_GELU && X)
-                        st<TC>(X + o, d.alpha * acc[i][j][r4] + (d.bias ? d.bias[gn + r4] : 0.f));
-                    float t = epi_one<TC>(d, acc[i][j][r4], gn + r4, X, o);
+                    if (d.epilogue == FOCUS_EPI_GELU && X) st<TC>(X + o, pre[r4]);
+                    float t = v[r4];
                     if (R) t += ld<TC>(R + o);
                     if (d.accumulate) t += ld<TC>(C + o);
                     st<TC>(C + o, t);
@@ -185,6 +204,32 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const focus_gemm_desc d
             }
         }
     }
+}
+
+template <int BM, int BN, int WAVES_M, int WAVES_N>
+int launch_nt(const focus_gemm_desc& d, int splits, hipStream_t s) {
+    const int tiles_m = (d.M + BM - 1) / BM, tiles_n = (d.N + BN - 1) / BN;
+    const int nbatch = d.batch0 * d.batch1;
+    int k_per_split = d.K;
+    if (splits > 1) {
+        k_per_split = ((d.K / BK + splits - 1) / splits) * BK;
+        splits = (d.K + k_per_split - 1) / k_per_split;
+    }
+    dim3 grid(tiles_m * tiles_n * splits, nbatch), blk(64 * WAVES_M * WAVES_N);
+    constexpr size_t lds = 2 * (BM + BN) * 128;
+    if (d.dtype_c == FOCUS_BF16) {
+        auto k = gemm_nt_kernel<BM, BN, WAVES_M, WAVES_N, bf16_t>;
+        static bool once = (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds) == hipSuccess);
+        (void)once;
+        hipLaunchKernelGGL(k, grid, blk, lds, s, d, tiles_m, tiles_n, splits, k_per_split);
+    } else {
+        auto k = gemm_nt_kernel<BM, BN, WAVES_M, WAVES_N, float>;
+        static bool once = (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds) == hipSuccess);
+        (void)once;
+        hipLaunchKernelGGL(k, grid, blk, lds, s, d, tiles_m, tiles_n, splits, k_per_split);
+    }
+    FOCUS_CHECK_LAUNCH();
+    return FOCUS_OK;
 }
 
 }  // namespace
@@ -201,17 +246,23 @@ bool focus_gemm_mfma_nt_ok(const focus_gemm_desc& d) {
 
 int focus_gemm_mfma_nt(const focus_gemm_desc& d, hipStream_t s) {
     if (!focus_gemm_mfma_nt_ok(d)) return FOCUS_ERR_ALIGN;
-    const int tiles_m = (d.M + BM - 1) / BM, tiles_n = (d.N + BN - 1) / BN;
     const int nbatch = d.batch0 * d.batch1;
     if (nbatch > 65535) return FOCUS_ERR_SHAPE;
-    dim3 grid(tiles_m * tiles_n, nbatch);
-    const size_t lds = 4 * TILE_BYTES;
-    if (d.dtype_c == FOCUS_BF16)
-        hipLaunchKernelGGL((gemm_nt_kernel<bf16_t>), grid, dim3(256), lds, s, d, tiles_m, tiles_n);
-    else
-        hipLaunchKernelGGL((gemm_nt_kernel<float>), grid, dim3(256), lds, s, d, tiles_m, tiles_n);
-    FOCUS_CHECK_LAUNCH();
-    return FOCUS_OK;
+    constexpr int CUS = 256;
+    const int64_t t256 = (int64_t)((d.M + 255) / 256) * ((d.N + 255) / 256) * nbatch;
+    const int64_t t128 = (int64_t)((d.M + 127) / 128) * ((d.N + 127) / 128) * nbatch;
+    // split-K only for plain fp32-output products (weight gradients): tiny output, long reduction
+    const bool can_split = d.dtype_c == FOCUS_F32 && d.epilogue == FOCUS_EPI_NONE && !d.bias && !d.residual &&
+                           d.accumulate && nbatch == 1;
+    if (can_split && t128 < CUS && d.K >= 1024) {
+        int splits = (int)std::min<int64_t>((2 * CUS + t128 - 1) / t128, d.K / 256);
+        if (splits < 1) splits = 1;
+        return launch_nt<128, 128, 2, 2>(d, splits, s);
+    }
+    // TODO(perf): a 256x256 / 8-wave instantiation exists in the template but hipcc spills its 128 accumulator
+    // registers at TM=8,TN=4; until the fragment loads are restructured everything runs the 128x128 tile.
+    (void)t256;
+    return launch_nt<128, 128, 2, 2>(d, 1, s);
 }
 
 // ---- public dispatcher ---------------------------------------------------------------------------

@@ -121,17 +121,21 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
     }
 }
 
-__global__ void ln_bwd_finish(const float* __restrict__ partial, float* __restrict__ dgamma,
-                              float* __restrict__ dbeta, int nblk, int D) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= D) return;
-    float a = 0.f, b = 0.f;
-    for (int k = 0; k < nblk; ++k) {
-        a += partial[(int64_t)k * D + c];
-        b += partial[(int64_t)(nblk + k) * D + c];
+// grid (ceil(D/64), 2): 64 columns per block, 4 row-lanes; blockIdx.y selects dgamma / dbeta
+__global__ __launch_bounds__(256) void ln_bwd_finish(const float* __restrict__ partial, float* __restrict__ dgamma,
+                                                     float* __restrict__ dbeta, int nblk, int D) {
+    __shared__ float red[4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), r4 = threadIdx.x >> 6;
+    const float* p = partial + (int64_t)blockIdx.y * nblk * D;
+    float a = 0.f;
+    if (c < D)
+        for (int k = r4; k < nblk; k += 4) a += p[(int64_t)k * D + c];
+    red[r4][threadIdx.x & 63] = a;
+    __syncthreads();
+    if (r4 == 0 && c < D) {
+        const int l = threadIdx.x;
+        (blockIdx.y == 0 ? dgamma : dbeta)[c] = red[0][l] + red[1][l] + red[2][l] + red[3][l];
     }
-    dgamma[c] = a;
-    dbeta[c] = b;
 }
 
 template <typename T>
@@ -176,7 +180,7 @@ extern "C" int focus_layernorm_fwd(const void* x, const float* gamma, const floa
 
 extern "C" int focus_layernorm_bwd_blocks(int rows) {
     int b = (rows + 3) / 4;
-    return b < 1 ? 1 : (b > 1024 ? 1024 : b);
+    return b < 1 ? 1 : (b > 256 ? 256 : b);
 }
 
 extern "C" int focus_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean,
@@ -189,7 +193,7 @@ extern "C" int focus_layernorm_bwd(const void* dy, const void* x, const float* g
     int rc = dtype == FOCUS_BF16 ? ln_bwd_launch<bf16_t>(dy, x, gamma, mean, rstd, dx, partial, rows, D, nblk, s)
                                  : ln_bwd_launch<float>(dy, x, gamma, mean, rstd, dx, partial, rows, D, nblk, s);
     if (rc) return rc;
-    hipLaunchKernelGGL(ln_bwd_finish, dim3((D + 255) / 256), dim3(256), 0, s, partial, dgamma, dbeta, nblk, D);
+    hipLaunchKernelGGL(ln_bwd_finish, dim3((D + 63) / 64, 2), dim3(256), 0, s, partial, dgamma, dbeta, nblk, D);
     FOCUS_CHECK_LAUNCH();
     return FOCUS_OK;
 }

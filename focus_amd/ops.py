@@ -44,6 +44,15 @@ def _p(t, off=0):
     return ctypes.c_void_p(t.data_ptr() + off * t.element_size())
 
 
+# bench.py sets this to a list to collect (flops, start_event, end_event) for every MFMA-path GEMM launch
+GEMM_TIMING = None
+
+
+def _mfma_path(ta, sA, sB, K):
+    return (ta.dtype == torch.bfloat16 and sA[1] == 1 and sB[0] == 1 and K > 0 and K % 64 == 0 and
+            sA[0] % 8 == 0 and sB[1] % 8 == 0)
+
+
 def gemm(M, N, K, A, sA, B, sB, C, sC, batch=(1, 1), bias=None, residual=None, aux=None, alpha=1.0,
          accumulate=False, epilogue=EPI_NONE):
     """C = epi(alpha*A.B + bias) + residual.  A/B/C are (tensor, element_offset); s* = (rs, cs, bs0, bs1)."""
@@ -64,6 +73,13 @@ def gemm(M, N, K, A, sA, B, sB, C, sC, batch=(1, 1), bias=None, residual=None, a
     d.dtype_ab = _dt(ta)
     d.dtype_c = _dt(tc)
     assert ta.dtype == tb.dtype
+    if GEMM_TIMING is not None and _mfma_path(ta, sA, sB, K):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        _lib.check(_lib.lib().focus_gemm(ctypes.byref(d), _stream()), "gemm")
+        e1.record()
+        GEMM_TIMING.append((2.0 * M * N * K * batch[0] * batch[1], e0, e1))
+        return
     _lib.check(_lib.lib().focus_gemm(ctypes.byref(d), _stream()), "gemm")
 
 
@@ -103,12 +119,14 @@ def mm_tn(a, b):
     by focus_transpose_pad and fed to the MFMA kernel; fp32: strided generic kernel."""
     M, N = a.shape
     K = b.shape[1]
-    c = torch.empty(N, K, device=a.device, dtype=torch.float32)
     if a.dtype == torch.bfloat16:
         at, bt = transpose_pad(a), transpose_pad(b)
         Mp = at.shape[1]
-        gemm(N, K, Mp, (at, 0), (Mp, 1, 0, 0), (bt, 0), (1, Mp, 0, 0), (c, 0), (K, 1, 0, 0))
+        # zero-initialised + accumulate: lets the C side split the long reduction over workgroups (fp32 atomics)
+        c = torch.zeros(N, K, device=a.device, dtype=torch.float32)
+        gemm(N, K, Mp, (at, 0), (Mp, 1, 0, 0), (bt, 0), (1, Mp, 0, 0), (c, 0), (K, 1, 0, 0), accumulate=True)
     else:
+        c = torch.empty(N, K, device=a.device, dtype=torch.float32)
         gemm(N, K, M, (a, 0), (1, a.stride(0), 0, 0), (b, 0), (b.stride(0), 1, 0, 0), (c, 0), (K, 1, 0, 0))
     return c
 

@@ -1,0 +1,43 @@
+"""One optimizer step of the supervised loop, in the reference's order (tools/train_net.py:68-121):
+H2D -> forward -> loss -> NaN check -> zero_grad -> backward (DDP all-reduce overlapped) -> clip-norm -> step.
+
+Differences that follow from the MI355X design and are deliberate:
+  * TRAIN.MIXED_PRECISION selects bf16 storage with fp32 accumulation inside the HIP kernels instead of fp16
+    autocast, so no GradScaler is needed (scale/unscale/update are identities);
+  * the per-scalar blocking metric all-reduces (train_net.py:247-250) are packed into one collective
+    (focus_amd/slowfast/utils/distributed.py:all_reduce).
+"""
+import torch
+
+from .slowfast.utils import misc
+
+
+def train_step(model, optimizer, loss_fun, inputs, labels, meta, cfg, check_nan=True):
+    preds = model(inputs, meta)                                   # train_net.py:86
+    loss = loss_fun(preds, labels)                                # :91-99
+    if check_nan:
+        misc.check_nan_losses(float(loss))                        # :102 (host sync, as in the reference)
+    optimizer.zero_grad(set_to_none=True)                         # :105
+    loss.backward()                                               # :106
+    if cfg.SOLVER.CLIP_GRAD_VAL:
+        torch.nn.utils.clip_grad_value_(model.parameters(), cfg.SOLVER.CLIP_GRAD_VAL)      # :108-111
+    elif cfg.SOLVER.CLIP_GRAD_L2NORM:
+        torch.nn.utils.clip_grad_norm_(model.parameters(), cfg.SOLVER.CLIP_GRAD_L2NORM)    # :112-117
+    optimizer.step()                                              # :120
+    return preds, loss
+
+
+def synthetic_batch(cfg, batch, device, seed=0):
+    """Synthetic clips of BASELINE.md section 3: frames ~ N(0,1) [B,3,T,H,W], boxes [B,T,O,4] cxcywh with
+    cx,cy ~ U(0.3,0.7), w,h ~ U(0.1,0.5) kept inside the frame, one object slot emptied, labels ~ randint.
+    Drawn with a CPU generator so every box/rank sees the same numbers for a given seed."""
+    g = torch.Generator().manual_seed(seed)
+    Tn, S, O = cfg.DATA.NUM_FRAMES, cfg.DATA.TRAIN_CROP_SIZE, cfg.ORVIT.O
+    x = torch.randn(batch, 3, Tn, S, S, generator=g)
+    wh = 0.1 + 0.4 * torch.rand(batch, Tn, O, 2, generator=g)
+    c = 0.3 + 0.4 * torch.rand(batch, Tn, O, 2, generator=g)
+    c = torch.minimum(torch.maximum(c, wh / 2), 1 - wh / 2)
+    boxes = torch.cat([c, wh], dim=-1)
+    boxes[batch - 1, :, O - 1] = 0                                 # empty-box path
+    labels = torch.randint(0, cfg.MODEL.NUM_CLASSES, (batch,), generator=g)
+    return [x.to(device)], labels.to(device), {"orvit_bboxes": boxes.to(device)}
