@@ -15,6 +15,8 @@
 //   * workgroup ids are remapped so that each XCD (private L2) walks a contiguous band of tiles (T1).
 #include "focus_common.h"
 #include "gemm_internal.h"
+#include <cstdlib>
+#include <type_traits>
 
 namespace {
 
@@ -27,8 +29,13 @@ constexpr int BK = 64;
 
 __device__ __forceinline__ int swz(int row, int chunk) { return row * 128 + ((chunk ^ (row & 7)) << 4); }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, typename TC>
-__global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_nt_kernel(const focus_gemm_desc d, int tiles_m,
+// One workgroup is persistent: it walks work units (output tile x K-split) u = first, first+stride, ... and treats
+// their K-steps as ONE stream, so the DMA for the next K-step -- including the first K-step of the NEXT tile -- is
+// always issued before the current step's MFMAs.  The pipeline is filled once per workgroup instead of once per
+// tile and every epilogue runs under the next tile's DMA flight (at K=768 a tile is only 12 K-steps long, so the
+// per-tile fill/drain was ~half of the time).
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool LDSEPI, typename TC>
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void gemm_nt_kernel(const focus_gemm_desc d, int tiles_m,
                                                                          int tiles_n, int splits, int k_per_split) {
     constexpr int NW = WAVES_M * WAVES_N;
     constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;   // per-wave output tile
@@ -37,18 +44,6 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_nt_kernel(const f
     constexpr int GA = BM / 8 / NW, GB = BN / 8 / NW;       // DMA instructions per wave per K-step
     static_assert(GA >= 1 && GB >= 1, "tile too small for the wave count");
     extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 stages][A | B]
-
-    // ---- XCD-aware work assignment (bijective for any grid size) ----
-    const int nwg = tiles_m * tiles_n * splits;
-    const int bid = blockIdx.x;
-    const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
-    const int lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-    const int split = lid % splits, tile = lid / splits;
-    const int tm = tile / tiles_n, tn = tile % tiles_n;
-    const int m0 = tm * BM, n0 = tn * BN;
-    const int k_begin = split * k_per_split;
-    const int k_end = min(d.K, k_begin + k_per_split);
-    const int nk = (k_end - k_begin) / BK;
 
     const int z = blockIdx.y;
     const int b0 = z / d.batch1, b1 = z % d.batch1;
@@ -63,41 +58,69 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_nt_kernel(const f
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = w / WAVES_N, wn = w % WAVES_N;
-
-    // DMA source addresses: instruction g of this wave fills tile rows (w*G + g)*8 .. +7; lane -> (row, chunk).
-    // Rows past M/N are clamped to the last valid row (their products are never stored).
+    const int frow = lane & 15, fq = lane >> 4;
     const int lrow = lane >> 3, cpos = lane & 7, csrc = (cpos ^ lrow) * 8;
+
+    // ---- XCD-aware unit assignment: XCD x (= blockIdx.x & 7) owns a contiguous band of units and deals them
+    // round-robin to its resident workgroups, so neighbours in the band (same A row panel) run together (T1) ----
+    const int nunits = tiles_m * tiles_n * splits;
+    const int G = gridDim.x, xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int gx = (G >> 3) + (xcd < (G & 7) ? 1 : 0);                 // workgroups living on this XCD label
+    const int q = nunits >> 3, r = nunits & 7;
+    const int band0 = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    const int band_n = q + (xcd < r ? 1 : 0);
+    const int my_units = j < band_n ? (band_n - j + gx - 1) / gx : 0;
+
+    struct Unit { int m0, n0, k0, nk; };
+    auto unit_of = [&](int i) __attribute__((always_inline)) {
+        const int u = band0 + j + i * gx;
+        const int split = u % splits, tile = u / splits;
+        Unit t;
+        t.m0 = (tile / tiles_n) * BM;
+        t.n0 = (tile % tiles_n) * BN;
+        t.k0 = split * k_per_split;
+        t.nk = (min(d.K, t.k0 + k_per_split) - t.k0) / BK;
+        return t;
+    };
+
+    // DMA issue cursor (runs one K-step ahead of the compute cursor)
     const bf16_t* a_src[GA];
     const bf16_t* b_src[GB];
+    int iu = 0, ikt = 0, ink = 0;
+    auto issue_setup = [&](int i) __attribute__((always_inline)) {
+        const Unit t = unit_of(i);
+        ink = t.nk;
 #pragma unroll
-    for (int g = 0; g < GA; ++g) {
-        const int row = min(m0 + (w * GA + g) * 8 + lrow, d.M - 1);
-        a_src[g] = A + row * lda + k_begin + csrc;
-    }
+        for (int g = 0; g < GA; ++g)
+            a_src[g] = A + (int64_t)min(t.m0 + (w * GA + g) * 8 + lrow, d.M - 1) * lda + t.k0 + csrc;
 #pragma unroll
-    for (int g = 0; g < GB; ++g) {
-        const int row = min(n0 + (w * GB + g) * 8 + lrow, d.N - 1);
-        b_src[g] = B + row * ldb + k_begin + csrc;
-    }
-    auto stage = [&](int st, int kt) {
+        for (int g = 0; g < GB; ++g)
+            b_src[g] = B + (int64_t)min(t.n0 + (w * GB + g) * 8 + lrow, d.N - 1) * ldb + t.k0 + csrc;
+    };
+    auto issue = [&](int st) __attribute__((always_inline)) {      // DMA of the cursor's K-step into LDS stage `st`, then advance the cursor
+        if (iu >= my_units) return;
         char* sa = smem + st * STAGE;
         char* sb = sa + A_BYTES;
 #pragma unroll
         for (int g = 0; g < GA; ++g)
-            __builtin_amdgcn_global_load_lds((gvoid_t*)(a_src[g] + kt * BK), (lvoid_t*)(sa + (w * GA + g) * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gvoid_t*)(a_src[g] + ikt * BK), (lvoid_t*)(sa + (w * GA + g) * 1024), 16, 0, 0);
 #pragma unroll
         for (int g = 0; g < GB; ++g)
-            __builtin_amdgcn_global_load_lds((gvoid_t*)(b_src[g] + kt * BK), (lvoid_t*)(sb + (w * GB + g) * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gvoid_t*)(b_src[g] + ikt * BK), (lvoid_t*)(sb + (w * GB + g) * 1024), 16, 0, 0);
+        if (++ikt == ink) {
+            ikt = 0;
+            if (++iu < my_units) issue_setup(iu);
+        }
     };
 
     f32x4 acc[TM][TN];
+    auto zero_acc = [&]() __attribute__((always_inline)) {
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-    const int frow = lane & 15, fq = lane >> 4;
-    auto compute = [&](int st) {
+            for (int jj = 0; jj < TN; ++jj) acc[i][jj] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    };
+    auto compute = [&](int st) __attribute__((always_inline)) {
         const char* sa = smem + st * STAGE;
         const char* sb = sa + A_BYTES;
 #pragma unroll
@@ -107,36 +130,15 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_nt_kernel(const f
             for (int i = 0; i < TM; ++i)
                 fa[i] = *reinterpret_cast<const bf16x8*>(sa + swz(wm * WTM + i * 16 + frow, ks * 4 + fq));
 #pragma unroll
-            for (int j = 0; j < TN; ++j)
-                fb[j] = *reinterpret_cast<const bf16x8*>(sb + swz(wn * WTN + j * 16 + frow, ks * 4 + fq));
-            __builtin_amdgcn_s_setprio(1);
+            for (int jj = 0; jj < TN; ++jj)
+                fb[jj] = *reinterpret_cast<const bf16x8*>(sb + swz(wn * WTN + jj * 16 + frow, ks * 4 + fq));
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
-            __builtin_amdgcn_s_setprio(0);
+                for (int jj = 0; jj < TN; ++jj)
+                    acc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[jj], fa[i], acc[i][jj], 0, 0, 0);
         }
     };
-
-    if (nk > 0) {
-        stage(0, 0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        // two K-steps per iteration so that both LDS stage offsets are compile-time constants
-        int kt = 0;
-        for (; kt + 1 < nk; kt += 2) {
-            stage(1, kt + 1);
-            compute(0);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            if (kt + 2 < nk) stage(0, kt + 2);
-            compute(1);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-        }
-        if (kt < nk) compute(0);
-    }
 
     // ---- epilogue: acc[i][j][r] = D[n = n0+wn*WTN+j*16+fq*4+r][m = m0+wm*WTM+i*16+frow] ----
     const size_t va = 4 * sizeof(TC);
@@ -144,66 +146,196 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_nt_kernel(const f
                         (!R || reinterpret_cast<uintptr_t>(R) % va == 0) &&
                         (!X || reinterpret_cast<uintptr_t>(X) % va == 0);
     const bool atomic = splits > 1;
+    auto epilogue = [&](int m0, int n0) __attribute__((always_inline)) {
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
-        const int gm = m0 + wm * WTM + i * 16 + frow;
-        if (gm >= d.M) continue;
+        for (int i = 0; i < TM; ++i) {
+            const int gm = m0 + wm * WTM + i * 16 + frow;
+            if (gm >= d.M) continue;
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int gn = n0 + wn * WTN + j * 16 + fq * 4;
-            if (gn >= d.N) continue;
-            const int64_t off = gm * d.rsC + (int64_t)gn * d.csC;
-            if (atomic) {
-                if constexpr (sizeof(TC) == 4) {
+            for (int jj = 0; jj < TN; ++jj) {
+                const int gn = n0 + wn * WTN + jj * 16 + fq * 4;
+                if (gn >= d.N) continue;
+                const int64_t off = gm * d.rsC + (int64_t)gn * d.csC;
+                if (atomic) {
+                    if constexpr (sizeof(TC) == 4) {
 #pragma unroll
-                    for (int r4 = 0; r4 < 4; ++r4)
-                        if (gn + r4 < d.N) atomicAdd(reinterpret_cast<float*>(C) + off + (int64_t)r4 * d.csC, d.alpha * acc[i][j][r4]);
+                        for (int r4 = 0; r4 < 4; ++r4)
+                            if (gn + r4 < d.N)
+                                atomicAdd(reinterpret_cast<float*>(C) + off + (int64_t)r4 * d.csC, d.alpha * acc[i][jj][r4]);
+                    }
+                    continue;
                 }
-                continue;
-            }
-            float v[4];
-            const bool full = vec_ok && gn + 3 < d.N;
-            float xs[4] = {0.f, 0.f, 0.f, 0.f};
-            if (d.epilogue >= FOCUS_EPI_DGELU) {
-                if (full) { const f4 xa = ld4<TC>(X + off); xs[0] = xa.x; xs[1] = xa.y; xs[2] = xa.z; xs[3] = xa.w; }
-                else
-                    for (int r4 = 0; r4 < 4; ++r4) if (gn + r4 < d.N) xs[r4] = ld<TC>(X + off + (int64_t)r4 * d.csC);
-            }
-            float pre[4];
-#pragma unroll
-            for (int r4 = 0; r4 < 4; ++r4) {
-                float t = d.alpha * acc[i][j][r4];
-                if (d.bias && gn + r4 < d.N) t += d.bias[gn + r4];
-                pre[r4] = t;
-                switch (d.epilogue) {
-                    case FOCUS_EPI_GELU: t = gelu_erf(t); break;
-                    case FOCUS_EPI_RELU: t = fmaxf(t, 0.f); break;
-                    case FOCUS_EPI_TANH: t = tanhf(t); break;
-                    case FOCUS_EPI_DGELU: t *= dgelu_erf(xs[r4]); break;
-                    case FOCUS_EPI_DRELU: t = xs[r4] > 0.f ? t : 0.f; break;
-                    case FOCUS_EPI_DTANH: t *= (1.f - xs[r4] * xs[r4]); break;
-                    default: break;
+                float v[4], pre[4];
+                const bool full = vec_ok && gn + 3 < d.N;
+                float xs[4] = {0.f, 0.f, 0.f, 0.f};
+                if (d.epilogue >= FOCUS_EPI_DGELU) {
+                    if (full) { const f4 xa = ld4<TC>(X + off); xs[0] = xa.x; xs[1] = xa.y; xs[2] = xa.z; xs[3] = xa.w; }
+                    else
+                        for (int r4 = 0; r4 < 4; ++r4) if (gn + r4 < d.N) xs[r4] = ld<TC>(X + off + (int64_t)r4 * d.csC);
                 }
-                v[r4] = t;
-            }
-            if (full) {
-                if (d.epilogue == FOCUS_EPI_GELU && X) st4<TC>(X + off, (f4){pre[0], pre[1], pre[2], pre[3]});
-                if (R) { const f4 rr = ld4<TC>(R + off); v[0] += rr.x; v[1] += rr.y; v[2] += rr.z; v[3] += rr.w; }
-                if (d.accumulate) { const f4 cc = ld4<TC>(C + off); v[0] += cc.x; v[1] += cc.y; v[2] += cc.z; v[3] += cc.w; }
-                st4<TC>(C + off, (f4){v[0], v[1], v[2], v[3]});
-            } else {
+#pragma unroll
                 for (int r4 = 0; r4 < 4; ++r4) {
-                    if (gn + r4 >= d.N) break;
-                    const int64_t o = off + (int64_t)r4 * d.csC;
-                    if (d.epilogue == FOCUS_EPI_GELU && X) st<TC>(X + o, pre[r4]);
-                    float t = v[r4];
-                    if (R) t += ld<TC>(R + o);
-                    if (d.accumulate) t += ld<TC>(C + o);
-                    st<TC>(C + o, t);
+                    float t = d.alpha * acc[i][jj][r4];
+                    if (d.bias && gn + r4 < d.N) t += d.bias[gn + r4];
+                    pre[r4] = t;
+                    switch (d.epilogue) {
+                        case FOCUS_EPI_GELU: t = gelu_erf(t); break;
+                        case FOCUS_EPI_RELU: t = fmaxf(t, 0.f); break;
+                        case FOCUS_EPI_TANH: t = tanhf(t); break;
+                        case FOCUS_EPI_DGELU: t *= dgelu_erf(xs[r4]); break;
+                        case FOCUS_EPI_DRELU: t = xs[r4] > 0.f ? t : 0.f; break;
+                        case FOCUS_EPI_DTANH: t *= (1.f - xs[r4] * xs[r4]); break;
+                        default: break;
+                    }
+                    v[r4] = t;
+                }
+                if (full) {
+                    if (d.epilogue == FOCUS_EPI_GELU && X) st4<TC>(X + off, (f4){pre[0], pre[1], pre[2], pre[3]});
+                    if (R) { const f4 rr = ld4<TC>(R + off); v[0] += rr.x; v[1] += rr.y; v[2] += rr.z; v[3] += rr.w; }
+                    if (d.accumulate) { const f4 cc = ld4<TC>(C + off); v[0] += cc.x; v[1] += cc.y; v[2] += cc.z; v[3] += cc.w; }
+                    st4<TC>(C + off, (f4){v[0], v[1], v[2], v[3]});
+                } else {
+                    for (int r4 = 0; r4 < 4; ++r4) {
+                        if (gn + r4 >= d.N) break;
+                        const int64_t o = off + (int64_t)r4 * d.csC;
+                        if (d.epilogue == FOCUS_EPI_GELU && X) st<TC>(X + o, pre[r4]);
+                        float t = v[r4];
+                        if (R) t += ld<TC>(R + o);
+                        if (d.accumulate) t += ld<TC>(C + o);
+                        st<TC>(C + o, t);
+                    }
                 }
             }
         }
+    };
+
+    // ---- bf16 epilogue through LDS: the wave parks its 64x64 tile of t = alpha*acc + bias (bf16) in a private
+    // 8 KiB slice of the just-consumed stage, re-reads it row-wise and finishes (activation / aux / residual) on
+    // 16-byte row-contiguous global accesses: every 128-B line of C, aux and residual is touched exactly once.
+    // (The direct path above writes 8-B pieces of 16 different rows per instruction -- 8x the store instructions
+    // and partial-line traffic; it remains for fp32 / atomic / unaligned outputs.)
+    static_assert(!LDSEPI || (sizeof(TC) == 2 && WTM == 64 && WTN == 64 && NW * 8192 <= STAGE), "LDS epilogue shape");
+    constexpr bool lds_epi = LDSEPI;      // the host checks layout/alignment (lds_epilogue_ok) before choosing it
+    auto epilogue_lds = [&](int st, int m0, int n0) __attribute__((always_inline)) {
+        char* slab = smem + st * STAGE + w * 8192;           // [64 rows][16 chunks of 8 B], chunk ^= row & 15
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int row = i * 16 + frow;
+#pragma unroll
+            for (int jj = 0; jj < TN; ++jj) {
+                const int gn = n0 + wn * WTN + jj * 16 + fq * 4;
+                float t[4];
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4) {
+                    t[r4] = d.alpha * acc[i][jj][r4];
+                    if (d.bias && gn + r4 < d.N) t[r4] += d.bias[gn + r4];
+                }
+                uint2 pk;
+                pk.x = (uint32_t)f32_to_bf16(t[0]) | ((uint32_t)f32_to_bf16(t[1]) << 16);
+                pk.y = (uint32_t)f32_to_bf16(t[2]) | ((uint32_t)f32_to_bf16(t[3]) << 16);
+                *reinterpret_cast<uint2*>(slab + row * 128 + (((jj * 4 + fq) ^ (row & 15)) << 3)) = pk;
+            }
+        }
+        // same wave wrote and reads its slab: only the wave's own LDS stores must have landed
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const int q8 = lane & 7;
+#pragma unroll
+        for (int p8 = 0; p8 < 8; ++p8) {
+            const int row = p8 * 8 + (lane >> 3);
+            const int gm = m0 + wm * WTM + row, gn = n0 + wn * WTN + q8 * 8;
+            uint4 raw = *reinterpret_cast<const uint4*>(slab + row * 128 + ((q8 ^ ((row & 15) >> 1)) << 4));
+            if (row & 1) { uint32_t a = raw.x, b = raw.y; raw.x = raw.z; raw.y = raw.w; raw.z = a; raw.w = b; }
+            if (gm >= d.M || gn >= d.N) continue;
+            const int64_t off = gm * d.rsC + gn;
+            float v[8] = {__uint_as_float(raw.x << 16), __uint_as_float(raw.x & 0xffff0000u),
+                          __uint_as_float(raw.y << 16), __uint_as_float(raw.y & 0xffff0000u),
+                          __uint_as_float(raw.z << 16), __uint_as_float(raw.z & 0xffff0000u),
+                          __uint_as_float(raw.w << 16), __uint_as_float(raw.w & 0xffff0000u)};
+            float xs[8];
+            if (d.epilogue >= FOCUS_EPI_DGELU) {
+                const uint4 xr = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(X) + off);
+                xs[0] = __uint_as_float(xr.x << 16); xs[1] = __uint_as_float(xr.x & 0xffff0000u);
+                xs[2] = __uint_as_float(xr.y << 16); xs[3] = __uint_as_float(xr.y & 0xffff0000u);
+                xs[4] = __uint_as_float(xr.z << 16); xs[5] = __uint_as_float(xr.z & 0xffff0000u);
+                xs[6] = __uint_as_float(xr.w << 16); xs[7] = __uint_as_float(xr.w & 0xffff0000u);
+            }
+            if (d.epilogue == FOCUS_EPI_GELU && X) *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(X) + off) = raw;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                switch (d.epilogue) {
+                    case FOCUS_EPI_GELU: v[e] = gelu_erf(v[e]); break;
+                    case FOCUS_EPI_RELU: v[e] = fmaxf(v[e], 0.f); break;
+                    case FOCUS_EPI_TANH: v[e] = tanhf(v[e]); break;
+                    case FOCUS_EPI_DGELU: v[e] *= dgelu_erf(xs[e]); break;
+                    case FOCUS_EPI_DRELU: v[e] = xs[e] > 0.f ? v[e] : 0.f; break;
+                    case FOCUS_EPI_DTANH: v[e] *= (1.f - xs[e] * xs[e]); break;
+                    default: break;
+                }
+            }
+            if (R) {
+                const uint4 rr = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(R) + off);
+                v[0] += __uint_as_float(rr.x << 16); v[1] += __uint_as_float(rr.x & 0xffff0000u);
+                v[2] += __uint_as_float(rr.y << 16); v[3] += __uint_as_float(rr.y & 0xffff0000u);
+                v[4] += __uint_as_float(rr.z << 16); v[5] += __uint_as_float(rr.z & 0xffff0000u);
+                v[6] += __uint_as_float(rr.w << 16); v[7] += __uint_as_float(rr.w & 0xffff0000u);
+            }
+            uint4 o;
+            o.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
+            o.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
+            o.z = (uint32_t)f32_to_bf16(v[4]) | ((uint32_t)f32_to_bf16(v[5]) << 16);
+            o.w = (uint32_t)f32_to_bf16(v[6]) | ((uint32_t)f32_to_bf16(v[7]) << 16);
+            *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(C) + off) = o;
+        }
+    };
+
+    if (my_units == 0) return;
+    // ---- main stream: outer loop over units, inner loop over the unit's K-steps.  The accumulators live only
+    // inside run_unit (so they stay in the accumulator file across the K loop); the DMA cursor is separate state and
+    // carries the prefetch across unit boundaries.  The LDS stage alternates every K-step, so a unit with an odd
+    // number of K-steps flips the parity the next unit starts on: run_unit exists once per starting parity. ----
+    auto kstep = [&](int st) __attribute__((always_inline)) {
+        issue(st ^ 1);                         // next K-step (maybe the next unit's first) lands in the other stage
+        compute(st);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                       // stage st is free for every wave; stage st^1 has landed
+    };
+    auto run_unit = [&](auto ptag, const Unit& cur) __attribute__((always_inline)) {
+        constexpr int P = decltype(ptag)::value;
+        zero_acc();
+        int kt = 0;
+        for (; kt + 1 < cur.nk; kt += 2) {
+            kstep(P);
+            kstep(P ^ 1);
+        }
+        if (kt < cur.nk) kstep(P);
+        if constexpr (lds_epi) {
+            // the stage consumed last is free (barrier above); its parity is known only at run time
+            epilogue_lds((P + cur.nk - 1) & 1, cur.m0, cur.n0);
+            __syncthreads();                   // slabs are re-read before the next K-step's DMA overwrites that stage
+        } else {
+            epilogue(cur.m0, cur.n0);
+        }
+    };
+    issue_setup(0);
+    issue(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int parity = 0;
+    for (int cu = 0; cu < my_units; ++cu) {
+        const Unit cur = unit_of(cu);
+        if (parity == 0) run_unit(std::integral_constant<int, 0>{}, cur);
+        else run_unit(std::integral_constant<int, 1>{}, cur);
+        parity ^= cur.nk & 1;
     }
+}
+
+static bool lds_epilogue_ok(const focus_gemm_desc& d, int splits) {
+    static const bool enabled = !(getenv("FOCUS_GEMM_LDS_EPI") && atoi(getenv("FOCUS_GEMM_LDS_EPI")) == 0);
+    if (!enabled || d.dtype_c != FOCUS_BF16 || splits > 1 || d.csC != 1 || (d.rsC & 7) || (d.N & 7)) return false;
+    if ((d.bsC0 & 7) || (d.bsC1 & 7)) return false;
+    if (!focus_aligned(d.C, 16) || (d.residual && !focus_aligned(d.residual, 16)) || (d.aux && !focus_aligned(d.aux, 16)))
+        return false;
+    return true;
 }
 
 template <int BM, int BN, int WAVES_M, int WAVES_N>
@@ -215,15 +347,26 @@ int launch_nt(const focus_gemm_desc& d, int splits, hipStream_t s) {
         k_per_split = ((d.K / BK + splits - 1) / splits) * BK;
         splits = (d.K + k_per_split - 1) / k_per_split;
     }
-    dim3 grid(tiles_m * tiles_n * splits, nbatch), blk(64 * WAVES_M * WAVES_N);
     constexpr size_t lds = 2 * (BM + BN) * 128;
-    if (d.dtype_c == FOCUS_BF16) {
-        auto k = gemm_nt_kernel<BM, BN, WAVES_M, WAVES_N, bf16_t>;
+    constexpr int per_cu = (160 * 1024) / (int)lds;
+    const int nunits = tiles_m * tiles_n * splits;
+    const int resident = 256 * per_cu / (nbatch > 1 ? std::min(nbatch, per_cu * 256) : 1);
+    dim3 grid(std::max(1, std::min(nunits, std::max(resident, 8))), nbatch), blk(64 * WAVES_M * WAVES_N);
+    constexpr bool can_lds = (BM / WAVES_M == 64) && (BN / WAVES_N == 64) && (WAVES_M * WAVES_N * 8192 <= (BM + BN) * 128);
+    if (d.dtype_c == FOCUS_BF16 && can_lds && lds_epilogue_ok(d, splits)) {
+        if constexpr (can_lds) {
+            auto k = gemm_nt_kernel<BM, BN, WAVES_M, WAVES_N, true, bf16_t>;
+            static bool once = (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds) == hipSuccess);
+            (void)once;
+            hipLaunchKernelGGL(k, grid, blk, lds, s, d, tiles_m, tiles_n, splits, k_per_split);
+        }
+    } else if (d.dtype_c == FOCUS_BF16) {
+        auto k = gemm_nt_kernel<BM, BN, WAVES_M, WAVES_N, false, bf16_t>;
         static bool once = (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds) == hipSuccess);
         (void)once;
         hipLaunchKernelGGL(k, grid, blk, lds, s, d, tiles_m, tiles_n, splits, k_per_split);
     } else {
-        auto k = gemm_nt_kernel<BM, BN, WAVES_M, WAVES_N, float>;
+        auto k = gemm_nt_kernel<BM, BN, WAVES_M, WAVES_N, false, float>;
         static bool once = (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds) == hipSuccess);
         (void)once;
         hipLaunchKernelGGL(k, grid, blk, lds, s, d, tiles_m, tiles_n, splits, k_per_split);
@@ -259,10 +402,13 @@ int focus_gemm_mfma_nt(const focus_gemm_desc& d, hipStream_t s) {
         if (splits < 1) splits = 1;
         return launch_nt<128, 128, 2, 2>(d, splits, s);
     }
-    // TODO(perf): a 256x256 / 8-wave instantiation exists in the template but hipcc spills its 128 accumulator
-    // registers at TM=8,TN=4; until the fragment loads are restructured everything runs the 128x128 tile.
     (void)t256;
-    return launch_nt<128, 128, 2, 2>(d, 1, s);
+    static const int variant = getenv("FOCUS_GEMM_VARIANT") ? atoi(getenv("FOCUS_GEMM_VARIANT")) : 0;
+    switch (variant) {   // tuning hook (tools/gemm_sweep.py); 0 is the shipped configuration
+        case 4: return launch_nt<256, 128, 4, 2>(d, 1, s);
+        case 6: return launch_nt<128, 256, 2, 4>(d, 1, s);
+        default: return launch_nt<128, 128, 2, 2>(d, 1, s);
+    }
 }
 
 // ---- public dispatcher ---------------------------------------------------------------------------
