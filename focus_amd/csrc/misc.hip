@@ -371,6 +371,23 @@ extern "C" int focus_cell_amax_bwd(const void* dy, const int32_t* arg, void* dx,
     return FOCUS_OK;
 }
 
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+__global__ void tr16_probe_kernel(int16_t* out) {
+    __shared__ __attribute__((aligned(16))) int16_t img[16 * 64];
+    for (int i = threadIdx.x; i < 16 * 64; i += 64) img[i] = (int16_t)(100 * (i / 64) + (i % 64));
+    __syncthreads();
+    const int l = threadIdx.x, g = l >> 4, q = (l & 15) >> 2, pp = l & 3;
+    auto* ptr = (__attribute__((address_space(3))) s16x4*)(img + (4 * g + q) * 64 + 4 * pp);
+    const s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16(ptr);
+    for (int i = 0; i < 4; ++i) out[l * 4 + i] = v[i];
+}
+extern "C" int focus_debug_tr16_probe(int16_t* out, void* stream) {
+    if (!out) return FOCUS_ERR_NULL;
+    hipLaunchKernelGGL(tr16_probe_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, out);
+    FOCUS_CHECK_LAUNCH();
+    return FOCUS_OK;
+}
+
 static const char* kErr[] = {"ok", "bad shape", "unsupported dtype", "misaligned pointer or stride",
                              "HIP launch failure", "null pointer", "workspace too small"};
 extern "C" const char* focus_strerror(int status) {

@@ -8,6 +8,7 @@
 #include "focus_common.h"
 #include "gemm_internal.h"
 #include "softmax_internal.h"
+#include "traj_internal.h"
 
 namespace {
 
@@ -147,8 +148,9 @@ int space_logits(const SpaceDims& D, const void* qkv, void* L, int dtype, hipStr
 
 extern "C" size_t focus_traj_space_workspace_bytes(int B, int F, int P, int heads, int d, int dtype, int backward) {
     const size_t S = (size_t)F * P, N = S + 1, C = (size_t)heads * d, es = focus_esize(dtype);
-    size_t bytes = (size_t)B * heads * S * S * es;           // logits / probabilities
-    bytes += (size_t)B * heads * N * es;                     // cls row
+    size_t bytes = (size_t)B * heads * N * es;               // cls row
+    if (backward || !focus_traj_space_mfma_ok(P, d, heads, dtype))
+        bytes += (size_t)B * heads * S * S * es;             // logits / probabilities (unfused path)
     if (backward) {
         bytes += (size_t)B * heads * S * S * es;             // d(prob) / d(logits)
         bytes += (size_t)B * heads * N * es;                 // d(cls row)
@@ -166,9 +168,13 @@ extern "C" int focus_traj_space_fwd(const void* qkv, void* xt, void* xdiag, void
     hipStream_t s = (hipStream_t)stream;
     SpaceDims D = {B, F, P, heads, d, F * P, F * P + 1, heads * d, 3 * (int64_t)heads * d};
     const float scale = 1.f / sqrtf((float)d);
-    void* L = ws;
-    void* Lc = mptr(ws, (int64_t)B * heads * D.S * D.S, dtype);
+    const bool fused = focus_traj_space_mfma_ok(P, d, heads, dtype);
+    void* Lc = ws;                                           // cls row first, then the (unfused) S x S logits
+    void* L = mptr(ws, (int64_t)B * heads * D.N, dtype);
     int rc;
+    if (fused) {
+        if ((rc = focus_traj_space_fwd_mfma(qkv, xt, xdiag, lse, B, F, P, heads, s))) return rc;
+    } else {
     // patch rows: logits -> per-frame softmax (saves lse) -> per-frame A.V
     if ((rc = space_logits(D, qkv, L, dtype, s))) return rc;
     if ((rc = focus_softmax_fwd_lse(L, L, lse, (int64_t)B * heads * D.S * F, P, P, scale, dtype, s))) return rc;
@@ -184,6 +190,7 @@ extern "C" int focus_traj_space_fwd(const void* qkv, void* xt, void* xdiag, void
         if ((rc = focus_gemm(&g, s))) return rc;
     }
     if ((rc = focus_diag_gather(xt, xdiag, B, D.S, F, D.C, dtype, s))) return rc;
+    }
     // cls row over all N keys
     {
         focus_gemm_desc g = base_desc(dtype);

@@ -1,0 +1,192 @@
+// traj_space_mfma.hip -- fused space step of trajectory attention (attention.py:524-535), bf16, head dim 64.
+//
+// For every query s and every frame f:  x~[s,f,:] = softmax_p(scale * q_s . k_{f,p}) . v_{f,p}   (P keys per frame)
+// The reference materialises the S x S logits (118 MB per clip and block); here a workgroup owns 128 queries of
+// one (batch, head) and walks the F frames: the frame's K and V^T tiles sit in LDS, each wave (32 queries) computes
+// the 32-key x 32-query logit tiles with v_mfma_f32_32x32x16_bf16 in the SWAPPED orientation (keys on the
+// accumulator rows, queries on the lanes), so the whole per-(query,frame) softmax is lane-local (one exchange with
+// the partner half-wave), and the normalised probabilities feed the P.V product straight from the accumulator
+// registers as the B operand (cdna_hip_programming.md section 3, "accumulator tile as the next MFMA's operand").
+// Exact softmax per frame (P <= 224 keys fit the register tile): no online rescaling.  Outputs x~ [B,S,F,C],
+// x_diag [B,S,C] (= x~ at the query's own frame) and the per-(query,frame) log-sum-exp for backward; rows leave
+// through a per-wave LDS slab so every global store is a 16-byte piece of a 128-byte row.
+#include "focus_common.h"
+#include "traj_internal.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+constexpr int HD = 64;                 // head dim
+constexpr int VT_STRIDE = 228;         // bf16 elements per V^T row (456 B: conflict-free 8-byte column reads)
+constexpr int QT = 128;                // queries per workgroup (4 waves x 32)
+
+__device__ __forceinline__ int swz(int row, int chunk) { return row * 128 + ((chunk ^ (row & 7)) << 4); }
+
+union Pack8 { bf16x8 v; bf16_t e[8]; uint4 u; };
+
+template <int NKB>
+__global__ __launch_bounds__(256, 2) void traj_space_fwd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ xt,
+                                                                bf16_t* __restrict__ xdiag, float* __restrict__ lse,
+                                                                int B, int F, int P, int heads) {
+    constexpr int KROWS = NKB * 32;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* sK = smem;                                          // [KROWS][64] bf16, 128-B rows, chunk-swizzled
+    bf16_t* sVt = reinterpret_cast<bf16_t*>(smem + KROWS * 128);   // [64][VT_STRIDE]
+    char* slabs = smem + KROWS * 128 + HD * VT_STRIDE * 2;    // 4 x [32][128 B]
+
+    const int S = F * P, N = S + 1, C = heads * HD;
+    const int64_t tok = 3 * (int64_t)C;
+    const int bh = blockIdx.y, b = bh / heads, hh = bh % heads;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int s_q = min(blockIdx.x * QT + w * 32 + r, S - 1);  // this lane's query (clamped)
+    const bool q_valid = blockIdx.x * QT + w * 32 + r < S;
+    const bf16_t* base = qkv + (int64_t)b * N * tok + hh * HD;
+    const float c2 = rsqrtf((float)HD) * 1.44269504088896341f;   // scale * log2(e)
+
+    // Q fragments: B operand of the swapped product, lane (r,h) holds Q[q=r][16*ks + 8h + j]
+    bf16x8 qf[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+        qf[ks] = *reinterpret_cast<const bf16x8*>(base + (int64_t)(1 + s_q) * tok + ks * 16 + 8 * h);
+
+    char* slab = slabs + w * 4096;
+    for (int f = 0; f < F; ++f) {
+        __syncthreads();   // previous frame's tiles are no longer read
+        // ---- stage K_f (row-major, swizzled) and V_f transposed ----
+        for (int e = tid; e < KROWS * 8; e += 256) {
+            const int p = e >> 3, c = e & 7;
+            uint4 kv = make_uint4(0, 0, 0, 0);
+            Pack8 vv; vv.u = make_uint4(0, 0, 0, 0);
+            if (p < P) {
+                const bf16_t* row = base + (int64_t)(1 + f * P + p) * tok + c * 8;
+                kv = *reinterpret_cast<const uint4*>(row + C);
+                vv.u = *reinterpret_cast<const uint4*>(row + 2 * C);
+            }
+            *reinterpret_cast<uint4*>(sK + swz(p, c)) = kv;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) sVt[(c * 8 + i) * VT_STRIDE + p] = vv.e[i];
+        }
+        __syncthreads();
+
+        // ---- logits: acc[kb][reg] = sum_d K[kb*32 + row(reg,h)][d] * Q[q=r][d] ----
+        f32x16 acc[NKB];
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[kb][i] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(sK + swz(kb * 32 + r, ks * 2 + h));
+                acc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], acc[kb], 0, 0, 0);
+            }
+        }
+        // ---- per-(query, frame) softmax over the P keys: this lane holds half of its query's keys ----
+        float m = -INFINITY;
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int key = kb * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+                const float t = key < P ? acc[kb][i] * c2 : -INFINITY;
+                acc[kb][i] = t;
+                m = fmaxf(m, t);
+            }
+        m = fmaxf(m, __shfl_xor(m, 32, 64));
+        float sum = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const float pexp = __builtin_amdgcn_exp2f(acc[kb][i] - m);
+                acc[kb][i] = pexp;
+                sum += pexp;
+            }
+        sum += __shfl_xor(sum, 32, 64);
+        const float inv = 1.f / sum;
+        if (h == 0 && q_valid)
+            lse[(((int64_t)b * heads + hh) * S + s_q) * F + f] = (m + __builtin_amdgcn_logf(sum)) * 0.69314718055994531f;
+
+        // ---- y[dblk][reg] = sum_key V^T[d][key] * P[key][q]  (P straight from the accumulators) ----
+        f32x16 y[2];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { y[0][i] = 0.f; y[1][i] = 0.f; }
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                Pack8 pf;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) pf.e[j] = f32_to_bf16(acc[kb][8 * s2 + j] * inv);
+                const int k0 = kb * 32 + 16 * s2 + 4 * h;
+#pragma unroll
+                for (int dblk = 0; dblk < 2; ++dblk) {
+                    const bf16_t* vrow = sVt + (dblk * 32 + r) * VT_STRIDE + k0;
+                    union { bf16x8 v; uint2 u[2]; } vf;
+                    vf.u[0] = *reinterpret_cast<const uint2*>(vrow);
+                    vf.u[1] = *reinterpret_cast<const uint2*>(vrow + 8);
+                    y[dblk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf.v, pf.v, y[dblk], 0, 0, 0);
+                }
+            }
+
+        // ---- rows out through the wave's LDS slab: [32 q][16 chunks of 8 B], chunk ^= q & 15 ----
+#pragma unroll
+        for (int dblk = 0; dblk < 2; ++dblk)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                uint2 pk;
+                pk.x = (uint32_t)f32_to_bf16(y[dblk][4 * g + 0]) | ((uint32_t)f32_to_bf16(y[dblk][4 * g + 1]) << 16);
+                pk.y = (uint32_t)f32_to_bf16(y[dblk][4 * g + 2]) | ((uint32_t)f32_to_bf16(y[dblk][4 * g + 3]) << 16);
+                *reinterpret_cast<uint2*>(slab + r * 128 + (((dblk * 8 + 2 * g + h) ^ (r & 15)) << 3)) = pk;
+            }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the wave re-reads only its own slab
+#pragma unroll
+        for (int p4 = 0; p4 < 4; ++p4) {
+            const int row = p4 * 8 + (lane >> 3), q8 = lane & 7;
+            uint4 raw = *reinterpret_cast<const uint4*>(slab + row * 128 + ((q8 ^ ((row & 15) >> 1)) << 4));
+            if (row & 1) { const uint32_t a0 = raw.x, a1 = raw.y; raw.x = raw.z; raw.y = raw.w; raw.z = a0; raw.w = a1; }
+            const int s_row = blockIdx.x * QT + w * 32 + row;
+            if (s_row < S) {
+                *reinterpret_cast<uint4*>(xt + (((int64_t)b * S + s_row) * F + f) * C + hh * HD + q8 * 8) = raw;
+                if (s_row / P == f)
+                    *reinterpret_cast<uint4*>(xdiag + ((int64_t)b * S + s_row) * C + hh * HD + q8 * 8) = raw;
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // slab reads done before the next frame overwrites it
+    }
+}
+
+template <int NKB>
+int launch_fwd(const void* qkv, void* xt, void* xdiag, float* lse, int B, int F, int P, int heads, hipStream_t s) {
+    const int S = F * P;
+    const size_t lds = (size_t)NKB * 32 * 128 + HD * VT_STRIDE * 2 + 4 * 4096;
+    auto k = traj_space_fwd_kernel<NKB>;
+    static bool once = (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds) == hipSuccess);
+    (void)once;
+    dim3 grid((S + QT - 1) / QT, B * heads);
+    hipLaunchKernelGGL(k, grid, dim3(256), lds, s, (const bf16_t*)qkv, (bf16_t*)xt, (bf16_t*)xdiag, lse, B, F, P, heads);
+    FOCUS_CHECK_LAUNCH();
+    return FOCUS_OK;
+}
+
+}  // namespace
+
+bool focus_traj_space_mfma_ok(int P, int d, int heads, int dtype) {
+    static const bool enabled = !(getenv("FOCUS_TRAJ_FUSED") && atoi(getenv("FOCUS_TRAJ_FUSED")) == 0);
+    return enabled && dtype == FOCUS_BF16 && d == HD && P >= 1 && P <= 224 && ((heads * HD) % 8) == 0;
+}
+
+// Patch-token rows only (xt, xdiag, lse); the cls row is handled by the caller.
+int focus_traj_space_fwd_mfma(const void* qkv, void* xt, void* xdiag, float* lse, int B, int F, int P, int heads,
+                              hipStream_t s) {
+    if (B * heads > 65535) return FOCUS_ERR_SHAPE;
+    if (!focus_aligned(qkv, 16) || !focus_aligned(xt, 16) || !focus_aligned(xdiag, 16)) return FOCUS_ERR_ALIGN;
+    const int nkb = (P + 31) / 32;
+    if (nkb <= 1) return launch_fwd<1>(qkv, xt, xdiag, lse, B, F, P, heads, s);
+    if (nkb <= 2) return launch_fwd<2>(qkv, xt, xdiag, lse, B, F, P, heads, s);
+    if (nkb <= 4) return launch_fwd<4>(qkv, xt, xdiag, lse, B, F, P, heads, s);
+    return launch_fwd<7>(qkv, xt, xdiag, lse, B, F, P, heads, s);
+}

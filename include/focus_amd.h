@@ -225,6 +225,11 @@ int focus_transpose_pad(const void* src, int src_dtype, int64_t src_ld, int64_t 
 int focus_diag_gather(const void* xt, void* xdiag, int B, int S, int F, int C, int dtype, void* stream);
 int focus_diag_scatter_add(const void* dxdiag, void* dxt, int B, int S, int F, int C, int dtype, void* stream);
 
+/* Hardware probe (bring-up aid, used by tests only): fills an LDS image img[r][c] = 100*r + c (16 rows x 64
+ * columns of int16, 128-B rows), issues ONE ds_read_b64_tr_b16 per lane with lane l of each 16-lane group g
+ * addressing row 4*g + (l%16)/4, column 4*(l%4), and returns the 4 int16 each lane received: out [64][4]. */
+int focus_debug_tr16_probe(int16_t* out, void* stream);
+
 /* dtype conversion (weights shadow copies, gradient casts): n elements. */
 int focus_cast(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t n, void* stream);
 

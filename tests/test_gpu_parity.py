@@ -416,3 +416,19 @@ def test_slot_attention_step_vs_oracle(oracle, dtype):
     close(kg.grad, kr.grad, tol * 2, "dk")
     close(vg.grad, vr.grad, tol * 2, "dv")
     close(qg.grad, qr.grad, tol * 2, "dq")
+
+
+def test_tr16_probe_documents_transposed_lds_read():
+    """Bring-up probe for ds_read_b64_tr_b16 (needed by the planned K-strided MFMA operand loads): records what
+    each lane receives; asserts the semantics cdna_hip_programming.md T10 describes."""
+    import ctypes
+    from focus_amd import _lib
+    out = torch.zeros(64, 4, dtype=torch.int16, device=dev())
+    _lib.check(_lib.lib().focus_debug_tr16_probe(ctypes.c_void_p(out.data_ptr()), None))
+    torch.cuda.synchronize()
+    got = out.cpu().numpy()
+    print("tr16 probe lanes 0..19:", got[:20].tolist())
+    for l in range(64):
+        g, i = l // 16, l % 16
+        # lane i of group g receives column i of the block's 4 rows (rows 4g..4g+3), row q in element q
+        assert got[l].tolist() == [100 * (4 * g + q) + i for q in range(4)], (l, got[l].tolist())
