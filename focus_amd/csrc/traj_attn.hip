@@ -148,13 +148,17 @@ int space_logits(const SpaceDims& D, const void* qkv, void* L, int dtype, hipStr
 
 extern "C" size_t focus_traj_space_workspace_bytes(int B, int F, int P, int heads, int d, int dtype, int backward) {
     const size_t S = (size_t)F * P, N = S + 1, C = (size_t)heads * d, es = focus_esize(dtype);
+    const bool fused = focus_traj_space_mfma_ok(P, d, heads, dtype);
     size_t bytes = (size_t)B * heads * N * es;               // cls row
-    if (backward || !focus_traj_space_mfma_ok(P, d, heads, dtype))
-        bytes += (size_t)B * heads * S * S * es;             // logits / probabilities (unfused path)
+    if (!fused) bytes += (size_t)B * heads * S * S * es;     // logits / probabilities (unfused path)
     if (backward) {
-        bytes += (size_t)B * heads * S * S * es;             // d(prob) / d(logits)
-        bytes += (size_t)B * heads * N * es;                 // d(cls row)
-        bytes += (size_t)B * S * F * C * es;                 // dxt + diagonal term
+        bytes += (size_t)B * heads * N * es + 4096;          // d(cls row) + alignment padding of the carve-up
+        if (fused) {
+            bytes += (size_t)B * heads * S * F * sizeof(float) + 256;   // delta
+        } else {
+            bytes += (size_t)B * heads * S * S * es;         // d(prob) / d(logits)
+            bytes += (size_t)B * S * F * C * es;             // dxt + diagonal term
+        }
     }
     return (bytes + 255) & ~(size_t)255;
 }
@@ -221,19 +225,27 @@ extern "C" int focus_traj_space_bwd(const void* qkv, const void* xt, const void*
     hipStream_t s = (hipStream_t)stream;
     SpaceDims D = {B, F, P, heads, d, F * P, F * P + 1, heads * d, 3 * (int64_t)heads * d};
     const float scale = 1.f / sqrtf((float)d);
-    const int64_t nLL = (int64_t)B * heads * D.S * D.S, nLc = (int64_t)B * heads * D.N;
-    void* L = ws;                         // probabilities
-    void* Lc = mptr(L, nLL, dtype);       // cls probabilities
-    void* dL = mptr(Lc, nLc, dtype);      // d prob -> d logits
-    void* dLc = mptr(dL, nLL, dtype);
-    void* dxs = mptr(dLc, nLc, dtype);    // dxt + diag(dxdiag)
+    const bool fused = focus_traj_space_mfma_ok(P, d, heads, dtype);
+    const int64_t nLL = fused ? 0 : (int64_t)B * heads * D.S * D.S, nLc = (int64_t)B * heads * D.N;
     const size_t es = focus_esize(dtype);
+    void* Lc = ws;                        // cls probabilities
+    void* dLc = mptr(Lc, (nLc + 127) & ~(int64_t)127, dtype);
+    void* L = mptr(dLc, (nLc + 127) & ~(int64_t)127, dtype);   // probabilities (unfused) | delta (fused)
+    void* dL = mptr(L, nLL, dtype);       // d prob -> d logits
+    void* dxs = mptr(dL, nLL, dtype);     // dxt + diag(dxdiag)
     int rc;
-    if (hipMemcpyAsync(dxs, dxt, (size_t)B * D.S * F * D.C * es, hipMemcpyDeviceToDevice, s) != hipSuccess)
-        return FOCUS_ERR_LAUNCH;
-    if ((rc = focus_diag_scatter_add(dxdiag, dxs, B, D.S, F, D.C, dtype, s))) return rc;
+    if (fused) {
+        // patch rows first: fully writes the q/k/v parts of tokens 1..N-1; the cls step below adds onto k/v
+        if ((rc = focus_traj_space_bwd_mfma(qkv, xt, lse, dxt, dxdiag, reinterpret_cast<float*>(L), dqkv, B, F, P, heads, s)))
+            return rc;
+    } else {
+        if (hipMemcpyAsync(dxs, dxt, (size_t)B * D.S * F * D.C * es, hipMemcpyDeviceToDevice, s) != hipSuccess)
+            return FOCUS_ERR_LAUNCH;
+        if ((rc = focus_diag_scatter_add(dxdiag, dxs, B, D.S, F, D.C, dtype, s))) return rc;
+    }
 
-    // ---- cls row first: it writes every row of the k and v parts and row 0 of the q part ----
+    // ---- cls row: row 0 of every part is written plainly; rows 1.. of the k and v parts are written (unfused: the
+    // patch step accumulates on top) or accumulated onto the fused kernels' output ----
     {
         focus_gemm_desc g = base_desc(dtype);   // recompute cls logits, then probabilities from lse
         g.M = 1; g.N = D.N; g.K = d; g.batch0 = B; g.batch1 = heads;
@@ -249,13 +261,17 @@ extern "C" int focus_traj_space_bwd(const void* qkv, const void* xt, const void*
         a.B = cptr(qkv, 2 * D.C, dtype); a.rsB = 1; a.csB = D.tok; a.bsB0 = (int64_t)D.N * D.tok; a.bsB1 = d;
         a.C = dLc; a.rsC = D.N; a.csC = 1; a.bsC0 = (int64_t)heads * D.N; a.bsC1 = D.N;
         if ((rc = focus_gemm(&a, s))) return rc;
-        // dV[n,:] = Ac[n] * dcls[h,:]   (outer product, K=1)
-        focus_gemm_desc v = base_desc(dtype);
-        v.M = D.N; v.N = d; v.K = 1; v.batch0 = B; v.batch1 = heads;
-        v.A = Lc; v.rsA = 1; v.csA = 1; v.bsA0 = (int64_t)heads * D.N; v.bsA1 = D.N;
-        v.B = dcls; v.rsB = 1; v.csB = 1; v.bsB0 = D.C; v.bsB1 = d;
-        v.C = mptr(dqkv, 2 * D.C, dtype); v.rsC = D.tok; v.csC = 1; v.bsC0 = (int64_t)D.N * D.tok; v.bsC1 = d;
-        if ((rc = focus_gemm(&v, s))) return rc;
+        // dV[n,:] = Ac[n] * dcls[h,:]   (outer product, K=1): token 0, then tokens 1..
+        for (int part = 0; part < 2; ++part) {
+            focus_gemm_desc v = base_desc(dtype);
+            v.M = part == 0 ? 1 : D.N - 1; v.N = d; v.K = 1; v.batch0 = B; v.batch1 = heads;
+            v.A = cptr(Lc, part, dtype); v.rsA = 1; v.csA = 1; v.bsA0 = (int64_t)heads * D.N; v.bsA1 = D.N;
+            v.B = dcls; v.rsB = 1; v.csB = 1; v.bsB0 = D.C; v.bsB1 = d;
+            v.C = mptr(dqkv, (int64_t)part * D.tok + 2 * D.C, dtype); v.rsC = D.tok; v.csC = 1;
+            v.bsC0 = (int64_t)D.N * D.tok; v.bsC1 = d;
+            if (part == 1 && fused) v.residual = v.C;
+            if ((rc = focus_gemm(&v, s))) return rc;
+        }
         // d logits (includes the scale factor)
         if ((rc = focus_softmax_bwd(dLc, Lc, dLc, (int64_t)B * heads, D.N, D.N, scale, dtype, s))) return rc;
         // dq0[:] = sum_n dLc[n] k[n,:]
@@ -266,13 +282,18 @@ extern "C" int focus_traj_space_bwd(const void* qkv, const void* xt, const void*
         q.C = dqkv; q.rsC = D.tok; q.csC = 1; q.bsC0 = (int64_t)D.N * D.tok; q.bsC1 = d;
         if ((rc = focus_gemm(&q, s))) return rc;
         // dK[n,:] = dLc[n] * q0[:]
-        focus_gemm_desc k = base_desc(dtype);
-        k.M = D.N; k.N = d; k.K = 1; k.batch0 = B; k.batch1 = heads;
-        k.A = dLc; k.rsA = 1; k.csA = 1; k.bsA0 = (int64_t)heads * D.N; k.bsA1 = D.N;
-        k.B = qkv; k.rsB = 1; k.csB = 1; k.bsB0 = (int64_t)D.N * D.tok; k.bsB1 = d;
-        k.C = mptr(dqkv, D.C, dtype); k.rsC = D.tok; k.csC = 1; k.bsC0 = (int64_t)D.N * D.tok; k.bsC1 = d;
-        if ((rc = focus_gemm(&k, s))) return rc;
+        for (int part = 0; part < 2; ++part) {
+            focus_gemm_desc k = base_desc(dtype);
+            k.M = part == 0 ? 1 : D.N - 1; k.N = d; k.K = 1; k.batch0 = B; k.batch1 = heads;
+            k.A = cptr(dLc, part, dtype); k.rsA = 1; k.csA = 1; k.bsA0 = (int64_t)heads * D.N; k.bsA1 = D.N;
+            k.B = qkv; k.rsB = 1; k.csB = 1; k.bsB0 = (int64_t)D.N * D.tok; k.bsB1 = d;
+            k.C = mptr(dqkv, (int64_t)part * D.tok + D.C, dtype); k.rsC = D.tok; k.csC = 1;
+            k.bsC0 = (int64_t)D.N * D.tok; k.bsC1 = d;
+            if (part == 1 && fused) k.residual = k.C;
+            if ((rc = focus_gemm(&k, s))) return rc;
+        }
     }
+    if (fused) return FOCUS_OK;
 
     // ---- patch rows ----
     if ((rc = space_logits(D, qkv, L, dtype, s))) return rc;
