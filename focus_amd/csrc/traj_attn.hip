@@ -196,6 +196,7 @@ extern "C" int focus_traj_space_fwd(const void* qkv, void* xt, void* xdiag, void
     if ((rc = focus_diag_gather(xt, xdiag, B, D.S, F, D.C, dtype, s))) return rc;
     }
     // cls row over all N keys
+    if (focus_traj_cls_ok(D.N, d)) return focus_traj_cls_fwd(qkv, cls_out, cls_lse, B, D.N, heads, dtype, s);
     {
         focus_gemm_desc g = base_desc(dtype);
         g.M = 1; g.N = D.N; g.K = d; g.batch0 = B; g.batch1 = heads;
@@ -246,6 +247,7 @@ extern "C" int focus_traj_space_bwd(const void* qkv, const void* xt, const void*
 
     // ---- cls row: row 0 of every part is written plainly; rows 1.. of the k and v parts are written (unfused: the
     // patch step accumulates on top) or accumulated onto the fused kernels' output ----
+    if (fused && focus_traj_cls_ok(D.N, d)) return focus_traj_cls_bwd(qkv, cls_lse, dcls, dqkv, B, D.N, heads, dtype, s);
     {
         focus_gemm_desc g = base_desc(dtype);   // recompute cls logits, then probabilities from lse
         g.M = 1; g.N = D.N; g.K = d; g.batch0 = B; g.batch1 = heads;
