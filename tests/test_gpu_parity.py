@@ -269,6 +269,41 @@ def test_full_size_blocks_vs_oracle(oracle, dtype):
             close(named[k].grad, p["b." + k].grad, tol * 3, kind + " " + k, floor=1e-2 * float(p["b." + k].grad.abs().max()) + 1e-6)
 
 
+@pytest.mark.parametrize("mixed", [False, True])
+def test_motionformer_full_size_vs_oracle(oracle, mixed):
+    """BASELINE configs[0]/[1] shape: the whole ORViT-MF 16x224 model (147.5 M parameters, reference init scheme)
+    on one synthetic clip -- logits and loss against the CPU oracle."""
+    from focus_amd.slowfast.models import build_model
+    from focus_amd.train import synthetic_batch
+    import bench
+    cfg = bench.make_cfg(1, 1, mixed=mixed)
+    torch.manual_seed(0)
+    m = build_model(cfg)
+    m.train()
+    with torch.no_grad():      # the reference init leaves the patch-embed conv weight and box_categories at zero
+        g = torch.Generator().manual_seed(5)
+        m.patch_embed_3d.proj.weight.copy_(0.02 * torch.randn(m.patch_embed_3d.proj.weight.shape, generator=g))
+        for blk in m.blocks:
+            if hasattr(blk, "box_categories"):
+                blk.box_categories.copy_(0.02 * torch.randn(blk.box_categories.shape, generator=g))
+    for mod in m.modules():    # stochastic depth off for the comparison
+        if mod.__class__.__name__ == "DropPath":
+            mod.drop_prob = 0.0
+    inputs, labels, meta = synthetic_batch(cfg, 1, "cpu", seed=7)
+    params = {k: v.detach().float().cpu().clone() for k, v in m.state_dict().items()}
+    ocfg = dict(depth=12, heads=12, orvit_layers=[1, 6, 10], temporal_resolution=8, patch=(2, 16, 16), crop=224)
+    ref = oracle.motionformer_forward(params, inputs[0], meta["orvit_bboxes"], ocfg, training=True)
+    got = m([inputs[0].to(dev())], {"orvit_bboxes": meta["orvit_bboxes"].to(dev())})
+    tol = 3e-2 if mixed else 1e-3
+    close(got, ref, tol, "full-size logits")
+    ref_loss = float(oracle.label_smoothing_ce(ref, labels))
+    from focus_amd.slowfast.models.losses import get_loss_func
+    loss = get_loss_func(cfg)(reduction="mean")(got, labels.to(dev()))
+    assert abs(float(loss.detach()) - ref_loss) < tol * ref_loss
+    loss.backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in m.parameters())
+
+
 def test_state_dict_abi_224():
     """Checkpoint ABI: parameter names/shapes of the full-size model equal the reference's (fixture)."""
     from focus_amd.slowfast.config.defaults import get_cfg
