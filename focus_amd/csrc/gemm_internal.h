@@ -8,3 +8,6 @@ int focus_gemm_generic(const focus_gemm_desc& d, hipStream_t s);
 // FOCUS_ERR_ALIGN / FOCUS_ERR_SHAPE when the operands do not qualify (caller falls back).
 int focus_gemm_mfma_nt(const focus_gemm_desc& d, hipStream_t s);
 bool focus_gemm_mfma_nt_ok(const focus_gemm_desc& d);
+// bf16 MFMA kernel for operands strided along the reduction (dW = dY^T . X from row-major activations).
+bool focus_gemm_mfma_tn_ok(const focus_gemm_desc& d);
+int focus_gemm_mfma_tn(const focus_gemm_desc& d, hipStream_t s);

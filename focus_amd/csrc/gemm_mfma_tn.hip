@@ -1,0 +1,184 @@
+// gemm_mfma_tn.hip -- bf16 MFMA GEMM for operands that are BOTH strided along the reduction index:
+//     C[I,J] (+)= alpha * sum_m  P[m, I]^T . Q[m, J]          P, Q row-major, m = their row index
+// This is the weight-gradient product dW[N,K] = dY[M,N]^T . X[M,K] computed straight from the row-major
+// activations -- no transposed copies of dY and X (the NT kernel needs both re-laid K-contiguous, which cost two
+// extra HBM round trips per Linear per step).
+// LDS tiles keep the global layout ([64 rows of m][128 columns], 256-B rows, DMA'd by global_load_lds_dwordx4
+// with a 16-B chunk swizzle chunk ^= row & 15 applied on the source address); the MFMA fragments, whose k index
+// runs over tile ROWS, are gathered with ds_read_b64_tr_b16 (cdna_hip_programming.md T10; semantics pinned by
+// tests/test_gpu_parity.py::test_tr16_probe...).  128x128 output tile, 4 waves (2x2), v_mfma_f32_16x16x32_bf16,
+// double-buffered, split over m with fp32 atomics into a zero-initialised C (the output is tiny, the reduction long).
+#include "focus_common.h"
+#include "gemm_internal.h"
+#include <algorithm>
+#include <cstdlib>
+
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((address_space(1))) const void gvoid_t;
+typedef __attribute__((address_space(3))) void lvoid_t;
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+
+constexpr int BI = 128, BJ = 128, BKM = 64;        // output tile, reduction rows per step
+constexpr int TILE = BKM * 256;                    // 16 KiB per operand per stage
+
+union Frag { bf16x8 v; s16x4 t[2]; };
+
+// byte offset of element (row, col) [col multiple of 4] in a [64][128 bf16] tile, 16-B chunks swizzled by row
+__device__ __forceinline__ int toff(int row, int col) {
+    return row * 256 + ((((col >> 3)) ^ (row & 15)) << 4) + (col & 4) * 2;
+}
+
+// k = tile rows r0..r0+7 (natural order), m/n = tile column c0 + (lane & 15); lane group g = lane>>4 selects r0.
+__device__ __forceinline__ bf16x8 col_frag16(const char* tile, int r0, int c0, int lane) {
+    const int i = lane & 15;
+    const int row = r0 + (i >> 2), col = c0 + 4 * (i & 3);
+    Frag f;
+    f.t[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(tile + toff(row, col)));
+    f.t[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(tile + toff(row + 4, col)));
+    return f.v;
+}
+
+__global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const focus_gemm_desc d, int tiles_i, int tiles_j, int splits,
+                                                         int m_per_split) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 stages][P tile | Q tile]
+    const int nwg = tiles_i * tiles_j * splits;
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+    const int lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    const int split = lid % splits, tile = lid / splits;
+    const int i0 = (tile / tiles_j) * BI, j0 = (tile % tiles_j) * BJ;
+    const int Mred = d.K;                                   // reduction length (rows of P and Q)
+    const int m_begin = split * m_per_split;
+    const int m_end = min(Mred, m_begin + m_per_split);
+    const int nk = (m_end - m_begin + BKM - 1) / BKM;
+    if (nk <= 0) return;
+
+    const bf16_t* Pm = static_cast<const bf16_t*>(d.A);     // P[m][i] : element (i, m) of "A" = Pm[m*ldp + i]
+    const bf16_t* Qm = static_cast<const bf16_t*>(d.B);     // Q[m][j]
+    const int64_t ldp = d.csA, ldq = d.rsB;
+    float* C = static_cast<float*>(d.C);
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wi = w >> 1, wj = w & 1;
+
+    // DMA: one wave instruction = 4 tile rows x 256 B; lane -> (row_in = lane>>4, cpos = lane&15).
+    // wave w, instruction g (0..3) covers tile rows (w*4 + g)*4 .. +3 ; rows/chunks are clamped into the matrix.
+    const int cpos = lane & 15, rin = lane >> 4;
+    auto stage = [&](int st, int kt) __attribute__((always_inline)) {
+        char* sp = smem + st * 2 * TILE;
+        char* sq = sp + TILE;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int row = (w * 4 + g) * 4 + rin;
+            const int m = min(m_begin + kt * BKM + row, Mred - 1);
+            const int ch = cpos ^ (row & 15);
+            const int ci = min(i0 + ch * 8, d.M - 8), cj = min(j0 + ch * 8, d.N - 8);
+            __builtin_amdgcn_global_load_lds((gvoid_t*)(Pm + (int64_t)m * ldp + ci), (lvoid_t*)(sp + (w * 4 + g) * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gvoid_t*)(Qm + (int64_t)m * ldq + cj), (lvoid_t*)(sq + (w * 4 + g) * 1024), 16, 0, 0);
+        }
+    };
+    // rows past the end of the reduction were DMA'd from a clamped address: zero them in the P tile
+    auto zero_tail = [&](int st, int kt) __attribute__((always_inline)) {
+        const int valid = m_end - (m_begin + kt * BKM);      // rows of this step that are real
+        if (valid >= BKM) return;
+        char* sp = smem + st * 2 * TILE;
+        for (int e = tid; e < BKM * 16; e += 256) {
+            const int row = e >> 4;
+            if (row >= valid) *reinterpret_cast<uint4*>(sp + row * 256 + (e & 15) * 16) = make_uint4(0, 0, 0, 0);
+        }
+    };
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int fq = lane >> 4;
+    auto compute = [&](int st) __attribute__((always_inline)) {
+        const char* sp = smem + st * 2 * TILE;
+        const char* sq = sp + TILE;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 fp[4], fqv[4];
+#pragma unroll
+            for (int a = 0; a < 4; ++a) fp[a] = col_frag16(sp, ks * 32 + 8 * fq, wi * 64 + a * 16, lane);
+#pragma unroll
+            for (int b = 0; b < 4; ++b) fqv[b] = col_frag16(sq, ks * 32 + 8 * fq, wj * 64 + b * 16, lane);
+            // D[j][i] = sum_m Q[m][j] * P[m][i]: lane ends up with 4 consecutive j of one i
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fqv[b], fp[a], acc[a][b], 0, 0, 0);
+        }
+    };
+
+    stage(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    zero_tail(0, 0);
+    __syncthreads();
+    int kt = 0;
+    for (; kt + 1 < nk; kt += 2) {
+        stage(1, kt + 1);
+        compute(0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        zero_tail(1, kt + 1);
+        if (kt + 2 < nk) stage(0, kt + 2);
+        __syncthreads();                       // tail zeroing visible before stage 1 is read (uniform, cheap)
+        compute(1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (kt + 2 < nk) { zero_tail(0, kt + 2); __syncthreads(); }
+    }
+    if (kt < nk) compute(0);
+
+    // acc[a][b][r4] = D[j = j0 + wj*64 + b*16 + fq*4 + r4][i = i0 + wi*64 + a*16 + (lane&15)]
+    const int fr = lane & 15;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        const int gi = i0 + wi * 64 + a * 16 + fr;
+        if (gi >= d.M) continue;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int gj = j0 + wj * 64 + b * 16 + fq * 4;
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4)
+                if (gj + r4 < d.N) atomicAdd(C + (int64_t)gi * d.rsC + (gj + r4), d.alpha * acc[a][b][r4]);
+        }
+    }
+}
+
+}  // namespace
+
+// A described as [M, K] with rsA == 1 (P[m][i] row-major: csA = ld of P), B as [K, N] with csB == 1 (Q[m][j]).
+bool focus_gemm_mfma_tn_ok(const focus_gemm_desc& d) {
+    static const bool enabled = !(getenv("FOCUS_GEMM_TN") && atoi(getenv("FOCUS_GEMM_TN")) == 0);
+    if (!enabled || d.dtype_ab != FOCUS_BF16 || d.dtype_c != FOCUS_F32) return false;
+    if (d.rsA != 1 || d.csB != 1 || d.csC != 1) return false;
+    if (d.batch0 * d.batch1 != 1 || !d.accumulate || d.bias || d.residual || d.epilogue != FOCUS_EPI_NONE) return false;
+    if ((d.csA & 7) || (d.rsB & 7) || (d.M & 7) || (d.N & 7) || d.M < 8 || d.N < 8 || d.K < 1) return false;
+    if (!focus_aligned(d.A, 16) || !focus_aligned(d.B, 16)) return false;
+    return true;
+}
+
+int focus_gemm_mfma_tn(const focus_gemm_desc& d, hipStream_t s) {
+    if (!focus_gemm_mfma_tn_ok(d)) return FOCUS_ERR_ALIGN;
+    const int tiles_i = (d.M + BI - 1) / BI, tiles_j = (d.N + BJ - 1) / BJ;
+    const int tiles = tiles_i * tiles_j;
+    int splits = std::max(1, std::min((2 * 256 + tiles - 1) / tiles, (d.K + 4 * BKM - 1) / (4 * BKM)));
+    int m_per_split = ((d.K + splits - 1) / splits + BKM - 1) / BKM * BKM;
+    splits = (d.K + m_per_split - 1) / m_per_split;
+    const size_t lds = 4 * TILE;
+    static bool once = (hipFuncSetAttribute((const void*)gemm_tn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds) == hipSuccess);
+    (void)once;
+    hipLaunchKernelGGL(gemm_tn_kernel, dim3(tiles * splits), dim3(256), lds, s, d, tiles_i, tiles_j, splits, m_per_split);
+    FOCUS_CHECK_LAUNCH();
+    return FOCUS_OK;
+}

@@ -44,13 +44,18 @@ def _p(t, off=0):
     return ctypes.c_void_p(t.data_ptr() + off * t.element_size())
 
 
+USE_TN_GEMM = True   # weight gradients straight from row-major activations (gemm_mfma_tn.hip)
+
 # bench.py sets this to a list to collect (flops, start_event, end_event) for every MFMA-path GEMM launch
 GEMM_TIMING = None
 
 
 def _mfma_path(ta, sA, sB, K):
-    return (ta.dtype == torch.bfloat16 and sA[1] == 1 and sB[0] == 1 and K > 0 and K % 64 == 0 and
-            sA[0] % 8 == 0 and sB[1] % 8 == 0)
+    if ta.dtype != torch.bfloat16:
+        return False
+    nt = sA[1] == 1 and sB[0] == 1 and K > 0 and K % 64 == 0 and sA[0] % 8 == 0 and sB[1] % 8 == 0
+    tn = sA[0] == 1 and sB[1] == 1 and sA[1] % 8 == 0 and sB[0] % 8 == 0
+    return nt or tn
 
 
 def gemm(M, N, K, A, sA, B, sB, C, sC, batch=(1, 1), bias=None, residual=None, aux=None, alpha=1.0,
@@ -119,10 +124,15 @@ def mm_tn(a, b):
     by focus_transpose_pad and fed to the MFMA kernel; fp32: strided generic kernel."""
     M, N = a.shape
     K = b.shape[1]
-    if a.dtype == torch.bfloat16:
+    if a.dtype == torch.bfloat16 and USE_TN_GEMM and N % 8 == 0 and K % 8 == 0 and N >= 8 and K >= 8:
+        # both operands stay row-major: the TN MFMA kernel gathers its fragments with transposed LDS reads.
+        # zero-initialised + accumulate: the long reduction is split over workgroups (fp32 atomics)
+        c = torch.zeros(N, K, device=a.device, dtype=torch.float32)
+        gemm(N, K, M, (a, 0), (1, a.stride(0), 0, 0), (b, 0), (b.stride(0), 1, 0, 0), (c, 0), (K, 1, 0, 0),
+             accumulate=True)
+    elif a.dtype == torch.bfloat16:
         at, bt = transpose_pad(a), transpose_pad(b)
         Mp = at.shape[1]
-        # zero-initialised + accumulate: lets the C side split the long reduction over workgroups (fp32 atomics)
         c = torch.zeros(N, K, device=a.device, dtype=torch.float32)
         gemm(N, K, Mp, (at, 0), (Mp, 1, 0, 0), (bt, 0), (1, Mp, 0, 0), (c, 0), (K, 1, 0, 0), accumulate=True)
     else:
@@ -150,6 +160,15 @@ def cast(x, dtype):
 # bf16 shadow copies of the fp32 master weights (and their transposes), refreshed when the parameter's
 # version counter changes (optimizer steps are in-place).
 _shadow_cache = {}
+_shadow_gen = 0
+
+
+def invalidate_shadows():
+    """Fused optimizers (torch._fused_adamw_) update parameters in place WITHOUT bumping Tensor._version, so the
+    version counter alone cannot tell that a bf16 shadow is stale.  construct_optimizer() registers this as an
+    optimizer post-step hook; call it yourself after any other out-of-band parameter update."""
+    global _shadow_gen
+    _shadow_gen += 1
 
 
 def shadow(w, dtype, transposed=False):
@@ -157,7 +176,7 @@ def shadow(w, dtype, transposed=False):
         return w.detach()
     key = (id(w), dtype, transposed)
     hit = _shadow_cache.get(key)
-    if hit is not None and hit[0]() is w and hit[1] == (w._version, w.data_ptr()):
+    if hit is not None and hit[0]() is w and hit[1] == (w._version, w.data_ptr(), _shadow_gen):
         return hit[2]
     wd = w.detach()
     if transposed:
@@ -168,7 +187,7 @@ def shadow(w, dtype, transposed=False):
     else:
         out = cast(wd, dtype)
     _shadow_cache[key] = (weakref.ref(w, lambda _r, k=key: _shadow_cache.pop(k, None)),
-                          (w._version, w.data_ptr()), out)
+                          (w._version, w.data_ptr(), _shadow_gen), out)
     return out
 
 

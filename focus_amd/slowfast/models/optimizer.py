@@ -23,8 +23,13 @@ def construct_optimizer(model, cfg):
     method = cfg.SOLVER.OPTIMIZING_METHOD
     if method == "adamw":
         fused = all(p.is_cuda for p in decay + no_decay)
-        return torch.optim.AdamW(groups, lr=cfg.SOLVER.BASE_LR, eps=1e-08, fused=fused)
-    if method == "sgd":
-        return torch.optim.SGD(groups, lr=cfg.SOLVER.BASE_LR, momentum=cfg.SOLVER.MOMENTUM,
-                               dampening=cfg.SOLVER.DAMPENING, nesterov=cfg.SOLVER.NESTEROV)
-    raise NotImplementedError("Does not support {} optimizer".format(method))
+        opt = torch.optim.AdamW(groups, lr=cfg.SOLVER.BASE_LR, eps=1e-08, fused=fused)
+    elif method == "sgd":
+        opt = torch.optim.SGD(groups, lr=cfg.SOLVER.BASE_LR, momentum=cfg.SOLVER.MOMENTUM,
+                              dampening=cfg.SOLVER.DAMPENING, nesterov=cfg.SOLVER.NESTEROV)
+    else:
+        raise NotImplementedError("Does not support {} optimizer".format(method))
+    # fused optimizers do not bump Tensor._version: tell the bf16 weight shadows that the masters moved
+    from focus_amd import ops
+    opt.register_step_post_hook(lambda *_a, **_k: ops.invalidate_shadows())
+    return opt

@@ -304,6 +304,36 @@ def test_motionformer_full_size_vs_oracle(oracle, mixed):
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in m.parameters())
 
 
+def test_training_steps_keep_bf16_shadows_fresh(oracle):
+    """Regression: torch's fused AdamW updates parameters without bumping Tensor._version; the bf16 weight shadows
+    must still follow the fp32 masters (optimizer post-step hook).  Two real optimizer steps, then product vs oracle
+    on the UPDATED weights."""
+    from focus_amd.slowfast.models import build_model
+    from focus_amd.slowfast.models.losses import get_loss_func
+    from focus_amd.slowfast.models.optimizer import construct_optimizer
+    from focus_amd.train import train_step
+    a, p = load_golden("motionformer_small")
+    cfg = _small_cfg(True)
+    cfg.merge_from_list(["SOLVER.OPTIMIZING_METHOD", "adamw", "SOLVER.BASE_LR", 3e-3, "SOLVER.WEIGHT_DECAY", 0.0,
+                         "SOLVER.CLIP_GRAD_L2NORM", 1.0])
+    m = build_model(cfg)
+    m.load_state_dict({k: v.float() for k, v in p.items()})
+    m.train()
+    opt = construct_optimizer(m, cfg)
+    loss_fun = get_loss_func(cfg)(reduction="mean")
+    x, boxes = T(a["x"]).to(dev()), T(a["boxes"]).to(dev())
+    labels = torch.from_numpy(a["labels"]).to(dev())
+    for _ in range(2):
+        train_step(m, opt, loss_fun, [x], labels, {"orvit_bboxes": boxes}, cfg)
+    moved = float((m.blocks[0].attn.qkv.weight.detach().cpu() - p["blocks.0.attn.qkv.weight"].float()).abs().max())
+    assert moved > 1e-3                                       # the masters really changed
+    params = {k: v.detach().float().cpu() for k, v in m.state_dict().items()}
+    ocfg = dict(depth=3, heads=4, orvit_layers=[1], temporal_resolution=2, patch=(2, 16, 16), crop=64)
+    ref = oracle.motionformer_forward(params, T(a["x"]), T(a["boxes"]), ocfg, training=True)
+    got = m([x], {"orvit_bboxes": boxes})
+    close(got, ref, 5e-2, "logits after 2 optimizer steps")
+
+
 def test_state_dict_abi_224():
     """Checkpoint ABI: parameter names/shapes of the full-size model equal the reference's (fixture)."""
     from focus_amd.slowfast.config.defaults import get_cfg
