@@ -157,16 +157,23 @@ def main():
         for _ in range(args.steps):
             train_step(model, optimizer, loss_fun, inputs, labels, meta, cfg)
         torch.cuda.synchronize()
-        recs, ops.GEMM_TIMING = ops.GEMM_TIMING, None
+        allrecs, ops.GEMM_TIMING = ops.GEMM_TIMING, None
+        recs = [r for r in allrecs if r[3] == "nt"]          # the dominant kernel: forward / dX GEMMs
+        tn = [r for r in allrecs if r[3] == "tn"]            # weight-gradient kernel, reported beside it
         fl = sum(r[0] for r in recs)
         ms = sum(r[1].elapsed_time(r[2]) for r in recs)
         ach = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        tn_ms = sum(r[1].elapsed_time(r[2]) for r in tn)
+        tn_tf = sum(r[0] for r in tn) / (tn_ms * 1e-3) / 1e12 if tn_ms > 0 else 0.0
         out["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                            "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None,
                            "kernel": "gemm_nt_kernel<bf16> (focus_amd/csrc/gemm_mfma.hip)",
                            "launches_per_step": len(recs) // max(args.steps, 1),
                            "avg_launch_us": round(1e3 * ms / max(len(recs), 1), 2),
-                           "kernel_ms_per_step": round(ms / max(args.steps, 1), 3)}
+                           "kernel_ms_per_step": round(ms / max(args.steps, 1), 3),
+                           "weight_grad_kernel": {"kernel": "gemm_tn_kernel (gemm_mfma_tn.hip)",
+                                                  "achieved": round(tn_tf, 2),
+                                                  "ms_per_step": round(tn_ms / max(args.steps, 1), 3)}}
     elif world > 1 and not args.no_roofline and not args.fp32:
         for _ in range(args.steps):       # keep ranks in lock-step with rank 0's instrumented pass
             train_step(model, optimizer, loss_fun, inputs, labels, meta, cfg)

@@ -11,3 +11,6 @@ bool focus_gemm_mfma_nt_ok(const focus_gemm_desc& d);
 // bf16 MFMA kernel for operands strided along the reduction (dW = dY^T . X from row-major activations).
 bool focus_gemm_mfma_tn_ok(const focus_gemm_desc& d);
 int focus_gemm_mfma_tn(const focus_gemm_desc& d, hipStream_t s);
+// wave-specialised (4 consumer + 4 loader waves, 3-stage ring) NT kernel for bf16 output with aligned rows
+bool focus_gemm_mfma_ws_ok(const focus_gemm_desc& d);
+int focus_gemm_mfma_ws(const focus_gemm_desc& d, hipStream_t s);

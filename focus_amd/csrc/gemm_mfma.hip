@@ -75,9 +75,15 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void gemm_nt_kernel(cons
     auto unit_of = [&](int i) __attribute__((always_inline)) {
         const int u = band0 + j + i * gx;
         const int split = u % splits, tile = u / splits;
+        // grouped order: ids walk 8 row-tiles down, then one column-tile right, so the ~64 units an XCD has in flight
+        // at a time form an 8 x 8 patch of the output: 8 A panels + 8 B panels (~3 MB at K=768) stay in its 4 MB L2
+        // instead of 3 A panels + every B panel.  LDS fill is L2-bandwidth bound: this is worth ~1.3-2x.
+        constexpr int GM = 8;
+        const int group = tile / (GM * tiles_n), first_m = group * GM;
+        const int gsz = min(tiles_m - first_m, GM), in_g = tile - group * GM * tiles_n;
         Unit t;
-        t.m0 = (tile / tiles_n) * BM;
-        t.n0 = (tile % tiles_n) * BN;
+        t.m0 = (first_m + in_g % gsz) * BM;
+        t.n0 = (in_g / gsz) * BN;
         t.k0 = split * k_per_split;
         t.nk = (min(d.K, t.k0 + k_per_split) - t.k0) / BK;
         return t;
@@ -125,18 +131,24 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void gemm_nt_kernel(cons
         const char* sb = sa + A_BYTES;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            bf16x8 fa[TM], fb[TN];
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-                fa[i] = *reinterpret_cast<const bf16x8*>(sa + swz(wm * WTM + i * 16 + frow, ks * 4 + fq));
+            bf16x8 fb[TN];
 #pragma unroll
             for (int jj = 0; jj < TN; ++jj)
                 fb[jj] = *reinterpret_cast<const bf16x8*>(sb + swz(wn * WTN + jj * 16 + frow, ks * 4 + fq));
+            // A fragments in groups of 4 rows-of-tiles: keeps the live fragment set at 4+TN (register budget of
+            // the 128x64-per-wave configuration)
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
+            for (int i0 = 0; i0 < TM; i0 += 4) {
+                bf16x8 fa[4];
 #pragma unroll
-                for (int jj = 0; jj < TN; ++jj)
-                    acc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[jj], fa[i], acc[i][jj], 0, 0, 0);
+                for (int i = 0; i < 4; ++i)
+                    fa[i] = *reinterpret_cast<const bf16x8*>(sa + swz(wm * WTM + (i0 + i) * 16 + frow, ks * 4 + fq));
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int jj = 0; jj < TN; ++jj)
+                        acc[i0 + i][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[jj], fa[i], acc[i0 + i][jj], 0, 0, 0);
+            }
         }
     };
 
@@ -403,9 +415,11 @@ int focus_gemm_mfma_nt(const focus_gemm_desc& d, hipStream_t s) {
         return launch_nt<128, 128, 2, 2>(d, splits, s);
     }
     (void)t256;
+    if (focus_gemm_mfma_ws_ok(d)) return focus_gemm_mfma_ws(d, s);
     static const int variant = getenv("FOCUS_GEMM_VARIANT") ? atoi(getenv("FOCUS_GEMM_VARIANT")) : 0;
     switch (variant) {   // tuning hook (tools/gemm_sweep.py); 0 is the shipped configuration
         case 4: return launch_nt<256, 128, 4, 2>(d, 1, s);
+        case 7: return launch_nt<256, 256, 2, 4>(d, 1, s);
         case 6: return launch_nt<128, 256, 2, 4>(d, 1, s);
         default: return launch_nt<128, 128, 2, 2>(d, 1, s);
     }

@@ -25,6 +25,35 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, fl
     }
 }
 
+// 16-byte loads: thread (tx, ty) sums columns 8*tx..8*tx+7 over rows ty, ty+8, ... of its strip
+__global__ __launch_bounds__(256) void colsum_bf16_vec_kernel(const bf16_t* __restrict__ x, float* __restrict__ out,
+                                                              int M, int N, int64_t ld_, int rows_per_block) {
+    __shared__ float red[8][32][9];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int c = (blockIdx.x * 32 + tx) * 8;
+    const int m_begin = blockIdx.y * rows_per_block, m_end = min(M, m_begin + rows_per_block);
+    float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (c < N)
+        for (int m = m_begin + ty; m < m_end; m += 8) {
+            const uint4 v = *reinterpret_cast<const uint4*>(x + (int64_t)m * ld_ + c);
+            s[0] += __uint_as_float(v.x << 16); s[1] += __uint_as_float(v.x & 0xffff0000u);
+            s[2] += __uint_as_float(v.y << 16); s[3] += __uint_as_float(v.y & 0xffff0000u);
+            s[4] += __uint_as_float(v.z << 16); s[5] += __uint_as_float(v.z & 0xffff0000u);
+            s[6] += __uint_as_float(v.w << 16); s[7] += __uint_as_float(v.w & 0xffff0000u);
+        }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) red[ty][tx][j] = s[j];
+    __syncthreads();
+    const int j = threadIdx.x & 7, t2 = threadIdx.x >> 3;     // 32 column groups x 8 columns
+    const int cc = (blockIdx.x * 32 + t2) * 8 + j;
+    if (cc < N) {
+        float t = 0.f;
+#pragma unroll
+        for (int y = 0; y < 8; ++y) t += red[y][t2][j];
+        atomicAdd(out + cc, t);
+    }
+}
+
 template <typename TS, typename TD>
 __global__ void cast_kernel(const TS* __restrict__ s, TD* __restrict__ d, int64_t n) {
     int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
@@ -237,6 +266,13 @@ extern "C" int focus_colsum(const void* x, float* out, int M, int N, int64_t row
     if (M <= 0 || N <= 0) return FOCUS_OK;
     hipStream_t s = (hipStream_t)stream;
     if (!accumulate && hipMemsetAsync(out, 0, sizeof(float) * N, s) != hipSuccess) return FOCUS_ERR_LAUNCH;
+    if (dtype == FOCUS_BF16 && (N & 7) == 0 && (row_stride & 7) == 0 && focus_aligned(x, 16)) {
+        const int rpb = 512;
+        hipLaunchKernelGGL(colsum_bf16_vec_kernel, dim3((N + 255) / 256, (M + rpb - 1) / rpb), dim3(256), 0, s,
+                           (const bf16_t*)x, out, M, N, row_stride, rpb);
+        FOCUS_CHECK_LAUNCH();
+        return FOCUS_OK;
+    }
     const int rpb = 256;
     dim3 grid((N + 63) / 64, (M + rpb - 1) / rpb);
     DISPATCH_T(dtype, hipLaunchKernelGGL((colsum_kernel<T>), grid, dim3(256), 0, s, (const T*)x, out, M, N,

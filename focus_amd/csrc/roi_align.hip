@@ -88,6 +88,8 @@ __global__ __launch_bounds__(256) void roi_fwd_kernel(const T* __restrict__ feat
     }
 }
 
+// One lane per channel: every atomic wave-instruction adds 256 contiguous bytes of one feature cell (the shape the
+// memory-side float atomics run fastest at -- MI355X_MICROARCH.md "Global float atomics").
 template <typename T>
 __global__ __launch_bounds__(256) void roi_bwd_kernel(const T* __restrict__ dout, const float* __restrict__ rois,
                                                       const int32_t* __restrict__ roi_img, float* __restrict__ dfeat,
@@ -96,28 +98,24 @@ __global__ __launch_bounds__(256) void roi_bwd_kernel(const T* __restrict__ dout
     const int k = blockIdx.y, ph = blockIdx.x;
     const Geom g = roi_geometry(rois + 4 * k, scale, PH, PW, sr, aligned);
     float* img = dfeat + (int64_t)roi_img[k] * H * W * C;
-    const int cq = C >> 2;
-    for (int it = threadIdx.x; it < PW * cq; it += 256) {
-        const int pw = it / cq, c = (it % cq) * 4;
-        f4 gr = ld4<T>(dout + ((int64_t)k * PH * PW + ph * PW + pw) * C + c);
-        gr.x /= g.count; gr.y /= g.count; gr.z /= g.count; gr.w /= g.count;
+    for (int pw = 0; pw < PW; ++pw) {
+        const T* drow = dout + ((int64_t)k * PH * PW + ph * PW + pw) * C;
         for (int iy = 0; iy < g.grid_h; ++iy) {
             const float y = sample_coord(g.y1, ph, g.bin_h, iy, g.grid_h);
             for (int ix = 0; ix < g.grid_w; ++ix) {
                 const float x = sample_coord(g.x1, pw, g.bin_w, ix, g.grid_w);
-                const Nbr n = locate(y, x, H, W);
+                const Nbr n = locate(y, x, H, W);           // block-uniform
                 if (n.y_low < 0) continue;
-                float* p1 = img + (int64_t)(n.y_low * W + n.x_low) * C + c;
-                float* p2 = img + (int64_t)(n.y_low * W + n.x_high) * C + c;
-                float* p3 = img + (int64_t)(n.y_high * W + n.x_low) * C + c;
-                float* p4 = img + (int64_t)(n.y_high * W + n.x_high) * C + c;
-                const float gv[4] = {gr.x, gr.y, gr.z, gr.w};
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    atomicAdd(p1 + j, gv[j] * n.w1);
-                    atomicAdd(p2 + j, gv[j] * n.w2);
-                    atomicAdd(p3 + j, gv[j] * n.w3);
-                    atomicAdd(p4 + j, gv[j] * n.w4);
+                float* p1 = img + (int64_t)(n.y_low * W + n.x_low) * C;
+                float* p2 = img + (int64_t)(n.y_low * W + n.x_high) * C;
+                float* p3 = img + (int64_t)(n.y_high * W + n.x_low) * C;
+                float* p4 = img + (int64_t)(n.y_high * W + n.x_high) * C;
+                for (int c = threadIdx.x; c < C; c += 256) {
+                    const float gv = ld<T>(drow + c) / g.count;
+                    if (n.w1 != 0.f) atomicAdd(p1 + c, gv * n.w1);
+                    if (n.w2 != 0.f) atomicAdd(p2 + c, gv * n.w2);
+                    if (n.w3 != 0.f) atomicAdd(p3 + c, gv * n.w3);
+                    if (n.w4 != 0.f) atomicAdd(p4 + c, gv * n.w4);
                 }
             }
         }

@@ -21,10 +21,10 @@ __device__ __forceinline__ float dot64(const T* row, const float* q) {
 
 // dynamic LDS: prob[N] floats
 template <typename T>
-__global__ __launch_bounds__(256) void cls_fwd_kernel(const T* __restrict__ qkv, T* __restrict__ cls_out,
+__global__ __launch_bounds__(1024) void cls_fwd_kernel(const T* __restrict__ qkv, T* __restrict__ cls_out,
                                                       float* __restrict__ cls_lse, int N, int heads) {
     extern __shared__ __attribute__((aligned(16))) float prob[];
-    __shared__ float sq[HD], red[16], part[4][HD];
+    __shared__ float sq[HD], red[16], part[16][HD];
     const int bh = blockIdx.x, b = bh / heads, hh = bh % heads, C = heads * HD;
     const int64_t tok = 3 * (int64_t)C;
     const T* base = qkv + (int64_t)b * N * tok + hh * HD;
@@ -32,25 +32,26 @@ __global__ __launch_bounds__(256) void cls_fwd_kernel(const T* __restrict__ qkv,
     if (threadIdx.x < HD) sq[threadIdx.x] = ld<T>(base + threadIdx.x) * scale;
     __syncthreads();
     float m = -INFINITY;
-    for (int n = threadIdx.x; n < N; n += 256) {
+    for (int n = threadIdx.x; n < N; n += 1024) {
         const float l = dot64<T>(base + (int64_t)n * tok + C, sq);
         prob[n] = l;
         m = fmaxf(m, l);
     }
     m = block_max(m, red);
     float s = 0.f;
-    for (int n = threadIdx.x; n < N; n += 256) { const float e = __expf(prob[n] - m); prob[n] = e; s += e; }
+    for (int n = threadIdx.x; n < N; n += 1024) { const float e = __expf(prob[n] - m); prob[n] = e; s += e; }
     s = block_sum(s, red);
     __syncthreads();
     const float inv = 1.f / s;
     const int dch = threadIdx.x & 63, pr = threadIdx.x >> 6;
     float acc = 0.f;
-    for (int n = pr; n < N; n += 4) acc += prob[n] * ld<T>(base + (int64_t)n * tok + 2 * C + dch);
+    for (int n = pr; n < N; n += 16) acc += prob[n] * ld<T>(base + (int64_t)n * tok + 2 * C + dch);
     part[pr][dch] = acc;
     __syncthreads();
     if (threadIdx.x < HD) {
-        st<T>(cls_out + (int64_t)b * C + hh * HD + threadIdx.x,
-              (part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x]) * inv);
+        float t = 0.f;
+        for (int y = 0; y < 16; ++y) t += part[y][threadIdx.x];
+        st<T>(cls_out + (int64_t)b * C + hh * HD + threadIdx.x, t * inv);
         if (threadIdx.x == 0) cls_lse[bh] = m + __logf(s);
     }
 }
@@ -58,13 +59,13 @@ __global__ __launch_bounds__(256) void cls_fwd_kernel(const T* __restrict__ qkv,
 // Adds the cls-row contributions onto dqkv: rows 1.. of the k and v parts are read-modify-written (the patch
 // kernels wrote them first); row 0 of the q, k and v parts is written plainly.
 template <typename T>
-__global__ __launch_bounds__(256) void cls_bwd_kernel(const T* __restrict__ qkv, const float* __restrict__ cls_lse,
+__global__ __launch_bounds__(1024) void cls_bwd_kernel(const T* __restrict__ qkv, const float* __restrict__ cls_lse,
                                                       const T* __restrict__ dcls, T* __restrict__ dqkv, int N,
                                                       int heads) {
     extern __shared__ __attribute__((aligned(16))) float buf[];   // prob[N] | dlog[N]
     float* prob = buf;
     float* dlog = buf + N;
-    __shared__ float sq[HD], sd[HD], red[16], part[4][HD];
+    __shared__ float sq[HD], sd[HD], red[16], part[16][HD];
     const int bh = blockIdx.x, b = bh / heads, hh = bh % heads, C = heads * HD;
     const int64_t tok = 3 * (int64_t)C;
     const T* base = qkv + (int64_t)b * N * tok + hh * HD;
@@ -76,7 +77,7 @@ __global__ __launch_bounds__(256) void cls_bwd_kernel(const T* __restrict__ qkv,
     }
     __syncthreads();
     float dot = 0.f;
-    for (int n = threadIdx.x; n < N; n += 256) {
+    for (int n = threadIdx.x; n < N; n += 1024) {
         const T* row = base + (int64_t)n * tok;
         const float a = __expf(dot64<T>(row + C, sq) - lse);
         const float da = dot64<T>(row + 2 * C, sd);
@@ -94,7 +95,7 @@ __global__ __launch_bounds__(256) void cls_bwd_kernel(const T* __restrict__ qkv,
     }
     dot = block_sum(dot, red);
     __syncthreads();
-    for (int n = threadIdx.x; n < N; n += 256) {
+    for (int n = threadIdx.x; n < N; n += 1024) {
         const float dl = scale * prob[n] * (dlog[n] - dot);      // d logit (scale included)
         dlog[n] = dl;
         // dK[n,:] (+)= dl * q0   (sq already carries one factor `scale`: divide it back out)
@@ -111,11 +112,14 @@ __global__ __launch_bounds__(256) void cls_bwd_kernel(const T* __restrict__ qkv,
     // dq0[:] = sum_n dl[n] * k[n,:]
     const int dch = threadIdx.x & 63, pr = threadIdx.x >> 6;
     float acc = 0.f;
-    for (int n = pr; n < N; n += 4) acc += dlog[n] * ld<T>(base + (int64_t)n * tok + C + dch);
+    for (int n = pr; n < N; n += 16) acc += dlog[n] * ld<T>(base + (int64_t)n * tok + C + dch);
     part[pr][dch] = acc;
     __syncthreads();
-    if (threadIdx.x < HD)
-        st<T>(dbase + threadIdx.x, part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x]);
+    if (threadIdx.x < HD) {
+        float t = 0.f;
+        for (int y = 0; y < 16; ++y) t += part[y][threadIdx.x];
+        st<T>(dbase + threadIdx.x, t);
+    }
 }
 
 }  // namespace
@@ -126,10 +130,10 @@ bool focus_traj_cls_ok(int N, int d) { return d == HD && N <= 8000; }
 int focus_traj_cls_fwd(const void* qkv, void* cls_out, float* cls_lse, int B, int N, int heads, int dtype, hipStream_t s) {
     const size_t lds = (size_t)N * sizeof(float);
     if (dtype == FOCUS_BF16)
-        hipLaunchKernelGGL((cls_fwd_kernel<bf16_t>), dim3(B * heads), dim3(256), lds, s, (const bf16_t*)qkv,
+        hipLaunchKernelGGL((cls_fwd_kernel<bf16_t>), dim3(B * heads), dim3(1024), lds, s, (const bf16_t*)qkv,
                            (bf16_t*)cls_out, cls_lse, N, heads);
     else
-        hipLaunchKernelGGL((cls_fwd_kernel<float>), dim3(B * heads), dim3(256), lds, s, (const float*)qkv,
+        hipLaunchKernelGGL((cls_fwd_kernel<float>), dim3(B * heads), dim3(1024), lds, s, (const float*)qkv,
                            (float*)cls_out, cls_lse, N, heads);
     FOCUS_CHECK_LAUNCH();
     return FOCUS_OK;
@@ -139,10 +143,10 @@ int focus_traj_cls_bwd(const void* qkv, const float* cls_lse, const void* dcls, 
                        int dtype, hipStream_t s) {
     const size_t lds = (size_t)2 * N * sizeof(float);
     if (dtype == FOCUS_BF16)
-        hipLaunchKernelGGL((cls_bwd_kernel<bf16_t>), dim3(B * heads), dim3(256), lds, s, (const bf16_t*)qkv, cls_lse,
+        hipLaunchKernelGGL((cls_bwd_kernel<bf16_t>), dim3(B * heads), dim3(1024), lds, s, (const bf16_t*)qkv, cls_lse,
                            (const bf16_t*)dcls, (bf16_t*)dqkv, N, heads);
     else
-        hipLaunchKernelGGL((cls_bwd_kernel<float>), dim3(B * heads), dim3(256), lds, s, (const float*)qkv, cls_lse,
+        hipLaunchKernelGGL((cls_bwd_kernel<float>), dim3(B * heads), dim3(1024), lds, s, (const float*)qkv, cls_lse,
                            (const float*)dcls, (float*)dqkv, N, heads);
     FOCUS_CHECK_LAUNCH();
     return FOCUS_OK;

@@ -51,11 +51,14 @@ GEMM_TIMING = None
 
 
 def _mfma_path(ta, sA, sB, K):
+    """'nt' / 'tn' when the C dispatcher will take that MFMA kernel for this descriptor, else None."""
     if ta.dtype != torch.bfloat16:
-        return False
-    nt = sA[1] == 1 and sB[0] == 1 and K > 0 and K % 64 == 0 and sA[0] % 8 == 0 and sB[1] % 8 == 0
-    tn = sA[0] == 1 and sB[1] == 1 and sA[1] % 8 == 0 and sB[0] % 8 == 0
-    return nt or tn
+        return None
+    if sA[1] == 1 and sB[0] == 1 and K > 0 and K % 64 == 0 and sA[0] % 8 == 0 and sB[1] % 8 == 0:
+        return "nt"
+    if sA[0] == 1 and sB[1] == 1 and sA[1] % 8 == 0 and sB[0] % 8 == 0:
+        return "tn"
+    return None
 
 
 def gemm(M, N, K, A, sA, B, sB, C, sC, batch=(1, 1), bias=None, residual=None, aux=None, alpha=1.0,
@@ -78,12 +81,13 @@ def gemm(M, N, K, A, sA, B, sB, C, sC, batch=(1, 1), bias=None, residual=None, a
     d.dtype_ab = _dt(ta)
     d.dtype_c = _dt(tc)
     assert ta.dtype == tb.dtype
-    if GEMM_TIMING is not None and _mfma_path(ta, sA, sB, K):
+    kind = _mfma_path(ta, sA, sB, K) if GEMM_TIMING is not None else None
+    if kind:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         _lib.check(_lib.lib().focus_gemm(ctypes.byref(d), _stream()), "gemm")
         e1.record()
-        GEMM_TIMING.append((2.0 * M * N * K * batch[0] * batch[1], e0, e1))
+        GEMM_TIMING.append((2.0 * M * N * K * batch[0] * batch[1], e0, e1, kind))
         return
     _lib.check(_lib.lib().focus_gemm(ctypes.byref(d), _stream()), "gemm")
 
