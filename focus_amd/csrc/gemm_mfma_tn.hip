@@ -49,8 +49,14 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const focus_gemm_desc d
     const int bid = blockIdx.x;
     const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
     const int lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-    const int split = lid % splits, tile = lid / splits;
-    const int i0 = (tile / tiles_j) * BI, j0 = (tile % tiles_j) * BJ;
+    // split-major order: the workgroups an XCD runs together work on the SAME slice of the reduction and on an
+    // 8-row-tile-deep patch of the output, so the P and Q rows of that slice are fetched into its L2 once and shared
+    const int tiles = tiles_i * tiles_j;
+    const int split = lid / tiles, tile = lid % tiles;
+    constexpr int GM = 8;
+    const int group = tile / (GM * tiles_j), first_i = group * GM;
+    const int gsz = min(tiles_i - first_i, GM), in_g = tile - group * GM * tiles_j;
+    const int i0 = (first_i + in_g % gsz) * BI, j0 = (in_g / gsz) * BJ;
     const int Mred = d.K;                                   // reduction length (rows of P and Q)
     const int m_begin = split * m_per_split;
     const int m_end = min(Mred, m_begin + m_per_split);
@@ -118,24 +124,24 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const focus_gemm_desc d
         }
     };
 
+    // only the last K-step of the last split can hold rows past the end of the reduction
+    const bool has_tail = (m_end - m_begin) % BKM != 0;
     stage(0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    zero_tail(0, 0);
-    __syncthreads();
+    if (has_tail && nk == 1) { zero_tail(0, 0); __syncthreads(); }
     int kt = 0;
     for (; kt + 1 < nk; kt += 2) {
         stage(1, kt + 1);
         compute(0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        zero_tail(1, kt + 1);
+        if (has_tail && kt + 2 == nk) { zero_tail(1, kt + 1); __syncthreads(); }
         if (kt + 2 < nk) stage(0, kt + 2);
-        __syncthreads();                       // tail zeroing visible before stage 1 is read (uniform, cheap)
         compute(1);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (kt + 2 < nk) { zero_tail(0, kt + 2); __syncthreads(); }
+        if (has_tail && kt + 3 == nk) { zero_tail(0, kt + 2); __syncthreads(); }
     }
     if (kt < nk) compute(0);
 

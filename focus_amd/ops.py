@@ -403,6 +403,79 @@ def traj_time(q2, k2, xt, heads):
     return _TrajTimeFn.apply(q2, k2, xt, heads)
 
 
+class _TrajTime2Fn(torch.autograd.Function):
+    """Temporal step in re-associated form (include/focus_amd.h: focus_traj_time2_*): the k2 = proj_kv(x~) GEMM over
+    all S*F rows is replaced by u = Wk[h]^T q2 (a per-head GEMM over S rows) + one HBM-bound kernel."""
+
+    @staticmethod
+    def forward(ctx, q2, xt, wk, bk, heads):
+        _need_gpu(q2, xt, wk)
+        B, S, F_, C = xt.shape
+        d = C // heads
+        q2 = q2.contiguous().view(B * S, C)
+        xt = xt.contiguous()
+        u = torch.empty(B * S, heads, C, device=xt.device, dtype=xt.dtype)
+        if xt.dtype == torch.bfloat16:
+            wkt = shadow(wk, xt.dtype, transposed=True)                  # [C_in, C_out]: K(=dd)-contiguous rows
+            gemm(B * S, C, d, (q2, 0), (C, 1, 0, d), (wkt, 0), (1, C, 0, d), (u, 0), (heads * C, 1, 0, C),
+                 batch=(1, heads))
+        else:
+            w = shadow(wk, xt.dtype)
+            gemm(B * S, C, d, (q2, 0), (C, 1, 0, d), (w, 0), (C, 1, 0, d * C), (u, 0), (heads * C, 1, 0, C),
+                 batch=(1, heads))
+        out = torch.empty(B, S, C, device=xt.device, dtype=xt.dtype)
+        attn2 = torch.empty(B, heads, S, F_, device=xt.device, dtype=torch.float32)
+        _lib.check(_lib.lib().focus_traj_time2_fwd(_p(u), _p(xt), _p(out), _p(attn2), B, S, F_, heads, d, _dt(xt),
+                                                   _stream()), "traj_time2_fwd")
+        ctx.save_for_backward(q2, xt, wk, u, attn2)
+        ctx.heads, ctx.has_b = heads, bk is not None
+        ctx.bshape = bk.shape if bk is not None else None
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        q2, xt, wk, u, attn2 = ctx.saved_tensors
+        heads = ctx.heads
+        B, S, F_, C = xt.shape
+        d = C // heads
+        dout = dout.contiguous()
+        du, dxt = torch.empty_like(u), torch.empty_like(xt)
+        _lib.check(_lib.lib().focus_traj_time2_bwd(_p(u), _p(xt), _p(attn2), _p(dout), _p(du), _p(dxt), 0, B, S, F_,
+                                                   heads, d, _dt(xt), _stream()), "traj_time2_bwd")
+        # dq2[:, h*d+dd] = sum_c du[:, h, c] * wk[h*d+dd, c]
+        w = shadow(wk, xt.dtype)
+        dq2 = torch.empty(B * S, C, device=xt.device, dtype=xt.dtype)
+        gemm(B * S, d, C, (du, 0), (heads * C, 1, 0, C), (w, 0), (1, C, 0, d * C), (dq2, 0), (C, 1, 0, d),
+             batch=(1, heads))
+        # dwk[h*d+dd, c] = sum_s q2[s, h*d+dd] * du[s, h, c]   (reduction over the rows of both operands)
+        dwk = torch.zeros(C, C, device=xt.device, dtype=torch.float32)
+        for h in range(heads):
+            gemm(d, C, B * S, (q2, h * d), (1, C, 0, 0), (du, h * C), (heads * C, 1, 0, 0), (dwk, h * d * C),
+                 (C, 1, 0, 0), accumulate=True)
+        dbk = torch.zeros(ctx.bshape, device=xt.device, dtype=torch.float32) if ctx.has_b else None
+        return dq2.view(B, S, C), dxt, dwk, dbk, None
+
+
+import os as _os
+_TIME2 = _os.environ.get("FOCUS_TIME2", "0") == "1"
+
+
+def traj_time2_ok(F_, heads, C):
+    """Opt-in (FOCUS_TIME2=1).  Measured on MI355X at B=8: the re-associated form removes 355 GF of GEMM per block
+    but its per-head GEMMs (K=64 / N=64) and the u/du round trips cost the same ~1.4 ms per block as the k2 path;
+    it pays only once u is formed inside the time kernel (VERDICT follow-up)."""
+    if not _TIME2:
+        return False
+    d = C // heads
+    lph = d // 4
+    return F_ == 8 and d % 4 == 0 and lph >= 1 and (lph & (lph - 1)) == 0 and heads <= 16 and C <= 768 and C % 8 == 0
+
+
+def traj_time2(q2, xt, wk, bk, heads):
+    """out [B,S,C] of the temporal step from q2 (un-scaled proj_q output), x~ and the k half of proj_kv."""
+    return _TrajTime2Fn.apply(q2, xt, wk, bk, heads)
+
+
 # --------------------------------------------------------------------------------------------------
 # Small joint attention (motion stream: attention.py:369-385; slot predictor: transformer.py:23-49)
 # --------------------------------------------------------------------------------------------------

@@ -9,9 +9,13 @@ from ..common import DropPath
 from .utils import Mlp, ObjectsCrops, box2spatial_layout
 
 
-def _relu_pair(seq, x):
-    """nn.Sequential(Linear(no bias), ReLU, Linear(no bias), ReLU): one fused 2-GEMM op + final ReLU."""
-    return torch.relu(ops.mlp(x, seq[0].weight, None, seq[2].weight, None, act=ops.EPI_RELU))
+def _relu_pair(seq, x, dtype=None):
+    """nn.Sequential(Linear(no bias), ReLU, Linear(no bias), ReLU) on the 4-d box coordinates: the first layer
+    (K=4) stays in fp32 on the raw coordinates, the second runs in the compute dtype (MFMA when bf16)."""
+    hid = torch.relu(ops.linear(x.float(), seq[0].weight))
+    if dtype is not None and dtype != hid.dtype:
+        hid = hid.to(dtype)
+    return torch.relu(ops.linear(hid, seq[2].weight))
 
 
 class ORViT(nn.Module):
@@ -77,8 +81,8 @@ class ORViT(nn.Module):
         p2d = self.patch_to_d
         pre = ops.mlp(crops, p2d[0].weight, None, p2d[2].weight, None, act=ops.EPI_RELU)  # last ReLU commutes with max
         obj = torch.relu(ops.cell_amax(pre)).view(BS, T, O, d)
-        box_emb = _relu_pair(self.c_coord_to_feature, box_tensors)           # 4-d input: kept in fp32
-        obj = obj + (self.box_categories + box_emb).to(x.dtype)                               # :141-143
+        box_emb = _relu_pair(self.c_coord_to_feature, box_tensors, x.dtype)
+        obj = obj + self.box_categories.to(x.dtype) + box_emb                               # :141-143
 
         all_tokens = torch.cat([patch_tokens.reshape(BS, T, H * W, d), obj], dim=2).flatten(1, 2)
         all_tokens = torch.cat([cls_token, all_tokens], dim=1)                              # :145-147
@@ -141,13 +145,13 @@ class MotionStream(nn.Module):
     def forward(self, box_tensors, H, W, dtype=None):
         BS = box_tensors.shape[0]
         dtype = dtype or box_tensors.dtype
-        box_emb = _relu_pair(self.c_coord_to_feature, box_tensors.float())   # 4-d input: kept in fp32
+        box_emb = _relu_pair(self.c_coord_to_feature, box_tensors, dtype)
         if self.cfg.ORVIT.MOTION_STREAM_SEP_POS_EMB:
             shape = (self.nb_frames, self.cfg.ORVIT.O, self.in_dim)
             cat = self.box_categories_T.expand(shape) + self.box_categories_O.expand(shape)
         else:
             cat = self.box_categories
-        box_emb = (cat.unsqueeze(0) + box_emb).to(dtype)                    # [BS,T,O,d]
+        box_emb = cat.to(dtype).unsqueeze(0) + box_emb                      # [BS,T,O,d]
         oshape = box_emb.shape
         box_emb, _ = self.attn(box_emb.flatten(1, -2), None, None)
         box_emb = box_emb.reshape(oshape)

@@ -88,8 +88,13 @@ class TrajectoryAttention(nn.Module):
         q2 = ops.linear(xdiag, self.proj_q.weight, self.proj_q.bias)               # :536 (scale applied in-kernel)
         wk = self.proj_kv.weight[:C]                                               # k2 half only (:537)
         bk = self.proj_kv.bias[:C] if self.proj_kv.bias is not None else None
-        k2 = ops.linear(xt, wk, bk)                                                # [B,S,F,C]
-        out = ops.traj_time(q2, k2, xt, h)                                         # :538-549
+        if ops.traj_time2_ok(F_, h, C):
+            # re-associated: logits = (Wk[h]^T q2) . x~ ; the bias term is constant over frames and cancels in
+            # the softmax -- k2 [B,S,F,C] (the block's largest GEMM) is never formed
+            out = ops.traj_time2(q2, xt, wk, bk, h)
+        else:
+            k2 = ops.linear(xt, wk, bk)                                            # [B,S,F,C]
+            out = ops.traj_time(q2, k2, xt, h)                                     # :538-549
         y = ops.linear(torch.cat((cls_out, out), dim=1), self.proj.weight, self.proj.bias, residual=residual)
         return y, thw_prev
 

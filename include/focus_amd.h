@@ -134,6 +134,18 @@ int focus_traj_time_bwd(const void* q2, const void* k2, const void* xt, const fl
                         const void* dout, void* dq2, void* dk2, void* dxt, int dxt_accum, int B, int S,
                         int F, int heads, int d, int dtype, void* stream);
 
+/* Re-associated time step.  With use_original_code=True the temporal logits are
+ *   scale * q2[s,h,:] . (Wk[h] x~[s,f,:] + bk[h])  =  scale * (Wk[h]^T q2[s,h,:]) . x~[s,f,:]  + (a term constant in f),
+ * and the softmax over f is shift invariant, so k2 = proj_kv(x~) (the largest GEMM of the block, 8x the tokens) is
+ * never formed: u [B,S,h,C] = Wk[h]^T q2[s,h,:] comes from a small per-head GEMM and these kernels read x~ once.
+ * Same outputs and gradients as focus_traj_time_* up to rounding order (proj_kv.bias gets its exact zero gradient).
+ *   fwd: u, xt -> out [B,S,C], attn2 [B,h,S,F] fp32.
+ *   bwd: dxt [B,S,F,C] (written, or accumulated onto when dxt_accum), du [B,S,h,C]. */
+int focus_traj_time2_fwd(const void* u, const void* xt, void* out, float* attn2, int B, int S, int F, int heads,
+                         int d, int dtype, void* stream);
+int focus_traj_time2_bwd(const void* u, const void* xt, const float* attn2, const void* dout, void* du, void* dxt,
+                         int dxt_accum, int B, int S, int F, int heads, int d, int dtype, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * RoIAlign over patch-token feature maps (ORViT/utils.py:58-75 -> torchvision.ops.roi_align with
  * output_size=(H,W), sampling_ratio=-1, aligned=True).  Channels-last on both sides:
