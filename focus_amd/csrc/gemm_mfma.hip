@@ -436,6 +436,8 @@ extern "C" int focus_gemm(const focus_gemm_desc* desc, void* stream) {
     if (d.accumulate && d.dtype_c != FOCUS_F32) return FOCUS_ERR_DTYPE;
     if (d.epilogue >= FOCUS_EPI_DGELU && !d.aux) return FOCUS_ERR_NULL;
     hipStream_t s = static_cast<hipStream_t>(stream);
+    if (focus_gemm_mfma_tn_ok(d)) return focus_gemm_mfma_tn(d, s);     // checked first: in this form aux is its slab workspace
+    if (d.aux && d.epilogue == FOCUS_EPI_NONE) d.aux = nullptr;
     if (focus_gemm_mfma_nt_ok(d)) return focus_gemm_mfma_nt(d, s);
     if (focus_gemm_mfma_tn_ok(d)) return focus_gemm_mfma_tn(d, s);
     return focus_gemm_generic(d, s);

@@ -66,7 +66,9 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const focus_gemm_desc d
     const bf16_t* Pm = static_cast<const bf16_t*>(d.A);     // P[m][i] : element (i, m) of "A" = Pm[m*ldp + i]
     const bf16_t* Qm = static_cast<const bf16_t*>(d.B);     // Q[m][j]
     const int64_t ldp = d.csA, ldq = d.rsB;
-    float* C = static_cast<float*>(d.C);
+    // slab mode: this split's partial tile goes to aux[split][M][N] with plain stores (summed by tn_reduce_kernel)
+    float* C = d.aux ? static_cast<float*>(d.aux) + (int64_t)split * d.M * d.N : static_cast<float*>(d.C);
+    const int64_t ldc = d.aux ? d.N : d.rsC;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -154,21 +156,59 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const focus_gemm_desc d
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
             const int gj = j0 + wj * 64 + b * 16 + fq * 4;
+            if (d.aux) {
+                if (gj < d.N)      // N % 8 == 0: the 4 columns are in range together
+                    *reinterpret_cast<float4*>(C + (int64_t)gi * ldc + gj) =
+                        make_float4(d.alpha * acc[a][b][0], d.alpha * acc[a][b][1], d.alpha * acc[a][b][2], d.alpha * acc[a][b][3]);
+            } else {
 #pragma unroll
-            for (int r4 = 0; r4 < 4; ++r4)
-                if (gj + r4 < d.N) atomicAdd(C + (int64_t)gi * d.rsC + (gj + r4), d.alpha * acc[a][b][r4]);
+                for (int r4 = 0; r4 < 4; ++r4)
+                    if (gj + r4 < d.N) atomicAdd(C + (int64_t)gi * ldc + (gj + r4), d.alpha * acc[a][b][r4]);
+            }
         }
     }
 }
 
+__global__ void tn_reduce_kernel(const float* __restrict__ parts, float* __restrict__ out, int64_t n4, int splits,
+                                 int N, int64_t rsC) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // one float4 per thread
+    if (i >= n4) return;
+    float4 s = reinterpret_cast<const float4*>(parts)[i];
+    for (int k = 1; k < splits; ++k) {
+        const float4 v = reinterpret_cast<const float4*>(parts)[(int64_t)k * n4 + i];
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    const int64_t e = i * 4, row = e / N, col = e % N;
+    *reinterpret_cast<float4*>(out + row * rsC + col) = s;
+}
+
+struct TnPlan { int tiles_i, tiles_j, splits, m_per_split; };
+TnPlan tn_plan(int M, int N, int K) {
+    TnPlan p;
+    p.tiles_i = (M + BI - 1) / BI;
+    p.tiles_j = (N + BJ - 1) / BJ;
+    const int tiles = p.tiles_i * p.tiles_j;
+    p.splits = std::max(1, std::min((2 * 256 + tiles - 1) / tiles, (K + 4 * BKM - 1) / (4 * BKM)));
+    p.m_per_split = ((K + p.splits - 1) / p.splits + BKM - 1) / BKM * BKM;
+    p.splits = (K + p.m_per_split - 1) / p.m_per_split;
+    return p;
+}
+
 }  // namespace
+
+extern "C" size_t focus_gemm_tn_workspace_bytes(int M, int N, int K) {
+    if (M <= 0 || N <= 0 || K <= 0) return 0;
+    return (size_t)tn_plan(M, N, K).splits * M * N * sizeof(float);
+}
 
 // A described as [M, K] with rsA == 1 (P[m][i] row-major: csA = ld of P), B as [K, N] with csB == 1 (Q[m][j]).
 bool focus_gemm_mfma_tn_ok(const focus_gemm_desc& d) {
     static const bool enabled = !(getenv("FOCUS_GEMM_TN") && atoi(getenv("FOCUS_GEMM_TN")) == 0);
     if (!enabled || d.dtype_ab != FOCUS_BF16 || d.dtype_c != FOCUS_F32) return false;
     if (d.rsA != 1 || d.csB != 1 || d.csC != 1) return false;
-    if (d.batch0 * d.batch1 != 1 || !d.accumulate || d.bias || d.residual || d.epilogue != FOCUS_EPI_NONE) return false;
+    if (d.batch0 * d.batch1 != 1 || d.bias || d.residual || d.epilogue != FOCUS_EPI_NONE) return false;
+    if (!d.aux && !d.accumulate) return false;          // atomic mode needs a zero-initialised accumulate target
+    if (d.aux && (d.accumulate || (d.rsC & 3) || !focus_aligned(d.aux, 16) || !focus_aligned(d.C, 16))) return false;
     if ((d.csA & 7) || (d.rsB & 7) || (d.M & 7) || (d.N & 7) || d.M < 8 || d.N < 8 || d.K < 1) return false;
     if (!focus_aligned(d.A, 16) || !focus_aligned(d.B, 16)) return false;
     return true;
@@ -176,15 +216,19 @@ bool focus_gemm_mfma_tn_ok(const focus_gemm_desc& d) {
 
 int focus_gemm_mfma_tn(const focus_gemm_desc& d, hipStream_t s) {
     if (!focus_gemm_mfma_tn_ok(d)) return FOCUS_ERR_ALIGN;
-    const int tiles_i = (d.M + BI - 1) / BI, tiles_j = (d.N + BJ - 1) / BJ;
-    const int tiles = tiles_i * tiles_j;
-    int splits = std::max(1, std::min((2 * 256 + tiles - 1) / tiles, (d.K + 4 * BKM - 1) / (4 * BKM)));
-    int m_per_split = ((d.K + splits - 1) / splits + BKM - 1) / BKM * BKM;
-    splits = (d.K + m_per_split - 1) / m_per_split;
+    const TnPlan pl = tn_plan(d.M, d.N, d.K);
+    const int tiles_i = pl.tiles_i, tiles_j = pl.tiles_j, tiles = tiles_i * tiles_j, splits = pl.splits;
+    const int m_per_split = pl.m_per_split;
     const size_t lds = 4 * TILE;
     static bool once = (hipFuncSetAttribute((const void*)gemm_tn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds) == hipSuccess);
     (void)once;
     hipLaunchKernelGGL(gemm_tn_kernel, dim3(tiles * splits), dim3(256), lds, s, d, tiles_i, tiles_j, splits, m_per_split);
     FOCUS_CHECK_LAUNCH();
+    if (d.aux) {
+        const int64_t n4 = (int64_t)d.M * d.N / 4;
+        hipLaunchKernelGGL(tn_reduce_kernel, dim3((unsigned)cdiv64(n4, 256)), dim3(256), 0, s, (const float*)d.aux,
+                           (float*)d.C, n4, splits, d.N, d.rsC);
+        FOCUS_CHECK_LAUNCH();
+    }
     return FOCUS_OK;
 }

@@ -131,9 +131,12 @@ def mm_tn(a, b):
     if a.dtype == torch.bfloat16 and USE_TN_GEMM and N % 8 == 0 and K % 8 == 0 and N >= 8 and K >= 8:
         # both operands stay row-major: the TN MFMA kernel gathers its fragments with transposed LDS reads.
         # zero-initialised + accumulate: the long reduction is split over workgroups (fp32 atomics)
-        c = torch.zeros(N, K, device=a.device, dtype=torch.float32)
+        # the long reduction is split over workgroups; partial tiles go to slabs and are summed by a second kernel
+        c = torch.empty(N, K, device=a.device, dtype=torch.float32)
+        nb = _lib.lib().focus_gemm_tn_workspace_bytes(N, K, M)
+        ws = torch.empty(nb // 4, device=a.device, dtype=torch.float32)
         gemm(N, K, M, (a, 0), (1, a.stride(0), 0, 0), (b, 0), (b.stride(0), 1, 0, 0), (c, 0), (K, 1, 0, 0),
-             accumulate=True)
+             aux=(ws, 0))
     elif a.dtype == torch.bfloat16:
         at, bt = transpose_pad(a), transpose_pad(b)
         Mp = at.shape[1]

@@ -78,6 +78,13 @@ typedef struct focus_gemm_desc {
 
 int focus_gemm(const focus_gemm_desc* desc, void* stream);
 
+/* Weight-gradient form (A strided along the reduction: rsA == 1, csB == 1, bf16 in, fp32 out): the long reduction is
+ * split over workgroups.  With desc->aux == NULL the partial sums are added to a zero-initialised C with fp32
+ * atomics (desc->accumulate must be 1); with desc->aux pointing to focus_gemm_tn_workspace_bytes(M, N, K) bytes the
+ * partials are stored to per-split slabs and summed by a second kernel (no atomics, bitwise reproducible, C is
+ * overwritten). */
+size_t focus_gemm_tn_workspace_bytes(int M, int N, int K);
+
 /* y[M,N] = act(x[M,K] . w[N,K]^T + bias) + residual -- nn.Linear forward (thin wrapper over focus_gemm). */
 int focus_linear_fwd(const void* x, const void* w, const float* bias, const void* residual, void* y,
                      void* aux, int M, int N, int K, int epilogue, int dtype, void* stream);
