@@ -89,6 +89,9 @@ def main():
     ap.add_argument("--fp32", action="store_true", help="TRAIN.MIXED_PRECISION False (precision path)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="process-group backend (nccl = RCCL; gloo for a rehearsal)")
+    ap.add_argument("--same-device", action="store_true",
+                    help="rehearsal only: every rank uses cuda:0 (needs --backend gloo; RCCL wants one GPU per rank)")
     args = ap.parse_args()
 
     import torch.distributed as dist
@@ -98,11 +101,13 @@ def main():
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit("--gpus %d needs `python -m torch.distributed.run --nproc-per-node %d bench.py ...`"
                          % (args.gpus, args.gpus))
+    if args.same_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world)   # "nccl" == RCCL on ROCm
+        dist.init_process_group(backend=args.backend, rank=rank, world_size=world)   # "nccl" == RCCL on ROCm
 
     from focus_amd import ops
     from focus_amd.slowfast.models import build_model
@@ -111,6 +116,7 @@ def main():
     from focus_amd.train import synthetic_batch, train_step
 
     cfg = make_cfg(world if world > 1 else 1, args.batch, mixed=not args.fp32)
+    cfg.DIST_BACKEND = args.backend
     torch.manual_seed(cfg.RNG_SEED)
     model = build_model(cfg, gpu_id=local_rank)
     model.train()

@@ -15,7 +15,8 @@ def wrap_ddp(model, device, cfg=None, bucket_cap_mb=64, compress=True):
         ddp = torch.nn.parallel.DistributedDataParallel(model, device_ids=[device], output_device=device, **kwargs)
     else:
         ddp = torch.nn.parallel.DistributedDataParallel(model, **kwargs)
-    if compress and on_gpu:
+    backend = getattr(cfg, "DIST_BACKEND", "nccl") if cfg is not None else "nccl"
+    if compress and on_gpu and backend == "nccl":      # gloo has no bf16 reductions
         from torch.distributed.algorithms.ddp_comm_hooks import default_hooks
         ddp.register_comm_hook(dist.group.WORLD, default_hooks.bf16_compress_hook)
     return ddp

@@ -31,8 +31,11 @@ MODEL_REGISTRY = Registry("MODEL")
 def build_model(cfg, gpu_id=None):
     """build.py:18-87: look the model up by cfg.MODEL.MODEL_NAME, move it to the current GPU and wrap it in
     DistributedDataParallel when cfg.NUM_GPUS > 1 (one process per GPU; backend "nccl" is RCCL on ROCm)."""
+    launched = torch.distributed.is_available() and torch.distributed.is_initialized()
     if torch.cuda.is_available():
-        assert cfg.NUM_GPUS <= torch.cuda.device_count(), "Cannot use more GPU devices than available"
+        # build.py:26-29.  Under an external one-process-per-GPU launcher (torch.distributed.run) a rank may see
+        # only its own device, so the check applies to the reference's own spawn model only.
+        assert launched or cfg.NUM_GPUS <= torch.cuda.device_count(), "Cannot use more GPU devices than available"
     else:
         assert cfg.NUM_GPUS == 0, "Cuda is not available. Please set `NUM_GPUS: 0 for running on CPUs."
     model = MODEL_REGISTRY.get(cfg.MODEL.MODEL_NAME)(cfg)

@@ -16,7 +16,7 @@ def train_step(model, optimizer, loss_fun, inputs, labels, meta, cfg, check_nan=
     preds = model(inputs, meta)                                   # train_net.py:86
     loss = loss_fun(preds, labels)                                # :91-99
     if check_nan:
-        misc.check_nan_losses(float(loss))                        # :102 (host sync, as in the reference)
+        misc.check_nan_losses(float(loss.detach()))                        # :102 (host sync, as in the reference)
     optimizer.zero_grad(set_to_none=True)                         # :105
     loss.backward()                                               # :106
     if cfg.SOLVER.CLIP_GRAD_VAL:

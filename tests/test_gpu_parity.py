@@ -334,6 +334,33 @@ def test_training_steps_keep_bf16_shadows_fresh(oracle):
     close(got, ref, 5e-2, "logits after 2 optimizer steps")
 
 
+def test_trajectory_attention_beyond_fused_limits(oracle):
+    """Frames longer than the fused kernels' 224-key register tile (the HR 16x336 config has P=441) take the unfused
+    path in bf16 as well; head dim 64 so everything else still runs the MFMA kernels."""
+    from focus_amd.slowfast.models.attention import TrajectoryAttention
+    g = torch.Generator().manual_seed(31)
+    C, heads, F_, P = 128, 2, 2, 230
+    m = TrajectoryAttention(C, num_heads=heads, qkv_bias=True)
+    with torch.no_grad():
+        for prm in m.parameters():
+            prm.copy_(0.05 * torch.randn(prm.shape, generator=g))
+    x = torch.randn(1, 1 + F_ * P, C, generator=g)
+    ct = torch.randn(1, 1 + F_ * P, C, generator=g)
+    p = {("." + k): v.detach().clone().requires_grad_() for k, v in m.state_dict().items()}
+    xr = x.clone().requires_grad_()
+    ref = oracle.trajectory_attention(p, "", xr, [F_, P, 1], heads)
+    (ref * ct).sum().backward()
+    m = m.to(dev())
+    for dtype in DTYPES:
+        m.zero_grad()
+        xg = x.to(dev(), dtype).requires_grad_()
+        y, _ = m(xg, [F_, P, 1])
+        (y.float() * ct.to(dev())).sum().backward()
+        close(y, ref, TOL[dtype], "y P=230")
+        close(xg.grad, xr.grad, TOL[dtype] * 2, "dx P=230")
+        close(m.qkv.weight.grad, p[".qkv.weight"].grad, TOL[dtype] * 3, "dqkv.weight P=230")
+
+
 def test_state_dict_abi_224():
     """Checkpoint ABI: parameter names/shapes of the full-size model equal the reference's (fixture)."""
     from focus_amd.slowfast.config.defaults import get_cfg
