@@ -173,7 +173,7 @@ def main():
         tn_tf = sum(r[0] for r in tn) / (tn_ms * 1e-3) / 1e12 if tn_ms > 0 else 0.0
         out["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                            "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None,
-                           "kernel": "gemm_nt_kernel<bf16> (focus_amd/csrc/gemm_mfma.hip)",
+                           "kernel": "gemm_nt_ws_kernel / gemm_nt_kernel, bf16 NT GEMM (focus_amd/csrc/gemm_mfma_ws.hip, gemm_mfma.hip)",
                            "launches_per_step": len(recs) // max(args.steps, 1),
                            "avg_launch_us": round(1e3 * ms / max(len(recs), 1), 2),
                            "kernel_ms_per_step": round(ms / max(args.steps, 1), 3),

@@ -415,7 +415,10 @@ int focus_gemm_mfma_nt(const focus_gemm_desc& d, hipStream_t s) {
         return launch_nt<128, 128, 2, 2>(d, splits, s);
     }
     (void)t256;
-    if (focus_gemm_mfma_ws_ok(d)) return focus_gemm_mfma_ws(d, s);
+    if (focus_gemm_mfma_ws_ok(d)) {
+        const int rc = focus_gemm_mfma_ws(d, s);
+        if (rc != FOCUS_ERR_SHAPE) return rc;
+    }
     static const int variant = getenv("FOCUS_GEMM_VARIANT") ? atoi(getenv("FOCUS_GEMM_VARIANT")) : 0;
     switch (variant) {   // tuning hook (tools/gemm_sweep.py); 0 is the shipped configuration
         case 4: return launch_nt<256, 128, 4, 2>(d, 1, s);

@@ -24,15 +24,22 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((address_space(1))) const void gvoid_t;
 typedef __attribute__((address_space(3))) void lvoid_t;
 
-constexpr int BM = 128, BN = 128, BK = 64, NSTAGE = 3;
-constexpr int A_BYTES = BM * 128, STAGE = (BM + BN) * 128;   // 32 KiB per stage
-constexpr int PIECES = 8;                                    // DMA pieces per loader wave per K-step (4 A + 4 B)
+constexpr int BK = 64, NSTAGE = 3;
 
 __device__ __forceinline__ int swz(int row, int chunk) { return row * 128 + ((chunk ^ (row & 7)) << 4); }
 
 struct Unit { int m0, n0, nk; };
 
-__global__ __launch_bounds__(512, 2) void gemm_nt_ws_kernel(const focus_gemm_desc d, int tiles_m, int tiles_n) {
+// BM = 128: 4 consumer waves (2x2 of 64x64) + 4 loaders, 96 KiB ring.
+// BM = 256: 8 consumer waves (4x2 of 64x64) + 4 loaders, 144 KiB ring (85 flop per LDS-filled byte instead of 64;
+//           two consumer waves per SIMD overlap each other's ds_read latency).
+template <int BM, int BN, bool kNtStore>
+__global__ __launch_bounds__(64 * (BM * BN / 4096 + 4)) void gemm_nt_ws_kernel(const focus_gemm_desc d, int tiles_m, int tiles_n) {
+    constexpr int NCONS = BM * BN / 4096;                        // consumer waves (64x64 each)
+    constexpr int WN = BN / 64;                                  // consumer grid is (BM/64) x WN
+    constexpr int A_BYTES = BM * 128, STAGE = (BM + BN) * 128;   // bytes per ring stage
+    constexpr int GA = BM / 8 / 4, GB = BN / 8 / 4;              // DMA pieces per loader wave per K-step
+    constexpr int PIECES = GA + GB;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int z = blockIdx.y;
     const int b0 = z / d.batch1, b1 = z % d.batch1;
@@ -69,37 +76,38 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_ws_kernel(const focus_gemm_des
     };
     const int total = my_units * nk;      // K-steps in this workgroup's stream
 
-    if (w >= 4) {
+    if (w >= NCONS) {
         // =============================== loader waves ===============================
-        const int L = w - 4;
+        const int L = w - NCONS;
         const int lrow = lane >> 3, cpos = lane & 7, csrc = (cpos ^ lrow) * 8;
-        const bf16_t* a_src[4];
-        const bf16_t* b_src[4];
+        const bf16_t* a_src[GA];
+        const bf16_t* b_src[GB];
         int iu = 0, ikt = 0;
         auto setup = [&](int i) __attribute__((always_inline)) {
             const Unit t = unit_of(i);
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                a_src[g] = A + (int64_t)min(t.m0 + (L * 4 + g) * 8 + lrow, d.M - 1) * lda + csrc;
-                b_src[g] = B + (int64_t)min(t.n0 + (L * 4 + g) * 8 + lrow, d.N - 1) * ldb + csrc;
-            }
+            for (int g = 0; g < GA; ++g)
+                a_src[g] = A + (int64_t)min(t.m0 + (L * GA + g) * 8 + lrow, d.M - 1) * lda + csrc;
+#pragma unroll
+            for (int g = 0; g < GB; ++g)
+                b_src[g] = B + (int64_t)min(t.n0 + (L * GB + g) * 8 + lrow, d.N - 1) * ldb + csrc;
         };
         auto issue = [&](int st) __attribute__((always_inline)) {
             char* sa = smem + st * STAGE;
             char* sb = sa + A_BYTES;
 #pragma unroll
-            for (int g = 0; g < 4; ++g)
-                __builtin_amdgcn_global_load_lds((gvoid_t*)(a_src[g] + ikt * BK), (lvoid_t*)(sa + (L * 4 + g) * 1024), 16, 0, 0);
+            for (int g = 0; g < GA; ++g)
+                __builtin_amdgcn_global_load_lds((gvoid_t*)(a_src[g] + ikt * BK), (lvoid_t*)(sa + (L * GA + g) * 1024), 16, 0, 0);
 #pragma unroll
-            for (int g = 0; g < 4; ++g)
-                __builtin_amdgcn_global_load_lds((gvoid_t*)(b_src[g] + ikt * BK), (lvoid_t*)(sb + (L * 4 + g) * 1024), 16, 0, 0);
+            for (int g = 0; g < GB; ++g)
+                __builtin_amdgcn_global_load_lds((gvoid_t*)(b_src[g] + ikt * BK), (lvoid_t*)(sb + (L * GB + g) * 1024), 16, 0, 0);
             if (++ikt == nk) { ikt = 0; if (++iu < my_units) setup(iu); }
         };
         setup(0);
         issue(0);
         if (total > 1) {
             issue(1);
-            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES) : "memory");
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
@@ -109,7 +117,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_ws_kernel(const focus_gemm_des
             if (t + 2 < total) {
                 issue(st2);
                 st2 = st2 == 2 ? 0 : st2 + 1;
-                asm volatile("s_waitcnt vmcnt(8)" ::: "memory");     // step t+1 landed, step t+2 in flight
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES) : "memory");     // step t+1 landed, step t+2 in flight
             } else {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
@@ -123,7 +131,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_ws_kernel(const focus_gemm_des
     }
 
     // =============================== consumer waves ===============================
-    const int wm = w >> 1, wn = w & 1;
+    const int wm = w / WN, wn = w % WN;
     const int frow = lane & 15, fq = lane >> 4;
     f32x4 acc[4][4];
     auto compute = [&](const char* sa) __attribute__((always_inline)) {
@@ -145,73 +153,81 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_ws_kernel(const focus_gemm_des
         }
     };
     auto epilogue = [&](char* stage, int m0, int n0) __attribute__((always_inline)) {
-        char* slab = stage + w * 8192;           // [64 rows][16 chunks of 8 B], chunk ^= row & 15
+        // the wave's 64x64 tile leaves in two 32-row halves through a private 4 KiB slab
+        // ([32 rows][16 chunks of 8 B], chunk ^= row & 15) inside the just-consumed stage
+        char* slab = stage + w * 4096;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int row = i * 16 + frow;
+        for (int half = 0; half < 2; ++half) {
 #pragma unroll
-            for (int jj = 0; jj < 4; ++jj) {
-                const int gn = n0 + wn * 64 + jj * 16 + fq * 4;
-                float t[4];
+            for (int i2 = 0; i2 < 2; ++i2) {
+                const int i = half * 2 + i2, row = i2 * 16 + frow;
 #pragma unroll
-                for (int r4 = 0; r4 < 4; ++r4) {
-                    t[r4] = d.alpha * acc[i][jj][r4];
-                    if (d.bias && gn + r4 < d.N) t[r4] += d.bias[gn + r4];
-                }
-                uint2 pk;
-                pk.x = (uint32_t)f32_to_bf16(t[0]) | ((uint32_t)f32_to_bf16(t[1]) << 16);
-                pk.y = (uint32_t)f32_to_bf16(t[2]) | ((uint32_t)f32_to_bf16(t[3]) << 16);
-                *reinterpret_cast<uint2*>(slab + row * 128 + (((jj * 4 + fq) ^ (row & 15)) << 3)) = pk;
-            }
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        const int q8 = lane & 7;
+                for (int jj = 0; jj < 4; ++jj) {
+                    const int gn = n0 + wn * 64 + jj * 16 + fq * 4;
+                    float t[4];
 #pragma unroll
-        for (int p8 = 0; p8 < 8; ++p8) {
-            const int row = p8 * 8 + (lane >> 3);
-            const int gm = m0 + wm * 64 + row, gn = n0 + wn * 64 + q8 * 8;
-            uint4 raw = *reinterpret_cast<const uint4*>(slab + row * 128 + ((q8 ^ ((row & 15) >> 1)) << 4));
-            if (row & 1) { const uint32_t a0 = raw.x, a1 = raw.y; raw.x = raw.z; raw.y = raw.w; raw.z = a0; raw.w = a1; }
-            if (gm >= d.M || gn >= d.N) continue;
-            const int64_t off = gm * d.rsC + gn;
-            float v[8] = {__uint_as_float(raw.x << 16), __uint_as_float(raw.x & 0xffff0000u),
-                          __uint_as_float(raw.y << 16), __uint_as_float(raw.y & 0xffff0000u),
-                          __uint_as_float(raw.z << 16), __uint_as_float(raw.z & 0xffff0000u),
-                          __uint_as_float(raw.w << 16), __uint_as_float(raw.w & 0xffff0000u)};
-            float xs[8];
-            if (d.epilogue >= FOCUS_EPI_DGELU) {
-                const uint4 xr = *reinterpret_cast<const uint4*>(X + off);
-                xs[0] = __uint_as_float(xr.x << 16); xs[1] = __uint_as_float(xr.x & 0xffff0000u);
-                xs[2] = __uint_as_float(xr.y << 16); xs[3] = __uint_as_float(xr.y & 0xffff0000u);
-                xs[4] = __uint_as_float(xr.z << 16); xs[5] = __uint_as_float(xr.z & 0xffff0000u);
-                xs[6] = __uint_as_float(xr.w << 16); xs[7] = __uint_as_float(xr.w & 0xffff0000u);
-            }
-            if (d.epilogue == FOCUS_EPI_GELU && X) *reinterpret_cast<uint4*>(X + off) = raw;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                switch (d.epilogue) {
-                    case FOCUS_EPI_GELU: v[e] = gelu_erf(v[e]); break;
-                    case FOCUS_EPI_RELU: v[e] = fmaxf(v[e], 0.f); break;
-                    case FOCUS_EPI_TANH: v[e] = tanhf(v[e]); break;
-                    case FOCUS_EPI_DGELU: v[e] *= dgelu_erf(xs[e]); break;
-                    case FOCUS_EPI_DRELU: v[e] = xs[e] > 0.f ? v[e] : 0.f; break;
-                    case FOCUS_EPI_DTANH: v[e] *= (1.f - xs[e] * xs[e]); break;
-                    default: break;
+                    for (int r4 = 0; r4 < 4; ++r4) {
+                        t[r4] = d.alpha * acc[i][jj][r4];
+                        if (d.bias && gn + r4 < d.N) t[r4] += d.bias[gn + r4];
+                    }
+                    uint2 pk;
+                    pk.x = (uint32_t)f32_to_bf16(t[0]) | ((uint32_t)f32_to_bf16(t[1]) << 16);
+                    pk.y = (uint32_t)f32_to_bf16(t[2]) | ((uint32_t)f32_to_bf16(t[3]) << 16);
+                    *reinterpret_cast<uint2*>(slab + row * 128 + (((jj * 4 + fq) ^ (row & 15)) << 3)) = pk;
                 }
             }
-            if (R) {
-                const uint4 rr = *reinterpret_cast<const uint4*>(R + off);
-                v[0] += __uint_as_float(rr.x << 16); v[1] += __uint_as_float(rr.x & 0xffff0000u);
-                v[2] += __uint_as_float(rr.y << 16); v[3] += __uint_as_float(rr.y & 0xffff0000u);
-                v[4] += __uint_as_float(rr.z << 16); v[5] += __uint_as_float(rr.z & 0xffff0000u);
-                v[6] += __uint_as_float(rr.w << 16); v[7] += __uint_as_float(rr.w & 0xffff0000u);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            const int q8 = lane & 7;
+#pragma unroll
+            for (int p8 = 0; p8 < 4; ++p8) {
+                const int row = p8 * 8 + (lane >> 3);
+                const int gm = m0 + wm * 64 + half * 32 + row, gn = n0 + wn * 64 + q8 * 8;
+                uint4 raw = *reinterpret_cast<const uint4*>(slab + row * 128 + ((q8 ^ ((row & 15) >> 1)) << 4));
+                if (row & 1) { const uint32_t a0 = raw.x, a1 = raw.y; raw.x = raw.z; raw.y = raw.w; raw.z = a0; raw.w = a1; }
+                if (gm >= d.M || gn >= d.N) continue;
+                const int64_t off = gm * d.rsC + gn;
+                float v[8] = {__uint_as_float(raw.x << 16), __uint_as_float(raw.x & 0xffff0000u),
+                              __uint_as_float(raw.y << 16), __uint_as_float(raw.y & 0xffff0000u),
+                              __uint_as_float(raw.z << 16), __uint_as_float(raw.z & 0xffff0000u),
+                              __uint_as_float(raw.w << 16), __uint_as_float(raw.w & 0xffff0000u)};
+                float xs[8];
+                if (d.epilogue >= FOCUS_EPI_DGELU) {
+                    const uint4 xr = *reinterpret_cast<const uint4*>(X + off);
+                    xs[0] = __uint_as_float(xr.x << 16); xs[1] = __uint_as_float(xr.x & 0xffff0000u);
+                    xs[2] = __uint_as_float(xr.y << 16); xs[3] = __uint_as_float(xr.y & 0xffff0000u);
+                    xs[4] = __uint_as_float(xr.z << 16); xs[5] = __uint_as_float(xr.z & 0xffff0000u);
+                    xs[6] = __uint_as_float(xr.w << 16); xs[7] = __uint_as_float(xr.w & 0xffff0000u);
+                }
+                if (d.epilogue == FOCUS_EPI_GELU && X) *reinterpret_cast<uint4*>(X + off) = raw;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    switch (d.epilogue) {
+                        case FOCUS_EPI_GELU: v[e] = gelu_erf(v[e]); break;
+                        case FOCUS_EPI_RELU: v[e] = fmaxf(v[e], 0.f); break;
+                        case FOCUS_EPI_TANH: v[e] = tanhf(v[e]); break;
+                        case FOCUS_EPI_DGELU: v[e] *= dgelu_erf(xs[e]); break;
+                        case FOCUS_EPI_DRELU: v[e] = xs[e] > 0.f ? v[e] : 0.f; break;
+                        case FOCUS_EPI_DTANH: v[e] *= (1.f - xs[e] * xs[e]); break;
+                        default: break;
+                    }
+                }
+                if (R) {
+                    const uint4 rr = *reinterpret_cast<const uint4*>(R + off);
+                    v[0] += __uint_as_float(rr.x << 16); v[1] += __uint_as_float(rr.x & 0xffff0000u);
+                    v[2] += __uint_as_float(rr.y << 16); v[3] += __uint_as_float(rr.y & 0xffff0000u);
+                    v[4] += __uint_as_float(rr.z << 16); v[5] += __uint_as_float(rr.z & 0xffff0000u);
+                    v[6] += __uint_as_float(rr.w << 16); v[7] += __uint_as_float(rr.w & 0xffff0000u);
+                }
+                uint4 o;
+                o.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
+                o.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
+                o.z = (uint32_t)f32_to_bf16(v[4]) | ((uint32_t)f32_to_bf16(v[5]) << 16);
+                o.w = (uint32_t)f32_to_bf16(v[6]) | ((uint32_t)f32_to_bf16(v[7]) << 16);
+                typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+                if (kNtStore) __builtin_nontemporal_store((u32x4){o.x, o.y, o.z, o.w}, reinterpret_cast<u32x4*>(C + off));
+                else *reinterpret_cast<uint4*>(C + off) = o;
             }
-            uint4 o;
-            o.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
-            o.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
-            o.z = (uint32_t)f32_to_bf16(v[4]) | ((uint32_t)f32_to_bf16(v[5]) << 16);
-            o.w = (uint32_t)f32_to_bf16(v[6]) | ((uint32_t)f32_to_bf16(v[7]) << 16);
-            *reinterpret_cast<uint4*>(C + off) = o;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // slab re-read before the second half overwrites it
         }
     };
 
@@ -240,8 +256,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_ws_kernel(const focus_gemm_des
 }  // namespace
 
 bool focus_gemm_mfma_ws_ok(const focus_gemm_desc& d) {
-    // opt-in (FOCUS_GEMM_WS=1): measured slower than the uniform kernel at one consumer wave per SIMD
-    static const bool enabled = getenv("FOCUS_GEMM_WS") && atoi(getenv("FOCUS_GEMM_WS")) == 1;
+    static const bool enabled = !(getenv("FOCUS_GEMM_WS") && atoi(getenv("FOCUS_GEMM_WS")) == 0);
     if (!enabled || !focus_gemm_mfma_nt_ok(d)) return false;
     if (d.dtype_c != FOCUS_BF16 || d.accumulate || d.csC != 1 || (d.rsC & 7) || (d.N & 7)) return false;
     if ((d.bsC0 & 7) || (d.bsC1 & 7)) return false;
@@ -250,17 +265,33 @@ bool focus_gemm_mfma_ws_ok(const focus_gemm_desc& d) {
     return true;
 }
 
-int focus_gemm_mfma_ws(const focus_gemm_desc& d, hipStream_t s) {
+template <int BM, int BN, bool NT>
+static int launch_ws(const focus_gemm_desc& d, hipStream_t s) {
     const int tiles_m = (d.M + BM - 1) / BM, tiles_n = (d.N + BN - 1) / BN;
     const int nbatch = d.batch0 * d.batch1;
-    if (nbatch > 65535) return FOCUS_ERR_SHAPE;
-    const size_t lds = NSTAGE * STAGE;
-    static bool once = (hipFuncSetAttribute((const void*)gemm_nt_ws_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds) == hipSuccess);
+    const size_t lds = (size_t)NSTAGE * (BM + BN) * 128;
+    auto k = gemm_nt_ws_kernel<BM, BN, NT>;
+    static bool once = (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds) == hipSuccess);
     (void)once;
     const int nunits = tiles_m * tiles_n;
     const int resident = std::max(8, 256 / std::max(1, std::min(nbatch, 32)));
     dim3 grid(std::min(nunits, resident), nbatch);
-    hipLaunchKernelGGL(gemm_nt_ws_kernel, grid, dim3(512), lds, s, d, tiles_m, tiles_n);
+    hipLaunchKernelGGL(k, grid, dim3(64 * (BM * BN / 4096 + 4)), lds, s, d, tiles_m, tiles_n);
     FOCUS_CHECK_LAUNCH();
     return FOCUS_OK;
+}
+
+int focus_gemm_mfma_ws(const focus_gemm_desc& d, hipStream_t s) {
+    if (d.batch0 * d.batch1 > 65535) return FOCUS_ERR_SHAPE;
+    static const int bm = getenv("FOCUS_GEMM_WS_BM") ? atoi(getenv("FOCUS_GEMM_WS_BM")) : 256;
+    // 256-row tiles need enough of them to occupy the chip (one workgroup per CU)
+    static const bool nt = !(getenv("FOCUS_GEMM_WS_NT") && atoi(getenv("FOCUS_GEMM_WS_NT")) == 0);
+    static const bool wide = !(getenv("FOCUS_GEMM_WS_WIDE") && atoi(getenv("FOCUS_GEMM_WS_WIDE")) == 0);
+    const int64_t t256 = (int64_t)((d.M + 255) / 256) * ((d.N + 127) / 128);
+    const int64_t tw = (int64_t)((d.M + 127) / 128) * ((d.N + 255) / 256);
+    if (wide && bm == 256 && d.N >= 256 && tw >= 192)       // 128 rows x 256 columns: 512-byte row segments of C
+        return nt ? launch_ws<128, 256, true>(d, s) : launch_ws<128, 256, false>(d, s);
+    if (bm == 256 && d.M >= 256 && t256 >= 192)
+        return nt ? launch_ws<256, 128, true>(d, s) : launch_ws<256, 128, false>(d, s);
+    return FOCUS_ERR_SHAPE;   // too few tiles for one 8-consumer workgroup per CU: the caller uses the uniform kernel
 }
