@@ -155,6 +155,7 @@ extern "C" size_t focus_traj_space_workspace_bytes(int B, int F, int P, int head
         bytes += (size_t)B * heads * N * es + 4096;          // d(cls row) + alignment padding of the carve-up
         if (fused) {
             bytes += (size_t)B * heads * S * F * sizeof(float) + 256;   // delta
+            bytes += (size_t)2 * B * heads * N * sizeof(float) + 256;   // cls prob / dlog scratch
         } else {
             bytes += (size_t)B * heads * S * S * es;         // d(prob) / d(logits)
             bytes += (size_t)B * S * F * C * es;             // dxt + diagonal term
@@ -247,7 +248,10 @@ extern "C" int focus_traj_space_bwd(const void* qkv, const void* xt, const void*
 
     // ---- cls row: row 0 of every part is written plainly; rows 1.. of the k and v parts are written (unfused: the
     // patch step accumulates on top) or accumulated onto the fused kernels' output ----
-    if (fused && focus_traj_cls_ok(D.N, d)) return focus_traj_cls_bwd(qkv, cls_lse, dcls, dqkv, B, D.N, heads, dtype, s);
+    if (fused && focus_traj_cls_ok(D.N, d)) {
+        float* scratch = reinterpret_cast<float*>(L) + (((int64_t)B * heads * D.S * F + 63) & ~(int64_t)63);
+        return focus_traj_cls_bwd(qkv, cls_lse, dcls, dqkv, scratch, B, D.N, heads, dtype, s);
+    }
     {
         focus_gemm_desc g = base_desc(dtype);   // recompute cls logits, then probabilities from lse
         g.M = 1; g.N = D.N; g.K = d; g.batch0 = B; g.batch1 = heads;

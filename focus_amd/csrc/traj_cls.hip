@@ -56,12 +56,13 @@ __global__ __launch_bounds__(1024) void cls_fwd_kernel(const T* __restrict__ qkv
     }
 }
 
-// Adds the cls-row contributions onto dqkv: rows 1.. of the k and v parts are read-modify-written (the patch
-// kernels wrote them first); row 0 of the q, k and v parts is written plainly.
+// Backward, phase A (one workgroup per (b,h)): recompute the probabilities from the saved lse, form
+// d logits (scale included) and dq0; prob and dlog go to scratch for phase B.
 template <typename T>
-__global__ __launch_bounds__(1024) void cls_bwd_kernel(const T* __restrict__ qkv, const float* __restrict__ cls_lse,
-                                                      const T* __restrict__ dcls, T* __restrict__ dqkv, int N,
-                                                      int heads) {
+__global__ __launch_bounds__(1024) void cls_bwd_a_kernel(const T* __restrict__ qkv, const float* __restrict__ cls_lse,
+                                                         const T* __restrict__ dcls, T* __restrict__ dqkv,
+                                                         float* __restrict__ prob_g, float* __restrict__ dlog_g, int N,
+                                                         int heads) {
     extern __shared__ __attribute__((aligned(16))) float buf[];   // prob[N] | dlog[N]
     float* prob = buf;
     float* dlog = buf + N;
@@ -69,7 +70,6 @@ __global__ __launch_bounds__(1024) void cls_bwd_kernel(const T* __restrict__ qkv
     const int bh = blockIdx.x, b = bh / heads, hh = bh % heads, C = heads * HD;
     const int64_t tok = 3 * (int64_t)C;
     const T* base = qkv + (int64_t)b * N * tok + hh * HD;
-    T* dbase = dqkv + (int64_t)b * N * tok + hh * HD;
     const float scale = rsqrtf((float)HD), lse = cls_lse[bh];
     if (threadIdx.x < HD) {
         sq[threadIdx.x] = ld<T>(base + threadIdx.x) * scale;
@@ -84,32 +84,16 @@ __global__ __launch_bounds__(1024) void cls_bwd_kernel(const T* __restrict__ qkv
         prob[n] = a;
         dlog[n] = da;
         dot += a * da;
-        // dV[n,:] (+)= a * dcls
-        T* dv = dbase + (int64_t)n * tok + 2 * C;
-#pragma unroll
-        for (int c = 0; c < HD; c += 4) {
-            f4 o = {a * sd[c], a * sd[c + 1], a * sd[c + 2], a * sd[c + 3]};
-            if (n > 0) { const f4 old = ld4<T>(dv + c); o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w; }
-            st4<T>(dv + c, o);
-        }
     }
     dot = block_sum(dot, red);
     __syncthreads();
     for (int n = threadIdx.x; n < N; n += 1024) {
-        const float dl = scale * prob[n] * (dlog[n] - dot);      // d logit (scale included)
+        const float dl = scale * prob[n] * (dlog[n] - dot);
         dlog[n] = dl;
-        // dK[n,:] (+)= dl * q0   (sq already carries one factor `scale`: divide it back out)
-        T* dk = dbase + (int64_t)n * tok + C;
-        const float f = dl / scale;
-#pragma unroll
-        for (int c = 0; c < HD; c += 4) {
-            f4 o = {f * sq[c], f * sq[c + 1], f * sq[c + 2], f * sq[c + 3]};
-            if (n > 0) { const f4 old = ld4<T>(dk + c); o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w; }
-            st4<T>(dk + c, o);
-        }
+        prob_g[(int64_t)bh * N + n] = prob[n];
+        dlog_g[(int64_t)bh * N + n] = dl;
     }
     __syncthreads();
-    // dq0[:] = sum_n dl[n] * k[n,:]
     const int dch = threadIdx.x & 63, pr = threadIdx.x >> 6;
     float acc = 0.f;
     for (int n = pr; n < N; n += 16) acc += dlog[n] * ld<T>(base + (int64_t)n * tok + C + dch);
@@ -118,7 +102,30 @@ __global__ __launch_bounds__(1024) void cls_bwd_kernel(const T* __restrict__ qkv
     if (threadIdx.x < HD) {
         float t = 0.f;
         for (int y = 0; y < 16; ++y) t += part[y][threadIdx.x];
-        st<T>(dbase + threadIdx.x, t);
+        st<T>(dqkv + (int64_t)b * N * tok + hh * HD + threadIdx.x, t);
+    }
+}
+
+// Phase B (grid: 64-row strips x (b,h)): dK[n,:] (+)= dlog[n] * q0,  dV[n,:] (+)= prob[n] * dcls; token 0 is written
+// plainly, tokens 1.. are read-modify-written (the patch kernels wrote them first).  16-byte accesses.
+template <typename T>
+__global__ __launch_bounds__(256) void cls_bwd_b_kernel(const T* __restrict__ qkv, const T* __restrict__ dcls,
+                                                        const float* __restrict__ prob_g,
+                                                        const float* __restrict__ dlog_g, T* __restrict__ dqkv, int N,
+                                                        int heads) {
+    const int bh = blockIdx.y, b = bh / heads, hh = bh % heads, C = heads * HD;
+    const int64_t tok = 3 * (int64_t)C;
+    for (int it = threadIdx.x; it < 64 * 16 * 2; it += 256) {
+        const int which = it / (64 * 16), rem = it % (64 * 16), n = blockIdx.x * 64 + rem / 16, c = (rem % 16) * 4;
+        if (n >= N) continue;
+        const float w = which == 0 ? dlog_g[(int64_t)bh * N + n] : prob_g[(int64_t)bh * N + n];
+        const T* src = which == 0 ? qkv + (int64_t)b * N * tok + hh * HD + c          // q0 (token 0, q part)
+                                  : dcls + (int64_t)b * C + hh * HD + c;
+        const f4 v = ld4<T>(src);
+        T* dst = dqkv + ((int64_t)b * N + n) * tok + (which == 0 ? C : 2 * C) + hh * HD + c;
+        f4 o = {w * v.x, w * v.y, w * v.z, w * v.w};
+        if (n > 0) { const f4 old = ld4<T>(dst); o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w; }
+        st4<T>(dst, o);
     }
 }
 
@@ -139,15 +146,24 @@ int focus_traj_cls_fwd(const void* qkv, void* cls_out, float* cls_lse, int B, in
     return FOCUS_OK;
 }
 
-int focus_traj_cls_bwd(const void* qkv, const float* cls_lse, const void* dcls, void* dqkv, int B, int N, int heads,
-                       int dtype, hipStream_t s) {
+int focus_traj_cls_bwd(const void* qkv, const float* cls_lse, const void* dcls, void* dqkv, float* scratch, int B,
+                       int N, int heads, int dtype, hipStream_t s) {
+    // scratch: 2 * B * heads * N floats (prob | dlog)
     const size_t lds = (size_t)2 * N * sizeof(float);
-    if (dtype == FOCUS_BF16)
-        hipLaunchKernelGGL((cls_bwd_kernel<bf16_t>), dim3(B * heads), dim3(1024), lds, s, (const bf16_t*)qkv, cls_lse,
-                           (const bf16_t*)dcls, (bf16_t*)dqkv, N, heads);
-    else
-        hipLaunchKernelGGL((cls_bwd_kernel<float>), dim3(B * heads), dim3(1024), lds, s, (const float*)qkv, cls_lse,
-                           (const float*)dcls, (float*)dqkv, N, heads);
+    float* prob_g = scratch;
+    float* dlog_g = scratch + (size_t)B * heads * N;
+    dim3 gb((N + 63) / 64, B * heads);
+    if (dtype == FOCUS_BF16) {
+        hipLaunchKernelGGL((cls_bwd_a_kernel<bf16_t>), dim3(B * heads), dim3(1024), lds, s, (const bf16_t*)qkv, cls_lse,
+                           (const bf16_t*)dcls, (bf16_t*)dqkv, prob_g, dlog_g, N, heads);
+        hipLaunchKernelGGL((cls_bwd_b_kernel<bf16_t>), gb, dim3(256), 0, s, (const bf16_t*)qkv, (const bf16_t*)dcls,
+                           prob_g, dlog_g, (bf16_t*)dqkv, N, heads);
+    } else {
+        hipLaunchKernelGGL((cls_bwd_a_kernel<float>), dim3(B * heads), dim3(1024), lds, s, (const float*)qkv, cls_lse,
+                           (const float*)dcls, (float*)dqkv, prob_g, dlog_g, N, heads);
+        hipLaunchKernelGGL((cls_bwd_b_kernel<float>), gb, dim3(256), 0, s, (const float*)qkv, (const float*)dcls, prob_g,
+                           dlog_g, (float*)dqkv, N, heads);
+    }
     FOCUS_CHECK_LAUNCH();
     return FOCUS_OK;
 }

@@ -17,15 +17,28 @@ namespace {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
 
 constexpr int HD = 64;                 // head dim
-constexpr int VT_STRIDE = 228;         // bf16 elements per V^T row (456 B: conflict-free 8-byte column reads)
 constexpr int QT = 128;                // queries per workgroup (4 waves x 32)
 
 __device__ __forceinline__ int swz(int row, int chunk) { return row * 128 + ((chunk ^ (row & 7)) << 4); }
 
-union Pack8 { bf16x8 v; bf16_t e[8]; uint4 u; };
+union Pack8 { bf16x8 v; bf16_t e[8]; uint4 u; s16x4 t[2]; };
+
+// V^T[d][key] fragment (A operand of  y^T = V^T . P) gathered from the ROW-major V tile with two transposed LDS reads:
+// element j <-> key r0 + 8*(j>>2) + (j&3), d = c0 + (lane & 31); the caller passes r0 = 16*s + 4*(lane>>5) (+ block).
+__device__ __forceinline__ bf16x8 col_frag(const char* tile, int r0, int c0, int lane) {
+    const int i = lane & 15, g = lane >> 4;
+    const int col = c0 + 16 * (g & 1) + 4 * (i & 3);
+    const int row = r0 + (i >> 2);
+    Pack8 p;
+    p.t[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(tile + swz(row, col >> 3) + (col & 4) * 2));
+    p.t[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(tile + swz(row + 8, col >> 3) + (col & 4) * 2));
+    return p.v;
+}
 
 template <int NKB>
 __global__ __launch_bounds__(256, 2) void traj_space_fwd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ xt,
@@ -34,8 +47,8 @@ __global__ __launch_bounds__(256, 2) void traj_space_fwd_kernel(const bf16_t* __
     constexpr int KROWS = NKB * 32;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* sK = smem;                                          // [KROWS][64] bf16, 128-B rows, chunk-swizzled
-    bf16_t* sVt = reinterpret_cast<bf16_t*>(smem + KROWS * 128);   // [64][VT_STRIDE]
-    char* slabs = smem + KROWS * 128 + HD * VT_STRIDE * 2;    // 4 x [32][128 B]
+    char* sV = smem + KROWS * 128;                            // same layout for V (read by columns: col_frag)
+    char* slabs = smem + 2 * KROWS * 128;                     // 4 x [32][128 B]
 
     const int S = F * P, N = S + 1, C = heads * HD;
     const int64_t tok = 3 * (int64_t)C;
@@ -56,19 +69,17 @@ __global__ __launch_bounds__(256, 2) void traj_space_fwd_kernel(const bf16_t* __
     char* slab = slabs + w * 4096;
     for (int f = 0; f < F; ++f) {
         __syncthreads();   // previous frame's tiles are no longer read
-        // ---- stage K_f (row-major, swizzled) and V_f transposed ----
+        // ---- stage K_f and V_f, both row-major with the 16-B chunk swizzle ----
         for (int e = tid; e < KROWS * 8; e += 256) {
             const int p = e >> 3, c = e & 7;
-            uint4 kv = make_uint4(0, 0, 0, 0);
-            Pack8 vv; vv.u = make_uint4(0, 0, 0, 0);
+            uint4 kv = make_uint4(0, 0, 0, 0), vv = kv;
             if (p < P) {
                 const bf16_t* row = base + (int64_t)(1 + f * P + p) * tok + c * 8;
                 kv = *reinterpret_cast<const uint4*>(row + C);
-                vv.u = *reinterpret_cast<const uint4*>(row + 2 * C);
+                vv = *reinterpret_cast<const uint4*>(row + 2 * C);
             }
             *reinterpret_cast<uint4*>(sK + swz(p, c)) = kv;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) sVt[(c * 8 + i) * VT_STRIDE + p] = vv.e[i];
+            *reinterpret_cast<uint4*>(sV + swz(p, c)) = vv;
         }
         __syncthreads();
 
@@ -124,11 +135,8 @@ __global__ __launch_bounds__(256, 2) void traj_space_fwd_kernel(const bf16_t* __
                 const int k0 = kb * 32 + 16 * s2 + 4 * h;
 #pragma unroll
                 for (int dblk = 0; dblk < 2; ++dblk) {
-                    const bf16_t* vrow = sVt + (dblk * 32 + r) * VT_STRIDE + k0;
-                    union { bf16x8 v; uint2 u[2]; } vf;
-                    vf.u[0] = *reinterpret_cast<const uint2*>(vrow);
-                    vf.u[1] = *reinterpret_cast<const uint2*>(vrow + 8);
-                    y[dblk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf.v, pf.v, y[dblk], 0, 0, 0);
+                    const bf16x8 vf = col_frag(sV, k0, dblk * 32, lane);
+                    y[dblk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf.v, y[dblk], 0, 0, 0);
                 }
             }
 
@@ -162,7 +170,7 @@ __global__ __launch_bounds__(256, 2) void traj_space_fwd_kernel(const bf16_t* __
 template <int NKB>
 int launch_fwd(const void* qkv, void* xt, void* xdiag, float* lse, int B, int F, int P, int heads, hipStream_t s) {
     const int S = F * P;
-    const size_t lds = (size_t)NKB * 32 * 128 + HD * VT_STRIDE * 2 + 4 * 4096;
+    const size_t lds = (size_t)2 * NKB * 32 * 128 + 4 * 4096;
     auto k = traj_space_fwd_kernel<NKB>;
     static bool once = (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds) == hipSuccess);
     (void)once;

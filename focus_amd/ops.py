@@ -283,6 +283,40 @@ def mlp(x, w1, b1, w2, b2, residual=None, act=EPI_GELU):
     return _MlpFn.apply(x, w1, b1, w2, b2, residual, act)
 
 
+class _ScaleAddFn(torch.autograd.Function):
+    """out = x + scale[b] * y  (per-sample scale: stochastic depth on a residual branch), one pass each way."""
+
+    @staticmethod
+    def forward(ctx, x, y, scale):
+        _need_gpu(x, y, scale)
+        x, y = x.contiguous(), y.contiguous()
+        B = x.shape[0]
+        per = x.numel() // B
+        out = torch.empty_like(x)
+        _lib.check(_lib.lib().focus_scale_add(_p(x), _p(y), _p(scale), _p(out), B, per, _dt(x), _stream()), "scale_add")
+        ctx.save_for_backward(scale)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (scale,) = ctx.saved_tensors
+        dout = dout.contiguous()
+        B = dout.shape[0]
+        dy = torch.empty_like(dout)
+        _lib.check(_lib.lib().focus_scale_add(None, _p(dout), _p(scale), _p(dy), B, dout.numel() // B, _dt(dout),
+                                              _stream()), "scale_add_bwd")
+        return dout, dy, None
+
+
+def residual_drop_path(x, y, drop_prob, training):
+    """x + drop_path(y) (common.py:46-60): the per-sample keep mask is drawn exactly as the reference draws it."""
+    if drop_prob == 0.0 or not training:
+        return x + y
+    keep = 1.0 - drop_prob
+    mask = (keep + torch.rand(x.shape[0], dtype=torch.float32, device=x.device)).floor_()
+    return _ScaleAddFn.apply(x, y, mask / keep)
+
+
 # --------------------------------------------------------------------------------------------------
 # LayerNorm
 # --------------------------------------------------------------------------------------------------

