@@ -34,7 +34,7 @@ struct Unit { int m0, n0, nk; };
 // BM = 256: 8 consumer waves (4x2 of 64x64) + 4 loaders, 144 KiB ring (85 flop per LDS-filled byte instead of 64;
 //           two consumer waves per SIMD overlap each other's ds_read latency).
 template <int BM, int BN, bool kNtStore>
-__global__ __launch_bounds__(64 * (BM * BN / 4096 + 4)) void gemm_nt_ws_kernel(const focus_gemm_desc d, int tiles_m, int tiles_n) {
+__global__ __launch_bounds__(64 * (BM * BN / 4096 + 4)) void gemm_nt_ws_kernel(const focus_gemm_desc d, int tiles_m, int tiles_n, int GM) {
     constexpr int NCONS = BM * BN / 4096;                        // consumer waves (64x64 each)
     constexpr int WN = BN / 64;                                  // consumer grid is (BM/64) x WN
     constexpr int A_BYTES = BM * 128, STAGE = (BM + BN) * 128;   // bytes per ring stage
@@ -65,7 +65,6 @@ __global__ __launch_bounds__(64 * (BM * BN / 4096 + 4)) void gemm_nt_ws_kernel(c
     if (my_units == 0) return;
     auto unit_of = [&](int i) __attribute__((always_inline)) {
         const int u = band0 + j + i * gx;
-        constexpr int GM = 8;           // grouped (8 row-tiles deep) order: see gemm_mfma.hip
         const int group = u / (GM * tiles_n), first_m = group * GM;
         const int gsz = min(tiles_m - first_m, GM), in_g = u - group * GM * tiles_n;
         Unit t;
@@ -276,7 +275,12 @@ static int launch_ws(const focus_gemm_desc& d, hipStream_t s) {
     const int nunits = tiles_m * tiles_n;
     const int resident = std::max(8, 256 / std::max(1, std::min(nbatch, 32)));
     dim3 grid(std::min(nunits, resident), nbatch);
-    hipLaunchKernelGGL(k, grid, dim3(64 * (BM * BN / 4096 + 4)), lds, s, d, tiles_m, tiles_n);
+    // unit order: narrow outputs (<= 4 column tiles, e.g. N = 768) walk a row of tiles first, so neighbouring
+    // 512-B pieces of the same C rows are written close together in time (measured +14 % on 100352x768x768);
+    // wide outputs use 8-row-tile-deep groups so an XCD's resident tiles share A and B panels in its L2.
+    static const int gm_env = getenv("FOCUS_GEMM_GM") ? std::max(1, atoi(getenv("FOCUS_GEMM_GM"))) : 0;
+    const int gm = gm_env ? gm_env : (tiles_n <= 4 ? 1 : 8);
+    hipLaunchKernelGGL(k, grid, dim3(64 * (BM * BN / 4096 + 4)), lds, s, d, tiles_m, tiles_n, gm);
     FOCUS_CHECK_LAUNCH();
     return FOCUS_OK;
 }

@@ -162,11 +162,13 @@ __global__ __launch_bounds__(256, 2) void traj_dq_kernel(const bf16_t* __restric
                 sa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], sa, 0, 0, 0);
                 dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, df[ks], dp, 0, 0, 0);
             }
+            const bool tail = kb * 32 + 32 > P;          // wave-uniform: only the last key block is padded
+            const float dels = del * scale;
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
-                const int key = kb * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
-                const float pr = key < P ? __builtin_amdgcn_exp2f(sa[i] * c2 - lse2) : 0.f;
-                sa[i] = pr * (dp[i] - del) * scale;      // dL[key][q]
+                float pr = __builtin_amdgcn_exp2f(fmaf(sa[i], c2, -lse2));
+                if (tail && kb * 32 + (i & 3) + 8 * (i >> 2) + 4 * h >= P) pr = 0.f;
+                sa[i] = pr * fmaf(dp[i], scale, -dels);   // dL[key][q] = P * (dP - delta) * scale
             }
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
@@ -302,9 +304,9 @@ __global__ __launch_bounds__(64 * NKB) void traj_dkv_kernel(const bf16_t* __rest
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int i = 4 * g + e;
-                const float pr = key_ok ? __builtin_amdgcn_exp2f(sa[i] * c2 - ls[e]) : 0.f;
+                const float pr = key_ok ? __builtin_amdgcn_exp2f(fmaf(sa[i], c2, -ls[e])) : 0.f;
                 sa[i] = pr;                                   // P[q][key]
-                dp[i] = pr * (dp[i] - de[e]) * scale;         // dL[q][key]
+                dp[i] = pr * fmaf(dp[i], scale, -de[e] * scale);   // dL[q][key]
             }
         }
 #pragma unroll

@@ -95,31 +95,36 @@ __global__ __launch_bounds__(256, 2) void traj_space_fwd_kernel(const bf16_t* __
                 acc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], acc[kb], 0, 0, 0);
             }
         }
-        // ---- per-(query, frame) softmax over the P keys: this lane holds half of its query's keys ----
+        // ---- per-(query, frame) softmax over the P keys: this lane holds half of its query's keys.
+        // VALU-lean form (the kernel is softmax-bound, not MFMA-bound): raw-logit max, one fma + one exp2 per
+        // element, only the tail key block is masked, and the 1/sum normalisation is applied to the 32 outputs
+        // after P.V instead of to the 16*NKB probabilities. ----
         float m = -INFINITY;
 #pragma unroll
-        for (int kb = 0; kb < NKB; ++kb)
+        for (int kb = 0; kb < NKB; ++kb) {
+            if (kb * 32 + 32 > P) {          // wave-uniform: only the last block can hold padded keys
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int key = kb * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
-                const float t = key < P ? acc[kb][i] * c2 : -INFINITY;
-                acc[kb][i] = t;
-                m = fmaxf(m, t);
+                for (int i = 0; i < 16; ++i)
+                    if (kb * 32 + (i & 3) + 8 * (i >> 2) + 4 * h >= P) acc[kb][i] = -INFINITY;
             }
+#pragma unroll
+            for (int i = 0; i < 16; ++i) m = fmaxf(m, acc[kb][i]);
+        }
         m = fmaxf(m, __shfl_xor(m, 32, 64));
+        const float m2 = m * c2;
         float sum = 0.f;
 #pragma unroll
         for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
-                const float pexp = __builtin_amdgcn_exp2f(acc[kb][i] - m);
+                const float pexp = __builtin_amdgcn_exp2f(fmaf(acc[kb][i], c2, -m2));
                 acc[kb][i] = pexp;
                 sum += pexp;
             }
         sum += __shfl_xor(sum, 32, 64);
         const float inv = 1.f / sum;
         if (h == 0 && q_valid)
-            lse[(((int64_t)b * heads + hh) * S + s_q) * F + f] = (m + __builtin_amdgcn_logf(sum)) * 0.69314718055994531f;
+            lse[(((int64_t)b * heads + hh) * S + s_q) * F + f] = (m2 + __builtin_amdgcn_logf(sum)) * 0.69314718055994531f;
 
         // ---- y[dblk][reg] = sum_key V^T[d][key] * P[key][q]  (P straight from the accumulators) ----
         f32x16 y[2];
@@ -131,7 +136,7 @@ __global__ __launch_bounds__(256, 2) void traj_space_fwd_kernel(const bf16_t* __
             for (int s2 = 0; s2 < 2; ++s2) {
                 Pack8 pf;
 #pragma unroll
-                for (int j = 0; j < 8; ++j) pf.e[j] = f32_to_bf16(acc[kb][8 * s2 + j] * inv);
+                for (int j = 0; j < 8; ++j) pf.e[j] = f32_to_bf16(acc[kb][8 * s2 + j]);   // un-normalised, <= 1
                 const int k0 = kb * 32 + 16 * s2 + 4 * h;
 #pragma unroll
                 for (int dblk = 0; dblk < 2; ++dblk) {
@@ -146,8 +151,8 @@ __global__ __launch_bounds__(256, 2) void traj_space_fwd_kernel(const bf16_t* __
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 uint2 pk;
-                pk.x = (uint32_t)f32_to_bf16(y[dblk][4 * g + 0]) | ((uint32_t)f32_to_bf16(y[dblk][4 * g + 1]) << 16);
-                pk.y = (uint32_t)f32_to_bf16(y[dblk][4 * g + 2]) | ((uint32_t)f32_to_bf16(y[dblk][4 * g + 3]) << 16);
+                pk.x = (uint32_t)f32_to_bf16(y[dblk][4 * g + 0] * inv) | ((uint32_t)f32_to_bf16(y[dblk][4 * g + 1] * inv) << 16);
+                pk.y = (uint32_t)f32_to_bf16(y[dblk][4 * g + 2] * inv) | ((uint32_t)f32_to_bf16(y[dblk][4 * g + 3] * inv) << 16);
                 *reinterpret_cast<uint2*>(slab + r * 128 + (((dblk * 8 + 2 * g + h) ^ (r & 15)) << 3)) = pk;
             }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the wave re-reads only its own slab
