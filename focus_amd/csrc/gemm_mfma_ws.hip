@@ -33,7 +33,7 @@ struct Unit { int m0, n0, nk; };
 // BM = 128: 4 consumer waves (2x2 of 64x64) + 4 loaders, 96 KiB ring.
 // BM = 256: 8 consumer waves (4x2 of 64x64) + 4 loaders, 144 KiB ring (85 flop per LDS-filled byte instead of 64;
 //           two consumer waves per SIMD overlap each other's ds_read latency).
-template <int BM, int BN, bool kNtStore>
+template <int BM, int BN, int EPI>
 __global__ __launch_bounds__(64 * (BM * BN / 4096 + 4)) void gemm_nt_ws_kernel(const focus_gemm_desc d, int tiles_m, int tiles_n, int GM) {
     constexpr int NCONS = BM * BN / 4096;                        // consumer waves (64x64 each)
     constexpr int WN = BN / 64;                                  // consumer grid is (BM/64) x WN
@@ -190,25 +190,24 @@ __global__ __launch_bounds__(64 * (BM * BN / 4096 + 4)) void gemm_nt_ws_kernel(c
                               __uint_as_float(raw.z << 16), __uint_as_float(raw.z & 0xffff0000u),
                               __uint_as_float(raw.w << 16), __uint_as_float(raw.w & 0xffff0000u)};
                 float xs[8];
-                if (d.epilogue >= FOCUS_EPI_DGELU) {
+                if constexpr (EPI >= FOCUS_EPI_DGELU) {
                     const uint4 xr = *reinterpret_cast<const uint4*>(X + off);
                     xs[0] = __uint_as_float(xr.x << 16); xs[1] = __uint_as_float(xr.x & 0xffff0000u);
                     xs[2] = __uint_as_float(xr.y << 16); xs[3] = __uint_as_float(xr.y & 0xffff0000u);
                     xs[4] = __uint_as_float(xr.z << 16); xs[5] = __uint_as_float(xr.z & 0xffff0000u);
                     xs[6] = __uint_as_float(xr.w << 16); xs[7] = __uint_as_float(xr.w & 0xffff0000u);
                 }
-                if (d.epilogue == FOCUS_EPI_GELU && X) *reinterpret_cast<uint4*>(X + off) = raw;
+                if constexpr (EPI == FOCUS_EPI_GELU) { if (X) *reinterpret_cast<uint4*>(X + off) = raw; }
+                // EPI is a template parameter: with a run-time switch here the 64 inlined copies of erf/tanh made the
+                // epilogue ~17k instructions (140 KB, larger than the instruction cache) and cost ~10 us per tile
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
-                    switch (d.epilogue) {
-                        case FOCUS_EPI_GELU: v[e] = gelu_erf(v[e]); break;
-                        case FOCUS_EPI_RELU: v[e] = fmaxf(v[e], 0.f); break;
-                        case FOCUS_EPI_TANH: v[e] = tanhf(v[e]); break;
-                        case FOCUS_EPI_DGELU: v[e] *= dgelu_erf(xs[e]); break;
-                        case FOCUS_EPI_DRELU: v[e] = xs[e] > 0.f ? v[e] : 0.f; break;
-                        case FOCUS_EPI_DTANH: v[e] *= (1.f - xs[e] * xs[e]); break;
-                        default: break;
-                    }
+                    if constexpr (EPI == FOCUS_EPI_GELU) v[e] = gelu_erf(v[e]);
+                    else if constexpr (EPI == FOCUS_EPI_RELU) v[e] = fmaxf(v[e], 0.f);
+                    else if constexpr (EPI == FOCUS_EPI_TANH) v[e] = tanhf(v[e]);
+                    else if constexpr (EPI == FOCUS_EPI_DGELU) v[e] *= dgelu_erf(xs[e]);
+                    else if constexpr (EPI == FOCUS_EPI_DRELU) v[e] = xs[e] > 0.f ? v[e] : 0.f;
+                    else if constexpr (EPI == FOCUS_EPI_DTANH) v[e] *= (1.f - xs[e] * xs[e]);
                 }
                 if (R) {
                     const uint4 rr = *reinterpret_cast<const uint4*>(R + off);
@@ -223,8 +222,8 @@ __global__ __launch_bounds__(64 * (BM * BN / 4096 + 4)) void gemm_nt_ws_kernel(c
                 o.z = (uint32_t)f32_to_bf16(v[4]) | ((uint32_t)f32_to_bf16(v[5]) << 16);
                 o.w = (uint32_t)f32_to_bf16(v[6]) | ((uint32_t)f32_to_bf16(v[7]) << 16);
                 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
-                if (kNtStore) __builtin_nontemporal_store((u32x4){o.x, o.y, o.z, o.w}, reinterpret_cast<u32x4*>(C + off));
-                else *reinterpret_cast<uint4*>(C + off) = o;
+                // non-temporal: C is not re-read by this kernel; keeps the A/B panels in L2 (+6-20 % at K <= 768)
+                __builtin_nontemporal_store((u32x4){o.x, o.y, o.z, o.w}, reinterpret_cast<u32x4*>(C + off));
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // slab re-read before the second half overwrites it
         }
@@ -264,12 +263,12 @@ bool focus_gemm_mfma_ws_ok(const focus_gemm_desc& d) {
     return true;
 }
 
-template <int BM, int BN, bool NT>
+template <int BM, int BN, int EPI>
 static int launch_ws(const focus_gemm_desc& d, hipStream_t s) {
     const int tiles_m = (d.M + BM - 1) / BM, tiles_n = (d.N + BN - 1) / BN;
     const int nbatch = d.batch0 * d.batch1;
     const size_t lds = (size_t)NSTAGE * (BM + BN) * 128;
-    auto k = gemm_nt_ws_kernel<BM, BN, NT>;
+    auto k = gemm_nt_ws_kernel<BM, BN, EPI>;
     static bool once = (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds) == hipSuccess);
     (void)once;
     const int nunits = tiles_m * tiles_n;
@@ -285,17 +284,25 @@ static int launch_ws(const focus_gemm_desc& d, hipStream_t s) {
     return FOCUS_OK;
 }
 
+template <int BM, int BN>
+static int launch_ws_epi(const focus_gemm_desc& d, hipStream_t s) {
+    switch (d.epilogue) {
+        case FOCUS_EPI_NONE: return launch_ws<BM, BN, FOCUS_EPI_NONE>(d, s);
+        case FOCUS_EPI_GELU: return launch_ws<BM, BN, FOCUS_EPI_GELU>(d, s);
+        case FOCUS_EPI_RELU: return launch_ws<BM, BN, FOCUS_EPI_RELU>(d, s);
+        case FOCUS_EPI_TANH: return launch_ws<BM, BN, FOCUS_EPI_TANH>(d, s);
+        case FOCUS_EPI_DGELU: return launch_ws<BM, BN, FOCUS_EPI_DGELU>(d, s);
+        case FOCUS_EPI_DRELU: return launch_ws<BM, BN, FOCUS_EPI_DRELU>(d, s);
+        case FOCUS_EPI_DTANH: return launch_ws<BM, BN, FOCUS_EPI_DTANH>(d, s);
+        default: return FOCUS_ERR_SHAPE;
+    }
+}
+
 int focus_gemm_mfma_ws(const focus_gemm_desc& d, hipStream_t s) {
     if (d.batch0 * d.batch1 > 65535) return FOCUS_ERR_SHAPE;
-    static const int bm = getenv("FOCUS_GEMM_WS_BM") ? atoi(getenv("FOCUS_GEMM_WS_BM")) : 256;
-    // 256-row tiles need enough of them to occupy the chip (one workgroup per CU)
-    static const bool nt = !(getenv("FOCUS_GEMM_WS_NT") && atoi(getenv("FOCUS_GEMM_WS_NT")) == 0);
-    static const bool wide = !(getenv("FOCUS_GEMM_WS_WIDE") && atoi(getenv("FOCUS_GEMM_WS_WIDE")) == 0);
     const int64_t t256 = (int64_t)((d.M + 255) / 256) * ((d.N + 127) / 128);
     const int64_t tw = (int64_t)((d.M + 127) / 128) * ((d.N + 255) / 256);
-    if (wide && bm == 256 && d.N >= 256 && tw >= 192)       // 128 rows x 256 columns: 512-byte row segments of C
-        return nt ? launch_ws<128, 256, true>(d, s) : launch_ws<128, 256, false>(d, s);
-    if (bm == 256 && d.M >= 256 && t256 >= 192)
-        return nt ? launch_ws<256, 128, true>(d, s) : launch_ws<256, 128, false>(d, s);
+    if (d.N >= 256 && tw >= 192) return launch_ws_epi<128, 256>(d, s);   // 512-byte row segments of C
+    if (d.M >= 256 && t256 >= 192) return launch_ws_epi<256, 128>(d, s);
     return FOCUS_ERR_SHAPE;   // too few tiles for one 8-consumer workgroup per CU: the caller uses the uniform kernel
 }
