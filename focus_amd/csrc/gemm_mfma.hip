@@ -34,7 +34,7 @@ __device__ __forceinline__ int swz(int row, int chunk) { return row * 128 + ((ch
 // always issued before the current step's MFMAs.  The pipeline is filled once per workgroup instead of once per
 // tile and every epilogue runs under the next tile's DMA flight (at K=768 a tile is only 12 K-steps long, so the
 // per-tile fill/drain was ~half of the time).
-template <int BM, int BN, int WAVES_M, int WAVES_N, bool LDSEPI, typename TC>
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool LDSEPI, int EPI, typename TC>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void gemm_nt_kernel(const focus_gemm_desc d, int tiles_m,
                                                                          int tiles_n, int splits, int k_per_split) {
     constexpr int NW = WAVES_M * WAVES_N;
@@ -180,7 +180,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void gemm_nt_kernel(cons
                 float v[4], pre[4];
                 const bool full = vec_ok && gn + 3 < d.N;
                 float xs[4] = {0.f, 0.f, 0.f, 0.f};
-                if (d.epilogue >= FOCUS_EPI_DGELU) {
+                if constexpr (EPI >= FOCUS_EPI_DGELU) {
                     if (full) { const f4 xa = ld4<TC>(X + off); xs[0] = xa.x; xs[1] = xa.y; xs[2] = xa.z; xs[3] = xa.w; }
                     else
                         for (int r4 = 0; r4 < 4; ++r4) if (gn + r4 < d.N) xs[r4] = ld<TC>(X + off + (int64_t)r4 * d.csC);
@@ -190,19 +190,16 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void gemm_nt_kernel(cons
                     float t = d.alpha * acc[i][jj][r4];
                     if (d.bias && gn + r4 < d.N) t += d.bias[gn + r4];
                     pre[r4] = t;
-                    switch (d.epilogue) {
-                        case FOCUS_EPI_GELU: t = gelu_erf(t); break;
-                        case FOCUS_EPI_RELU: t = fmaxf(t, 0.f); break;
-                        case FOCUS_EPI_TANH: t = tanhf(t); break;
-                        case FOCUS_EPI_DGELU: t *= dgelu_erf(xs[r4]); break;
-                        case FOCUS_EPI_DRELU: t = xs[r4] > 0.f ? t : 0.f; break;
-                        case FOCUS_EPI_DTANH: t *= (1.f - xs[r4] * xs[r4]); break;
-                        default: break;
-                    }
+                    if constexpr (EPI == FOCUS_EPI_GELU) t = gelu_erf(t);
+                    else if constexpr (EPI == FOCUS_EPI_RELU) t = fmaxf(t, 0.f);
+                    else if constexpr (EPI == FOCUS_EPI_TANH) t = tanhf(t);
+                    else if constexpr (EPI == FOCUS_EPI_DGELU) t *= dgelu_erf(xs[r4]);
+                    else if constexpr (EPI == FOCUS_EPI_DRELU) t = xs[r4] > 0.f ? t : 0.f;
+                    else if constexpr (EPI == FOCUS_EPI_DTANH) t *= (1.f - xs[r4] * xs[r4]);
                     v[r4] = t;
                 }
                 if (full) {
-                    if (d.epilogue == FOCUS_EPI_GELU && X) st4<TC>(X + off, (f4){pre[0], pre[1], pre[2], pre[3]});
+                    if constexpr (EPI == FOCUS_EPI_GELU) { if (X) st4<TC>(X + off, (f4){pre[0], pre[1], pre[2], pre[3]}); }
                     if (R) { const f4 rr = ld4<TC>(R + off); v[0] += rr.x; v[1] += rr.y; v[2] += rr.z; v[3] += rr.w; }
                     if (d.accumulate) { const f4 cc = ld4<TC>(C + off); v[0] += cc.x; v[1] += cc.y; v[2] += cc.z; v[3] += cc.w; }
                     st4<TC>(C + off, (f4){v[0], v[1], v[2], v[3]});
@@ -210,7 +207,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void gemm_nt_kernel(cons
                     for (int r4 = 0; r4 < 4; ++r4) {
                         if (gn + r4 >= d.N) break;
                         const int64_t o = off + (int64_t)r4 * d.csC;
-                        if (d.epilogue == FOCUS_EPI_GELU && X) st<TC>(X + o, pre[r4]);
+                        if constexpr (EPI == FOCUS_EPI_GELU) { if (X) st<TC>(X + o, pre[r4]); }
                         float t = v[r4];
                         if (R) t += ld<TC>(R + o);
                         if (d.accumulate) t += ld<TC>(C + o);
@@ -264,25 +261,24 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void gemm_nt_kernel(cons
                           __uint_as_float(raw.z << 16), __uint_as_float(raw.z & 0xffff0000u),
                           __uint_as_float(raw.w << 16), __uint_as_float(raw.w & 0xffff0000u)};
             float xs[8];
-            if (d.epilogue >= FOCUS_EPI_DGELU) {
+            if constexpr (EPI >= FOCUS_EPI_DGELU) {
                 const uint4 xr = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(X) + off);
                 xs[0] = __uint_as_float(xr.x << 16); xs[1] = __uint_as_float(xr.x & 0xffff0000u);
                 xs[2] = __uint_as_float(xr.y << 16); xs[3] = __uint_as_float(xr.y & 0xffff0000u);
                 xs[4] = __uint_as_float(xr.z << 16); xs[5] = __uint_as_float(xr.z & 0xffff0000u);
                 xs[6] = __uint_as_float(xr.w << 16); xs[7] = __uint_as_float(xr.w & 0xffff0000u);
             }
-            if (d.epilogue == FOCUS_EPI_GELU && X) *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(X) + off) = raw;
+            if constexpr (EPI == FOCUS_EPI_GELU) { if (X) *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(X) + off) = raw; }
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                switch (d.epilogue) {
-                    case FOCUS_EPI_GELU: v[e] = gelu_erf(v[e]); break;
-                    case FOCUS_EPI_RELU: v[e] = fmaxf(v[e], 0.f); break;
-                    case FOCUS_EPI_TANH: v[e] = tanhf(v[e]); break;
-                    case FOCUS_EPI_DGELU: v[e] *= dgelu_erf(xs[e]); break;
-                    case FOCUS_EPI_DRELU: v[e] = xs[e] > 0.f ? v[e] : 0.f; break;
-                    case FOCUS_EPI_DTANH: v[e] *= (1.f - xs[e] * xs[e]); break;
-                    default: break;
-                }
+                // EPI is a template parameter: a run-time switch here, unrolled 8x per row pass, grew the kernel to
+                // ~30k instructions (far beyond the instruction cache)
+                if constexpr (EPI == FOCUS_EPI_GELU) v[e] = gelu_erf(v[e]);
+                else if constexpr (EPI == FOCUS_EPI_RELU) v[e] = fmaxf(v[e], 0.f);
+                else if constexpr (EPI == FOCUS_EPI_TANH) v[e] = tanhf(v[e]);
+                else if constexpr (EPI == FOCUS_EPI_DGELU) v[e] *= dgelu_erf(xs[e]);
+                else if constexpr (EPI == FOCUS_EPI_DRELU) v[e] = xs[e] > 0.f ? v[e] : 0.f;
+                else if constexpr (EPI == FOCUS_EPI_DTANH) v[e] *= (1.f - xs[e] * xs[e]);
             }
             if (R) {
                 const uint4 rr = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(R) + off);
@@ -350,6 +346,18 @@ static bool lds_epilogue_ok(const focus_gemm_desc& d, int splits) {
     return true;
 }
 
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool LDSEPI, int EPI, typename TC>
+void launch_nt_inst(const focus_gemm_desc& d, dim3 grid, int tiles_m, int tiles_n, int splits, int k_per_split, hipStream_t s) {
+    constexpr size_t lds = 2 * (BM + BN) * 128;
+    auto k = gemm_nt_kernel<BM, BN, WAVES_M, WAVES_N, LDSEPI, EPI, TC>;
+    static bool once = (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds) == hipSuccess);
+    (void)once;
+    hipLaunchKernelGGL(k, grid, dim3(64 * WAVES_M * WAVES_N), lds, s, d, tiles_m, tiles_n, splits, k_per_split);
+}
+
+// Instances: bf16 output through the LDS epilogue for every activation; the direct epilogue (fp32 outputs, split-K
+// atomics, layouts the LDS epilogue cannot take) only without activation -- anything else returns FOCUS_ERR_SHAPE and
+// the dispatcher uses the generic kernel.
 template <int BM, int BN, int WAVES_M, int WAVES_N>
 int launch_nt(const focus_gemm_desc& d, int splits, hipStream_t s) {
     const int tiles_m = (d.M + BM - 1) / BM, tiles_n = (d.N + BN - 1) / BN;
@@ -363,26 +371,28 @@ int launch_nt(const focus_gemm_desc& d, int splits, hipStream_t s) {
     constexpr int per_cu = (160 * 1024) / (int)lds;
     const int nunits = tiles_m * tiles_n * splits;
     const int resident = 256 * per_cu / (nbatch > 1 ? std::min(nbatch, per_cu * 256) : 1);
-    dim3 grid(std::max(1, std::min(nunits, std::max(resident, 8))), nbatch), blk(64 * WAVES_M * WAVES_N);
-    constexpr bool can_lds = (BM / WAVES_M == 64) && (BN / WAVES_N == 64) && (WAVES_M * WAVES_N * 8192 <= (BM + BN) * 128);
-    if (d.dtype_c == FOCUS_BF16 && can_lds && lds_epilogue_ok(d, splits)) {
-        if constexpr (can_lds) {
-            auto k = gemm_nt_kernel<BM, BN, WAVES_M, WAVES_N, true, bf16_t>;
-            static bool once = (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds) == hipSuccess);
-            (void)once;
-            hipLaunchKernelGGL(k, grid, blk, lds, s, d, tiles_m, tiles_n, splits, k_per_split);
+    dim3 grid(std::max(1, std::min(nunits, std::max(resident, 8))), nbatch);
+    static_assert((BM / WAVES_M == 64) && (BN / WAVES_N == 64) && (WAVES_M * WAVES_N * 8192 <= (BM + BN) * 128), "LDS epilogue shape");
+#define FOCUS_NT_LDS(E) launch_nt_inst<BM, BN, WAVES_M, WAVES_N, true, E, bf16_t>(d, grid, tiles_m, tiles_n, splits, k_per_split, s)
+    if (d.dtype_c == FOCUS_BF16 && lds_epilogue_ok(d, splits)) {
+        switch (d.epilogue) {
+            case FOCUS_EPI_NONE: FOCUS_NT_LDS(FOCUS_EPI_NONE); break;
+            case FOCUS_EPI_GELU: FOCUS_NT_LDS(FOCUS_EPI_GELU); break;
+            case FOCUS_EPI_RELU: FOCUS_NT_LDS(FOCUS_EPI_RELU); break;
+            case FOCUS_EPI_TANH: FOCUS_NT_LDS(FOCUS_EPI_TANH); break;
+            case FOCUS_EPI_DGELU: FOCUS_NT_LDS(FOCUS_EPI_DGELU); break;
+            case FOCUS_EPI_DRELU: FOCUS_NT_LDS(FOCUS_EPI_DRELU); break;
+            case FOCUS_EPI_DTANH: FOCUS_NT_LDS(FOCUS_EPI_DTANH); break;
+            default: return FOCUS_ERR_SHAPE;
         }
+    } else if (d.epilogue != FOCUS_EPI_NONE) {
+        return FOCUS_ERR_SHAPE;
     } else if (d.dtype_c == FOCUS_BF16) {
-        auto k = gemm_nt_kernel<BM, BN, WAVES_M, WAVES_N, false, bf16_t>;
-        static bool once = (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds) == hipSuccess);
-        (void)once;
-        hipLaunchKernelGGL(k, grid, blk, lds, s, d, tiles_m, tiles_n, splits, k_per_split);
+        launch_nt_inst<BM, BN, WAVES_M, WAVES_N, false, FOCUS_EPI_NONE, bf16_t>(d, grid, tiles_m, tiles_n, splits, k_per_split, s);
     } else {
-        auto k = gemm_nt_kernel<BM, BN, WAVES_M, WAVES_N, false, float>;
-        static bool once = (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds) == hipSuccess);
-        (void)once;
-        hipLaunchKernelGGL(k, grid, blk, lds, s, d, tiles_m, tiles_n, splits, k_per_split);
+        launch_nt_inst<BM, BN, WAVES_M, WAVES_N, false, FOCUS_EPI_NONE, float>(d, grid, tiles_m, tiles_n, splits, k_per_split, s);
     }
+#undef FOCUS_NT_LDS
     FOCUS_CHECK_LAUNCH();
     return FOCUS_OK;
 }
@@ -404,7 +414,6 @@ int focus_gemm_mfma_nt(const focus_gemm_desc& d, hipStream_t s) {
     const int nbatch = d.batch0 * d.batch1;
     if (nbatch > 65535) return FOCUS_ERR_SHAPE;
     constexpr int CUS = 256;
-    const int64_t t256 = (int64_t)((d.M + 255) / 256) * ((d.N + 255) / 256) * nbatch;
     const int64_t t128 = (int64_t)((d.M + 127) / 128) * ((d.N + 127) / 128) * nbatch;
     // split-K only for plain fp32-output products (weight gradients): tiny output, long reduction
     const bool can_split = d.dtype_c == FOCUS_F32 && d.epilogue == FOCUS_EPI_NONE && !d.bias && !d.residual &&
@@ -414,18 +423,11 @@ int focus_gemm_mfma_nt(const focus_gemm_desc& d, hipStream_t s) {
         if (splits < 1) splits = 1;
         return launch_nt<128, 128, 2, 2>(d, splits, s);
     }
-    (void)t256;
     if (focus_gemm_mfma_ws_ok(d)) {
         const int rc = focus_gemm_mfma_ws(d, s);
         if (rc != FOCUS_ERR_SHAPE) return rc;
     }
-    static const int variant = getenv("FOCUS_GEMM_VARIANT") ? atoi(getenv("FOCUS_GEMM_VARIANT")) : 0;
-    switch (variant) {   // tuning hook (tools/gemm_sweep.py); 0 is the shipped configuration
-        case 4: return launch_nt<256, 128, 4, 2>(d, 1, s);
-        case 7: return launch_nt<256, 256, 2, 4>(d, 1, s);
-        case 6: return launch_nt<128, 256, 2, 4>(d, 1, s);
-        default: return launch_nt<128, 128, 2, 2>(d, 1, s);
-    }
+    return launch_nt<128, 128, 2, 2>(d, 1, s);
 }
 
 // ---- public dispatcher ---------------------------------------------------------------------------
@@ -441,8 +443,10 @@ extern "C" int focus_gemm(const focus_gemm_desc* desc, void* stream) {
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (focus_gemm_mfma_tn_ok(d)) return focus_gemm_mfma_tn(d, s);     // checked first: in this form aux is its slab workspace
     if (d.aux && d.epilogue == FOCUS_EPI_NONE) d.aux = nullptr;
-    if (focus_gemm_mfma_nt_ok(d)) return focus_gemm_mfma_nt(d, s);
-    if (focus_gemm_mfma_tn_ok(d)) return focus_gemm_mfma_tn(d, s);
+    if (focus_gemm_mfma_nt_ok(d)) {
+        const int rc = focus_gemm_mfma_nt(d, s);
+        if (rc != FOCUS_ERR_SHAPE) return rc;      // shape/epilogue the MFMA instances do not cover
+    }
     return focus_gemm_generic(d, s);
 }
 
