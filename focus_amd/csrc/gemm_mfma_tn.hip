@@ -4,7 +4,7 @@
 // activations -- no transposed copies of dY and X (the NT kernel needs both re-laid K-contiguous, which cost two
 // extra HBM round trips per Linear per step).
 // LDS tiles keep the global layout ([64 rows of m][128 columns], 256-B rows, DMA'd by global_load_lds_dwordx4
-// with a 16-B chunk swizzle chunk ^= row & 15 applied on the source address); the MFMA fragments, whose k index
+// with a 16-B chunk swizzle (swz below) applied on the source address); the MFMA fragments, whose k index
 // runs over tile ROWS, are gathered with ds_read_b64_tr_b16 (cdna_hip_programming.md T10; semantics pinned by
 // tests/test_gpu_parity.py::test_tr16_probe...).  128x128 output tile, 4 waves (2x2), v_mfma_f32_16x16x32_bf16,
 // double-buffered, split over m with fp32 atomics into a zero-initialised C (the output is tiny, the reduction long).
@@ -28,8 +28,13 @@ constexpr int TILE = BKM * 256;                    // 16 KiB per operand per sta
 union Frag { bf16x8 v; s16x4 t[2]; };
 
 // byte offset of element (row, col) [col multiple of 4] in a [64][128 bf16] tile, 16-B chunks swizzled by row
+// The swizzle is chosen for the transposed reads: one 32-lane bank group of ds_read_b64_tr_b16 touches tile rows
+// {r..r+3} u {r+8..r+11} x two adjacent chunks, so the XOR key must give those 8 rows 8 different EVEN values
+// (key = row & 15 put rows r and r+1 on the same chunk pair: a 2-way conflict on every read, measured as
+// SQ_LDS_BANK_CONFLICT = 50 % of SQ_LDS_IDX_ACTIVE).
+__device__ __forceinline__ int swz(int row) { return ((row & 3) | ((row >> 1) & 4)) << 1; }
 __device__ __forceinline__ int toff(int row, int col) {
-    return row * 256 + ((((col >> 3)) ^ (row & 15)) << 4) + (col & 4) * 2;
+    return row * 256 + ((((col >> 3)) ^ swz(row)) << 4) + (col & 4) * 2;
 }
 
 // k = tile rows r0..r0+7 (natural order), m/n = tile column c0 + (lane & 15); lane group g = lane>>4 selects r0.
@@ -84,7 +89,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const focus_gemm_desc d
         for (int g = 0; g < 4; ++g) {
             const int row = (w * 4 + g) * 4 + rin;
             const int m = min(m_begin + kt * BKM + row, Mred - 1);
-            const int ch = cpos ^ (row & 15);
+            const int ch = cpos ^ swz(row);
             const int ci = min(i0 + ch * 8, d.M - 8), cj = min(j0 + ch * 8, d.N - 8);
             __builtin_amdgcn_global_load_lds((gvoid_t*)(Pm + (int64_t)m * ldp + ci), (lvoid_t*)(sp + (w * 4 + g) * 1024), 16, 0, 0);
             __builtin_amdgcn_global_load_lds((gvoid_t*)(Qm + (int64_t)m * ldq + cj), (lvoid_t*)(sq + (w * 4 + g) * 1024), 16, 0, 0);

@@ -28,8 +28,15 @@ constexpr float LOG2E = 1.44269504088896341f;
 
 union Pack8 { bf16x8 v; bf16_t e[8]; uint4 u; uint2 h2[2]; s16x4 t[2]; };
 
-// byte offset of the 16-B chunk `chunk` of row `row` in a [rows][64 bf16] tile with 128-B rows
-__device__ __forceinline__ int swz(int row, int chunk) { return row * 128 + ((chunk ^ (row & 7)) << 4); }
+// 16-B chunk swizzle of a [rows][64 bf16] tile with 128-B rows.  A row covers half of the 64 LDS banks (row parity
+// picks the half), so the XOR key is built from row>>1, bit-reversed: (a) a ds_read_b128 bank group reads one chunk
+// of 16 rows whose row>>1 values are 8 distinct ones mod 8 -> 16 distinct (half, chunk) slots; (b) a
+// ds_read_b64_tr_b16 bank group reads 4 adjacent chunks of rows r..r+3 -> rows r and r+2 need keys that differ in
+// bit 2, which the reversal provides.  (key = row & 7 was 2-way conflicted on both: SQ_LDS_BANK_CONFLICT ~40 %.)
+__device__ __forceinline__ int swz(int row, int chunk) {
+    const int key = ((row & 2) << 1) | ((row >> 1) & 2) | ((row >> 3) & 1);
+    return row * 128 + ((chunk ^ key) << 4);
+}
 
 // MFMA 32x32x16 operand whose k index runs over tile ROWS and whose m/n index is a tile COLUMN, in the k order of
 // an accumulator tile used as the other operand: element j <-> row r0 + 8*(j>>2) + (j&3), column c0 + (lane&31),

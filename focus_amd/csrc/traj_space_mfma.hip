@@ -24,7 +24,15 @@ typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
 constexpr int HD = 64;                 // head dim
 constexpr int QT = 128;                // queries per workgroup (4 waves x 32)
 
-__device__ __forceinline__ int swz(int row, int chunk) { return row * 128 + ((chunk ^ (row & 7)) << 4); }
+// 16-B chunk swizzle of a [rows][64 bf16] tile with 128-B rows.  A row covers half of the 64 LDS banks (row parity
+// picks the half), so the XOR key is built from row>>1, bit-reversed: (a) a ds_read_b128 bank group reads one chunk
+// of 16 rows whose row>>1 values are 8 distinct ones mod 8 -> 16 distinct (half, chunk) slots; (b) a
+// ds_read_b64_tr_b16 bank group reads 4 adjacent chunks of rows r..r+3 -> rows r and r+2 need keys that differ in
+// bit 2, which the reversal provides.  (key = row & 7 was 2-way conflicted on both: SQ_LDS_BANK_CONFLICT ~40 %.)
+__device__ __forceinline__ int swz(int row, int chunk) {
+    const int key = ((row & 2) << 1) | ((row >> 1) & 2) | ((row >> 3) & 1);
+    return row * 128 + ((chunk ^ key) << 4);
+}
 
 union Pack8 { bf16x8 v; bf16_t e[8]; uint4 u; s16x4 t[2]; };
 
