@@ -88,6 +88,7 @@ def main():
     ap.add_argument("--batch", type=int, default=8, help="clips per GPU")
     ap.add_argument("--fp32", action="store_true", help="TRAIN.MIXED_PRECISION False (precision path)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--gemm-shapes", action="store_true", help="print per-shape GEMM timings to stderr")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="process-group backend (nccl = RCCL; gloo for a rehearsal)")
     ap.add_argument("--same-device", action="store_true",
@@ -170,6 +171,16 @@ def main():
         ms = sum(r[1].elapsed_time(r[2]) for r in recs)
         ach = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
         tn_ms = sum(r[1].elapsed_time(r[2]) for r in tn)
+        if args.gemm_shapes:
+            import collections
+            by = collections.defaultdict(lambda: [0, 0.0, 0.0])
+            for r in allrecs:
+                e = by[(r[3],) + r[4]]
+                e[0] += 1; e[1] += r[1].elapsed_time(r[2]); e[2] += r[0]
+            print("kind (M,N,K,batch,epi)  calls/step  avg_us  TF/s  ms/step", file=sys.stderr)
+            for k, e in sorted(by.items(), key=lambda kv: -kv[1][1]):
+                print("%-44s %5.1f %8.1f %7.0f %7.3f" % (k, e[0] / args.steps, 1e3 * e[1] / e[0], e[2] / e[1] / 1e9,
+                                                         e[1] / args.steps), file=sys.stderr)
         tn_tf = sum(r[0] for r in tn) / (tn_ms * 1e-3) / 1e12 if tn_ms > 0 else 0.0
         out["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                            "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None,
@@ -177,7 +188,7 @@ def main():
                            "launches_per_step": len(recs) // max(args.steps, 1),
                            "avg_launch_us": round(1e3 * ms / max(len(recs), 1), 2),
                            "kernel_ms_per_step": round(ms / max(args.steps, 1), 3),
-                           "weight_grad_kernel": {"kernel": "gemm_tn_kernel (gemm_mfma_tn.hip)",
+                           "weight_grad_kernel": {"kernel": "gemm_tn_ws_kernel / gemm_tn_kernel (gemm_mfma_tn_ws.hip, gemm_mfma_tn.hip)",
                                                   "achieved": round(tn_tf, 2),
                                                   "ms_per_step": round(tn_ms / max(args.steps, 1), 3)}}
     elif world > 1 and not args.no_roofline and not args.fp32:

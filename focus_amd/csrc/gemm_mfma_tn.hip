@@ -203,6 +203,8 @@ TnPlan tn_plan(int M, int N, int K) {
 
 extern "C" size_t focus_gemm_tn_workspace_bytes(int M, int N, int K) {
     if (M <= 0 || N <= 0 || K <= 0) return 0;
+    const focus_tn_plan ws = focus_gemm_tn_ws_plan(M, N, K);
+    if (ws.kind) return (size_t)ws.splits * M * N * sizeof(float);
     return (size_t)tn_plan(M, N, K).splits * M * N * sizeof(float);
 }
 
@@ -221,6 +223,18 @@ bool focus_gemm_mfma_tn_ok(const focus_gemm_desc& d) {
 
 int focus_gemm_mfma_tn(const focus_gemm_desc& d, hipStream_t s) {
     if (!focus_gemm_mfma_tn_ok(d)) return FOCUS_ERR_ALIGN;
+    const focus_tn_plan ws = focus_gemm_tn_ws_plan(d.M, d.N, d.K);
+    if (ws.kind) {                                   // large outputs with a long reduction: wave-specialised kernel
+        const int rc = focus_gemm_mfma_tn_ws(d, ws, s);
+        if (rc != FOCUS_OK) return rc;
+        if (d.aux) {
+            const int64_t n4 = (int64_t)d.M * d.N / 4;
+            hipLaunchKernelGGL(tn_reduce_kernel, dim3((unsigned)cdiv64(n4, 256)), dim3(256), 0, s, (const float*)d.aux,
+                               (float*)d.C, n4, ws.splits, d.N, d.rsC);
+            FOCUS_CHECK_LAUNCH();
+        }
+        return FOCUS_OK;
+    }
     const TnPlan pl = tn_plan(d.M, d.N, d.K);
     const int tiles_i = pl.tiles_i, tiles_j = pl.tiles_j, tiles = tiles_i * tiles_j, splits = pl.splits;
     const int m_per_split = pl.m_per_split;

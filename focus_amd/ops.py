@@ -87,7 +87,7 @@ def gemm(M, N, K, A, sA, B, sB, C, sC, batch=(1, 1), bias=None, residual=None, a
         e0.record()
         _lib.check(_lib.lib().focus_gemm(ctypes.byref(d), _stream()), "gemm")
         e1.record()
-        GEMM_TIMING.append((2.0 * M * N * K * batch[0] * batch[1], e0, e1, kind))
+        GEMM_TIMING.append((2.0 * M * N * K * batch[0] * batch[1], e0, e1, kind, (M, N, K, batch[0] * batch[1], epilogue)))
         return
     _lib.check(_lib.lib().focus_gemm(ctypes.byref(d), _stream()), "gemm")
 

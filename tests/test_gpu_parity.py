@@ -547,3 +547,19 @@ def test_tr16_probe_documents_transposed_lds_read():
         g, i = l // 16, l % 16
         # lane i of group g receives column i of the block's 4 rows (rows 4g..4g+3), row q in element q
         assert got[l].tolist() == [100 * (4 * g + q) + i for q in range(4)], (l, got[l].tolist())
+
+
+@pytest.mark.parametrize("shape", [(768, 384, 12552), (384, 768, 4104), (136, 264, 2500), (264, 136, 2055),
+                                   (2304, 768, 6280), (256, 256, 2048)])
+def test_weight_grad_gemm_ws(shape):
+    """dW = dY^T . X through the wave-specialised TN kernel (long reductions, ragged edges on every side) against
+    an fp64 product of the same bf16 operands; the result is fp32 (exact products, fp32 accumulation order differs)."""
+    from focus_amd import ops
+    N, K, M = shape
+    g = torch.Generator().manual_seed(N + K + M)
+    dy = torch.randn(M, N, generator=g).bfloat16().to(dev())
+    x = torch.randn(M, K, generator=g).bfloat16().to(dev())
+    got = ops.mm_tn(dy, x)
+    want = (dy.double().t() @ x.double()).float()
+    assert got.shape == (N, K) and got.dtype == torch.float32
+    assert rel(got, want) < 1e-5

@@ -9,7 +9,7 @@ from focus_amd import ops  # noqa: E402
 dev = torch.device("cuda:0")
 once = len(sys.argv) > 1
 out = []
-for (N, K, M) in [(3072, 768, 12552), (768, 3072, 12552), (768, 768, 12552), (2304, 768, 12552), (768, 768, 100352)]:
+for (N, K, M) in [(3072, 768, 12552), (768, 3072, 12552), (768, 768, 12552), (2304, 768, 12552), (768, 768, 100352), (384, 768, 50176), (768, 1536, 12544)]:
     dy = torch.randn(M, N, device=dev).bfloat16()
     x = torch.randn(M, K, device=dev).bfloat16()
     c = ops.mm_tn(dy, x)
