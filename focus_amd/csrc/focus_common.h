@@ -45,6 +45,21 @@ template <> __device__ __forceinline__ void st4<bf16_t>(bf16_t* p, f4 v) {
     *reinterpret_cast<uint2*>(p) = o;
 }
 
+// ---- LDS-DMA issued from inline asm ----------------------------------------------------------------
+// global_load_lds_dwordx4 hidden from hipcc: with the builtin the compiler cannot tell which later LDS accesses alias
+// the DMA in flight and drains s_waitcnt vmcnt(0) before them (measured in traj_space_fwd: every frame's prefetch was
+// waited for right after it was issued).  The statement is absent from the compiler's vmcnt bookkeeping: the caller
+// counts it (s_waitcnt vmcnt(N)), then a barrier, then the ds_read (cdna_hip_programming.md, inline-asm rules).
+// lds_dst: wave-uniform LDS byte address of the 1 KiB piece; lane l writes bytes [16 l, 16 l + 16) of it.
+__device__ __forceinline__ uint32_t lds_addr_of(const void* p) {
+    return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)p;
+}
+__device__ __forceinline__ void glds16(const void* gsrc, uint32_t lds_dst) {
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+
 // ---- wave (64 lanes) and block reductions --------------------------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

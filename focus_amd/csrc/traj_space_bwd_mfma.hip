@@ -169,12 +169,12 @@ __global__ __launch_bounds__(256, 2) void traj_dq_kernel(const bf16_t* __restric
                 sa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], sa, 0, 0, 0);
                 dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, df[ks], dp, 0, 0, 0);
             }
-            const bool tail = kb * 32 + 32 > P;          // wave-uniform: only the last key block is padded
+            // padded keys need no mask here: their K rows are staged as zeros, so whatever dL they get is multiplied
+            // by K^T = 0 in the dQ product (and exp2(0 - lse2) is finite)
             const float dels = del * scale;
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
-                float pr = __builtin_amdgcn_exp2f(fmaf(sa[i], c2, -lse2));
-                if (tail && kb * 32 + (i & 3) + 8 * (i >> 2) + 4 * h >= P) pr = 0.f;
+                const float pr = __builtin_amdgcn_exp2f(fmaf(sa[i], c2, -lse2));
                 sa[i] = pr * fmaf(dp[i], scale, -dels);   // dL[key][q] = P * (dP - delta) * scale
             }
 #pragma unroll
@@ -374,9 +374,14 @@ int focus_traj_space_bwd_mfma(const void* qkv, const void* xt, const float* lse,
     hipLaunchKernelGGL(traj_delta_kernel, dim3((unsigned)cdiv64(rows, 4)), dim3(256), 0, s, (const bf16_t*)dxt,
                        (const bf16_t*)dxdiag, (const bf16_t*)xt, delta, rows, S, F, P, heads);
     FOCUS_CHECK_LAUNCH();
-    const int nkb = (P + 31) / 32;
-    if (nkb <= 1) return launch_bwd<1>(qkv, dxt, dxdiag, lse, delta, dqkv, B, F, P, heads, s);
-    if (nkb <= 2) return launch_bwd<2>(qkv, dxt, dxdiag, lse, delta, dqkv, B, F, P, heads, s);
-    if (nkb <= 4) return launch_bwd<4>(qkv, dxt, dxdiag, lse, delta, dqkv, B, F, P, heads, s);
+    switch ((P + 31) / 32) {
+        case 1: return launch_bwd<1>(qkv, dxt, dxdiag, lse, delta, dqkv, B, F, P, heads, s);
+        case 2: return launch_bwd<2>(qkv, dxt, dxdiag, lse, delta, dqkv, B, F, P, heads, s);
+        case 3: return launch_bwd<3>(qkv, dxt, dxdiag, lse, delta, dqkv, B, F, P, heads, s);
+        case 4: return launch_bwd<4>(qkv, dxt, dxdiag, lse, delta, dqkv, B, F, P, heads, s);
+        case 5: return launch_bwd<5>(qkv, dxt, dxdiag, lse, delta, dqkv, B, F, P, heads, s);
+        case 6: return launch_bwd<6>(qkv, dxt, dxdiag, lse, delta, dqkv, B, F, P, heads, s);
+        default: break;
+    }
     return launch_bwd<7>(qkv, dxt, dxdiag, lse, delta, dqkv, B, F, P, heads, s);
 }

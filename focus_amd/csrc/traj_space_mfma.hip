@@ -20,6 +20,8 @@ typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+typedef __attribute__((address_space(1))) const void gvoid_t;
+typedef __attribute__((address_space(3))) void lvoid_t;
 
 constexpr int HD = 64;                 // head dim
 constexpr int QT = 128;                // queries per workgroup (4 waves x 32)
@@ -53,15 +55,16 @@ __global__ __launch_bounds__(256, 2) void traj_space_fwd_kernel(const bf16_t* __
                                                                 bf16_t* __restrict__ xdiag, float* __restrict__ lse,
                                                                 int B, int F, int P, int heads) {
     constexpr int KROWS = NKB * 32;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* sK = smem;                                          // [KROWS][64] bf16, 128-B rows, chunk-swizzled
-    char* sV = smem + KROWS * 128;                            // same layout for V (read by columns: col_frag)
-    char* slabs = smem + 2 * KROWS * 128;                     // 4 x [32][128 B]
+    // K and V tiles are SEPARATE LDS objects on purpose: with one array the compiler cannot tell a ds_read of K from
+    // an LDS-DMA to V in flight and drains vmcnt(0) before every first read (cdna_hip_programming.md section 5)
+    __shared__ __attribute__((aligned(1024))) char sK[KROWS * 128];   // [KROWS][64] bf16, 128-B rows, chunk-swizzled
+    __shared__ __attribute__((aligned(1024))) char sV[KROWS * 128];   // same layout for V (read by columns: col_frag)
+    __shared__ __attribute__((aligned(1024))) char slabs[4 * 4096];   // 4 x [32][128 B] output slabs, one per wave
 
     const int S = F * P, N = S + 1, C = heads * HD;
     const int64_t tok = 3 * (int64_t)C;
     const int bh = blockIdx.y, b = bh / heads, hh = bh % heads;
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
     const int s_q = min(blockIdx.x * QT + w * 32 + r, S - 1);  // this lane's query (clamped)
     const bool q_valid = blockIdx.x * QT + w * 32 + r < S;
@@ -75,22 +78,29 @@ __global__ __launch_bounds__(256, 2) void traj_space_fwd_kernel(const bf16_t* __
         qf[ks] = *reinterpret_cast<const bf16x8*>(base + (int64_t)(1 + s_q) * tok + ks * 16 + 8 * h);
 
     char* slab = slabs + w * 4096;
-    for (int f = 0; f < F; ++f) {
-        __syncthreads();   // previous frame's tiles are no longer read
-        // ---- stage K_f and V_f, both row-major with the 16-B chunk swizzle ----
-        for (int e = tid; e < KROWS * 8; e += 256) {
-            const int p = e >> 3, c = e & 7;
-            uint4 kv = make_uint4(0, 0, 0, 0), vv = kv;
-            if (p < P) {
-                const bf16_t* row = base + (int64_t)(1 + f * P + p) * tok + c * 8;
-                kv = *reinterpret_cast<const uint4*>(row + C);
-                vv = *reinterpret_cast<const uint4*>(row + 2 * C);
-            }
-            *reinterpret_cast<uint4*>(sK + swz(p, c)) = kv;
-            *reinterpret_cast<uint4*>(sV + swz(p, c)) = vv;
+    // ---- K_f / V_f staging by LDS-DMA (global_load_lds_dwordx4), issued by the same 4 waves and overlapped by phase:
+    // K_{f+1} streams in while frame f's softmax and P.V run, V_{f+1} while frame f's rows leave and frame f+1's
+    // logits are computed.  One wave instruction fills 8 tile rows (1 KiB, lane-linear); the chunk swizzle is
+    // applied on the SOURCE address; rows >= P are clamped to row P-1 (their logits are masked below).
+    // Waits are counted: a wave's only other vector-memory traffic is stores, and loads retire in order, so
+    // "at most NKB outstanding" means every load older than the last NKB has landed.
+    const int drow = lane >> 3, dkey = ((drow & 2) << 1) | ((drow >> 1) & 2);          // key bits of row&7 (see swz)
+    auto dma_tile = [&](char* tile, int f, int part) __attribute__((always_inline)) {
+#pragma unroll
+        for (int g = 0; g < NKB; ++g) {
+            const int t = g * 4 + w;                                  // 8-row group of the tile
+            const int row = t * 8 + drow;
+            const int key = dkey | ((t & 1));                         // bit 3 of the row = bit 0 of t
+            const bf16_t* src = base + (int64_t)(1 + f * P + min(row, P - 1)) * tok + part * C + (((lane & 7) ^ key) << 3);
+            glds16(src, __builtin_amdgcn_readfirstlane(lds_addr_of(tile) + t * 1024));
         }
-        __syncthreads();
-
+    };
+    dma_tile(sK, 0, 1);
+    dma_tile(sV, 0, 2);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    for (int f = 0; f < F; ++f) {
+        const bool more = f + 1 < F;
         // ---- logits: acc[kb][reg] = sum_d K[kb*32 + row(reg,h)][d] * Q[q=r][d] ----
         f32x16 acc[NKB];
 #pragma unroll
@@ -103,6 +113,9 @@ __global__ __launch_bounds__(256, 2) void traj_space_fwd_kernel(const bf16_t* __
                 acc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], acc[kb], 0, 0, 0);
             }
         }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                 // A: every wave has read K_f
+        if (more) dma_tile(sK, f + 1, 1);
         // ---- per-(query, frame) softmax over the P keys: this lane holds half of its query's keys.
         // VALU-lean form (the kernel is softmax-bound, not MFMA-bound): raw-logit max, one fma + one exp2 per
         // element, only the tail key block is masked, and the 1/sum normalisation is applied to the 32 outputs
@@ -110,10 +123,14 @@ __global__ __launch_bounds__(256, 2) void traj_space_fwd_kernel(const bf16_t* __
         float m = -INFINITY;
 #pragma unroll
         for (int kb = 0; kb < NKB; ++kb) {
-            if (kb * 32 + 32 > P) {          // wave-uniform: only the last block can hold padded keys
+            // NKB == ceil(P/32) (one instantiation per block count): only the LAST block holds padded keys, and that
+            // is known at compile time -- a run-time test per block made the compiler materialise all 16*NKB key
+            // masks (cmp + s_or + cndmask + SGPR spills: ~900 of the ~2000 instructions per frame)
+            if (kb == NKB - 1) {
+                const int lim = P - kb * 32 - 4 * h;      // row (i&3) + 8*(i>>2) of this lane's half is real iff < lim
 #pragma unroll
                 for (int i = 0; i < 16; ++i)
-                    if (kb * 32 + (i & 3) + 8 * (i >> 2) + 4 * h >= P) acc[kb][i] = -INFINITY;
+                    if ((i & 3) + 8 * (i >> 2) >= lim) acc[kb][i] = -INFINITY;
             }
 #pragma unroll
             for (int i = 0; i < 16; ++i) m = fmaxf(m, acc[kb][i]);
@@ -134,6 +151,10 @@ __global__ __launch_bounds__(256, 2) void traj_space_fwd_kernel(const bf16_t* __
         if (h == 0 && q_valid)
             lse[(((int64_t)b * heads + hh) * S + s_q) * F + f] = (m2 + __builtin_amdgcn_logf(sum)) * 0.69314718055994531f;
 
+        // V_f was issued before the K_{f+1} pieces above: at most NKB loads outstanding <=> V_f has landed
+        if (more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NKB) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                 // D: V_f is visible to every wave
         // ---- y[dblk][reg] = sum_key V^T[d][key] * P[key][q]  (P straight from the accumulators) ----
         f32x16 y[2];
 #pragma unroll
@@ -153,6 +174,13 @@ __global__ __launch_bounds__(256, 2) void traj_space_fwd_kernel(const bf16_t* __
                 }
             }
 
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                 // B: every wave has read V_f
+        if (more) {
+            dma_tile(sV, f + 1, 2);
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NKB) : "memory");   // K_{f+1} (issued after A) has landed
+            __builtin_amdgcn_s_barrier();             // C: K_{f+1} is visible to every wave
+        }
         // ---- rows out through the wave's LDS slab: [32 q][16 chunks of 8 B], chunk ^= q & 15 ----
 #pragma unroll
         for (int dblk = 0; dblk < 2; ++dblk)
@@ -183,7 +211,7 @@ __global__ __launch_bounds__(256, 2) void traj_space_fwd_kernel(const bf16_t* __
 template <int NKB>
 int launch_fwd(const void* qkv, void* xt, void* xdiag, float* lse, int B, int F, int P, int heads, hipStream_t s) {
     const int S = F * P;
-    const size_t lds = (size_t)2 * NKB * 32 * 128 + 4 * 4096;
+    const size_t lds = 0;            // all LDS is static (separate objects, see the kernel)
     auto k = traj_space_fwd_kernel<NKB>;
     static bool once = (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds) == hipSuccess);
     (void)once;
@@ -205,9 +233,14 @@ int focus_traj_space_fwd_mfma(const void* qkv, void* xt, void* xdiag, float* lse
                               hipStream_t s) {
     if (B * heads > 65535) return FOCUS_ERR_SHAPE;
     if (!focus_aligned(qkv, 16) || !focus_aligned(xt, 16) || !focus_aligned(xdiag, 16)) return FOCUS_ERR_ALIGN;
-    const int nkb = (P + 31) / 32;
-    if (nkb <= 1) return launch_fwd<1>(qkv, xt, xdiag, lse, B, F, P, heads, s);
-    if (nkb <= 2) return launch_fwd<2>(qkv, xt, xdiag, lse, B, F, P, heads, s);
-    if (nkb <= 4) return launch_fwd<4>(qkv, xt, xdiag, lse, B, F, P, heads, s);
+    switch ((P + 31) / 32) {     // exact block count: the kernels rely on NKB == ceil(P/32)
+        case 1: return launch_fwd<1>(qkv, xt, xdiag, lse, B, F, P, heads, s);
+        case 2: return launch_fwd<2>(qkv, xt, xdiag, lse, B, F, P, heads, s);
+        case 3: return launch_fwd<3>(qkv, xt, xdiag, lse, B, F, P, heads, s);
+        case 4: return launch_fwd<4>(qkv, xt, xdiag, lse, B, F, P, heads, s);
+        case 5: return launch_fwd<5>(qkv, xt, xdiag, lse, B, F, P, heads, s);
+        case 6: return launch_fwd<6>(qkv, xt, xdiag, lse, B, F, P, heads, s);
+        default: break;
+    }
     return launch_fwd<7>(qkv, xt, xdiag, lse, B, F, P, heads, s);
 }
