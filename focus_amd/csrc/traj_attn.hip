@@ -154,8 +154,9 @@ extern "C" size_t focus_traj_space_workspace_bytes(int B, int F, int P, int head
     if (backward) {
         bytes += (size_t)B * heads * N * es + 4096;          // d(cls row) + alignment padding of the carve-up
         if (fused) {
-            bytes += (size_t)B * heads * S * F * sizeof(float) + 256;   // delta
+            bytes += (size_t)2 * (B * heads * S * F * sizeof(float) + 256);   // delta * scale, lse in base-2 units
             bytes += (size_t)2 * B * heads * N * sizeof(float) + 256;   // cls prob / dlog scratch
+            bytes += (size_t)B * S * C * es + 256;                      // dxsum: dX rows of each query's own frame
         } else {
             bytes += (size_t)B * heads * S * S * es;         // d(prob) / d(logits)
             bytes += (size_t)B * S * F * C * es;             // dxt + diagonal term
@@ -238,7 +239,11 @@ extern "C" int focus_traj_space_bwd(const void* qkv, const void* xt, const void*
     int rc;
     if (fused) {
         // patch rows first: fully writes the q/k/v parts of tokens 1..N-1; the cls step below adds onto k/v
-        if ((rc = focus_traj_space_bwd_mfma(qkv, xt, lse, dxt, dxdiag, reinterpret_cast<float*>(L), dqkv, B, F, P, heads, s)))
+        float* delta = reinterpret_cast<float*>(L);
+        float* cls_scratch = delta + (((int64_t)B * heads * D.S * F + 63) & ~(int64_t)63);
+        float* lse2 = cls_scratch + (((int64_t)2 * B * heads * D.N + 63) & ~(int64_t)63);
+        void* dxsum = lse2 + (((int64_t)B * heads * D.S * F + 63) & ~(int64_t)63);
+        if ((rc = focus_traj_space_bwd_mfma(qkv, xt, lse, dxt, dxdiag, delta, lse2, dxsum, dqkv, B, F, P, heads, s)))
             return rc;
     } else {
         if (hipMemcpyAsync(dxs, dxt, (size_t)B * D.S * F * D.C * es, hipMemcpyDeviceToDevice, s) != hipSuccess)

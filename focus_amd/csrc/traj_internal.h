@@ -4,7 +4,8 @@ bool focus_traj_space_mfma_ok(int P, int d, int heads, int dtype);
 int focus_traj_space_fwd_mfma(const void* qkv, void* xt, void* xdiag, float* lse, int B, int F, int P, int heads,
                               hipStream_t s);
 int focus_traj_space_bwd_mfma(const void* qkv, const void* xt, const float* lse, const void* dxt, const void* dxdiag,
-                              float* delta, void* dqkv, int B, int F, int P, int heads, hipStream_t s);
+                              float* delta, float* lse2, void* dxsum, void* dqkv, int B, int F, int P, int heads,
+                              hipStream_t s);
 // cls row (one query per (b,h) over all N keys); bwd ADDS onto rows 1.. of the k/v parts of dqkv, writes row 0.
 bool focus_traj_cls_ok(int N, int d);
 int focus_traj_cls_fwd(const void* qkv, void* cls_out, float* cls_lse, int B, int N, int heads, int dtype, hipStream_t s);

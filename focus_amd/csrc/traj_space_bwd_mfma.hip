@@ -5,13 +5,16 @@
 //     dV_{f,p} = sum_s P * dX[s,f,:]          dP = dX[s,f,:].v_{f,p}       dL = P * (dP - delta) * scale
 //     dK_{f,p} = sum_s dL * q_s               dQ_s = sum_{f,p} dL * k_{f,p}
 // Three kernels, no atomics, every output written exactly once:
-//   traj_delta_kernel : delta [B,h,S,F]                                   (HBM-bound, reads dx~ and x~ once)
-//   traj_dq_kernel    : workgroup = 128 queries of one (b,h), walks the frames; keys on the accumulator rows
-//                       (swapped products), dL feeds  dQ^T += K^T.dL  straight from the accumulator registers;
-//                       K^T fragments come from the row-major K tile through ds_read_b64_tr_b16.
-//   traj_dkv_kernel   : workgroup = the <=224 keys of one (b,h,frame), one wave per 32 keys, walks all queries;
-//                       queries on the accumulator rows, P and dL feed  dV += P^T.dX,  dK += dL^T.Q  as A operands,
-//                       dX / Q column fragments through ds_read_b64_tr_b16.
+//   traj_delta_kernel : delta [B,h,S,F] and dxsum [B,S,C]                 (HBM-bound, reads dx~ and x~ once)
+//   traj_dq_kernel    : workgroup = 128 queries of one (b,h), walks the (frame, 32-key block) stream; keys on the
+//                       accumulator rows (swapped products), dL feeds  dQ^T += K^T.dL  straight from the accumulator
+//                       registers; K^T fragments come from the row-major K block through ds_read_b64_tr_b16.
+//   traj_dkv_kernel   : workgroup = the <=224 keys of one (b,h,frame), one wave per 32 keys, walks all queries in
+//                       32-query chunks; queries on the accumulator rows, P and dL feed  dV += P^T.dX,  dK += dL^T.Q
+//                       as A operands, dX / Q column fragments through ds_read_b64_tr_b16.
+// Both MFMA kernels stream their tiles through a 4-stage LDS ring filled by LDS-DMA three steps ahead (inline-asm
+// global_load_lds_dwordx4, counted s_waitcnt vmcnt, one raw s_barrier per step): no vector-memory load sits in the
+// loops, so nothing but the DMA itself is on the vmcnt counter and the compiler adds no waits of its own.
 #include "focus_common.h"
 #include "traj_internal.h"
 
@@ -59,12 +62,16 @@ __device__ __forceinline__ bf16x8 pack_acc(const f32x16& a, int s2) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// delta[b,h,s,f] = sum_d (dxt[b,s,f,h,d] + [f == s/P] dxdiag[b,s,h,d]) * xt[b,s,f,h,d]
+// delta[b,h,s,f] = scale * sum_d (dxt[b,s,f,h,d] + [f == s/P] dxdiag[b,s,h,d]) * xt[b,s,f,h,d]
+// lse2[b,h,s,f]  = lse[b,h,s,f] * log2(e)
+// dxsum[b,s,:]   = dxt[b,s,s/P,:] + dxdiag[b,s,:]      (so the kernels below can DMA dX rows without an add)
 // one wave per (b,s); a head's 64 channels sit on 16 adjacent lanes (4 channels per lane)
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void traj_delta_kernel(const bf16_t* __restrict__ dxt, const bf16_t* __restrict__ dxdiag,
-                                                         const bf16_t* __restrict__ xt, float* __restrict__ delta,
-                                                         int64_t rows, int S, int F, int P, int heads) {
+                                                         const bf16_t* __restrict__ xt, const float* __restrict__ lse,
+                                                         float* __restrict__ delta, float* __restrict__ lse2,
+                                                         bf16_t* __restrict__ dxsum, int64_t rows, int S, int F, int P,
+                                                         int heads) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -81,100 +88,158 @@ __global__ __launch_bounds__(256) void traj_delta_kernel(const bf16_t* __restric
             if (act) {
                 f4 g = ld4<bf16_t>(dxt + (row * F + f) * C + c);
                 const f4 x = ld4<bf16_t>(xt + (row * F + f) * C + c);
-                if (f == fs) { g.x += dd.x; g.y += dd.y; g.z += dd.z; g.w += dd.w; }
+                if (f == fs) {
+                    g.x += dd.x; g.y += dd.y; g.z += dd.z; g.w += dd.w;
+                    st4<bf16_t>(dxsum + row * C + c, g);      // dX row of the query's own frame, for the dQ / dKV kernels
+                }
                 p = g.x * x.x + g.y * x.y + g.z * x.z + g.w * x.w;
             }
 #pragma unroll
             for (int o = 8; o > 0; o >>= 1) p += __shfl_xor(p, o, 64);
-            if (act && (lane & 15) == 0) delta[((b * heads + c / HD) * S + s) * F + f] = p;
+            if (act && (lane & 15) == 0) {
+                // pre-scaled for the MFMA kernels: delta * scale, and the forward's lse in base-2 units
+                const int64_t o = ((b * heads + c / HD) * S + s) * F + f;
+                delta[o] = p * 0.125f;                     // scale = 1/sqrt(64)
+                lse2[o] = lse[o] * LOG2E;
+            }
         }
     }
 }
 
+// vmcnt wait with a wave-uniform run-time count (0, 1, 2, ... 8; larger values wait for 8)
+__device__ __forceinline__ void wait_vmcnt(int n) {
+    switch (n) {
+        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+        case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+        case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+        case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+        case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+        case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+        case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+    }
+}
+
+constexpr int MAXF = 16;     // frames the per-wave lse / delta tables are sized for
+
 // ------------------------------------------------------------------------------------------------
-// dQ
+// dQ.  Stream step t = (frame f, key block kb): ring stage t & 3 = [K block 32 x 128 B | V block 32 x 128 B]; wave w
+// DMAs rows 8w..8w+7 of both (2 instructions per step).  The wave's own 32 dX rows of frame f come by DMA into a
+// private 4 KiB tile (4 instructions per frame, issued at kb = 0 of frame f-1 after the fragments of frame f-1 have
+// been read into registers); lse / delta of its queries for all frames sit in LDS tables filled before the loop.
+// Wait counts: an operation has landed once at most (instructions issued after it) remain outstanding.
 // ------------------------------------------------------------------------------------------------
 template <int NKB>
 __global__ __launch_bounds__(256, 2) void traj_dq_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dxt,
-                                                         const bf16_t* __restrict__ dxdiag, const float* __restrict__ lse,
+                                                         const bf16_t* __restrict__ dxsum, const float* __restrict__ lse,
                                                          const float* __restrict__ delta, bf16_t* __restrict__ dqkv,
                                                          int B, int F, int P, int heads) {
-    constexpr int KROWS = NKB * 32;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* sK = smem;                       // [KROWS][64] bf16 row-major, chunk-swizzled
-    char* sV = smem + KROWS * 128;         // same for V
-    char* slabs = smem + 2 * KROWS * 128;  // 4 x [32][128 B]
+    __shared__ __attribute__((aligned(1024))) char ring[4 * 8192];       // after the loop: the 4 output slabs
+    __shared__ __attribute__((aligned(1024))) char sDX[4 * 4096];        // per wave: [32 q][128 B] dX rows, swizzled
+    __shared__ float sLse[4][MAXF * 32];
+    __shared__ float sDel[4][MAXF * 32];
 
     const int S = F * P, N = S + 1, C = heads * HD;
     const int64_t tok = 3 * (int64_t)C;
     const int bh = blockIdx.y, b = bh / heads, hh = bh % heads;
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
     const int s_raw = blockIdx.x * QT + w * 32 + r;
     const bool q_valid = s_raw < S;
-    const int s_q = min(s_raw, S - 1), fs = s_q / P;
+    const int s_q = min(s_raw, S - 1);
     const bf16_t* base = qkv + (int64_t)b * N * tok + hh * HD;
     const float scale = rsqrtf((float)HD), c2 = scale * LOG2E;
+    const int T = F * NKB;
 
-    bf16x8 qf[4];
-    Pack8 dd[4];   // dx_diag row fragments (added to dx~ on the query's own frame)
+    // ---- DMA helpers ----
+    const int drow = lane >> 3, dkey = ((drow & 2) << 1) | ((drow >> 1) & 2), dchunk = lane & 7;
+    const uint32_t ring_a = lds_addr_of(ring), dx_a = lds_addr_of(sDX) + w * 4096;
+    auto dma_step = [&](int t) __attribute__((always_inline)) {          // K and V rows 8w..8w+7 of block (f, kb)
+        const int f = t / NKB, kb = t - f * NKB;
+        const int row = min(kb * 32 + w * 8 + drow, P - 1);              // padded keys: a copy of the last real row
+        const bf16_t* src = base + (int64_t)(1 + f * P + row) * tok + C + ((dchunk ^ (dkey | (w & 1))) << 3);
+        const uint32_t dst = __builtin_amdgcn_readfirstlane(ring_a + (t & 3) * 8192 + w * 1024);
+        glds16(src, dst);
+        glds16(src + C, dst + 4096);
+    };
+    auto dma_dx = [&](int f) __attribute__((always_inline)) {            // this wave's 32 dX rows of frame f
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-        qf[ks] = *reinterpret_cast<const bf16x8*>(base + (int64_t)(1 + s_q) * tok + ks * 16 + 8 * h);
-        dd[ks].u = *reinterpret_cast<const uint4*>(dxdiag + ((int64_t)b * S + s_q) * C + hh * HD + ks * 16 + 8 * h);
+        for (int g = 0; g < 4; ++g) {
+            const int s = min(blockIdx.x * QT + w * 32 + g * 8 + drow, S - 1);
+            const bool own = s >= f * P && s < (f + 1) * P;
+            const bf16_t* rowp = own ? dxsum + ((int64_t)b * S + s) * C : dxt + (((int64_t)b * S + s) * F + f) * C;
+            glds16(rowp + hh * HD + ((dchunk ^ (dkey | (g & 1))) << 3), __builtin_amdgcn_readfirstlane(dx_a + g * 1024));
+        }
+    };
+
+    // ---- prologue: tables, Q fragments, first DMAs ----
+    for (int f2 = h; f2 < F; f2 += 2) {
+        const int64_t sf = (((int64_t)b * heads + hh) * S + s_q) * F + f2;
+        sLse[w][f2 * 32 + r] = q_valid ? lse[sf] : INFINITY;             // (base-2 lse) +inf -> P = 0 for padded queries
+        sDel[w][f2 * 32 + r] = delta[sf];                                // (already times scale)
     }
+    bf16x8 qf[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+        qf[ks] = *reinterpret_cast<const bf16x8*>(base + (int64_t)(1 + s_q) * tok + ks * 16 + 8 * h);
     f32x16 dq[2];
 #pragma unroll
     for (int i = 0; i < 16; ++i) { dq[0][i] = 0.f; dq[1][i] = 0.f; }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // ordinary loads above are done before any DMA is counted
+    // ... and the compiler is told so: without this it keeps the Q loads "pending" into the loop and emits its own
+    // s_waitcnt vmcnt(0) at their first use in EVERY step, draining the DMA ring
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) asm volatile("" : "+v"(qf[ks]));
+    dma_dx(0);
+    dma_step(0);
+    if (T > 1) dma_step(1);
+    if (T > 2) dma_step(2);
 
+    const char* mydx = sDX + w * 4096;
+    bf16x8 df[4];
+    float lse2 = 0.f, dels = 0.f;
+    int t = 0;
     for (int f = 0; f < F; ++f) {
-        __syncthreads();
-        for (int e = tid; e < KROWS * 8; e += 256) {
-            const int p = e >> 3, c = e & 7;
-            uint4 kv = make_uint4(0, 0, 0, 0), vv = kv;
-            if (p < P) {
-                const bf16_t* row = base + (int64_t)(1 + f * P + p) * tok + c * 8;
-                kv = *reinterpret_cast<const uint4*>(row + C);
-                vv = *reinterpret_cast<const uint4*>(row + 2 * C);
-            }
-            *reinterpret_cast<uint4*>(sK + swz(p, c)) = kv;
-            *reinterpret_cast<uint4*>(sV + swz(p, c)) = vv;
-        }
-        // dX fragments of this lane's query for frame f (B operand: [k=d][col=q])
-        bf16x8 df[4];
+        const bool more = f + 1 < F;
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            Pack8 g;
-            g.u = *reinterpret_cast<const uint4*>(dxt + (((int64_t)b * S + s_q) * F + f) * C + hh * HD + ks * 16 + 8 * h);
-            if (f == fs) {
+        for (int kb = 0; kb < NKB; ++kb, ++t) {
+            // ---- step t landed?  instructions issued after it: steps t+1, t+2 (2 each) and, for kb = 1..3, the
+            // 4 dX instructions of frame f+1 issued at kb = 0 ----
+            const int ahead = 2 * min(2, T - 1 - t);
+            if (kb == 0) wait_vmcnt(NKB >= 4 ? ahead : 0);
+            else wait_vmcnt(ahead + ((kb <= 3 && more) ? 4 : 0));
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();          // step t visible to all; everyone is done with stage (t-1) & 3
+            if (kb == 0) {
+                // this frame's dX fragments (B operand: [k=d][col=q]) and softmax statistics
 #pragma unroll
-                for (int j = 0; j < 8; ++j) g.e[j] = f32_to_bf16(bf16_to_f32(g.e[j]) + bf16_to_f32(dd[ks].e[j]));
+                for (int ks = 0; ks < 4; ++ks) df[ks] = *reinterpret_cast<const bf16x8*>(mydx + swz(r, ks * 2 + h));
+                lse2 = sLse[w][f * 32 + r];
+                dels = sDel[w][f * 32 + r];
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // the dX tile is free for frame f+1
             }
-            df[ks] = g.v;
-        }
-        const int64_t sf = (((int64_t)b * heads + hh) * S + s_q) * F + f;
-        const float lse2 = q_valid ? lse[sf] * LOG2E : INFINITY;
-        const float del = delta[sf];
-        __syncthreads();
+            if (t + 3 < T) dma_step(t + 3);
+            if (kb == 0 && more) dma_dx(f + 1);
 
-#pragma unroll
-        for (int kb = 0; kb < NKB; ++kb) {
+            const char* sK = ring + (t & 3) * 8192;
+            const char* sV = sK + 4096;
             f32x16 sa, dp;
 #pragma unroll
             for (int i = 0; i < 16; ++i) { sa[i] = 0.f; dp[i] = 0.f; }
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
-                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(sK + swz(kb * 32 + r, ks * 2 + h));
-                const bf16x8 vf = *reinterpret_cast<const bf16x8*>(sV + swz(kb * 32 + r, ks * 2 + h));
+                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(sK + swz(r, ks * 2 + h));
+                const bf16x8 vf = *reinterpret_cast<const bf16x8*>(sV + swz(r, ks * 2 + h));
                 sa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], sa, 0, 0, 0);
                 dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, df[ks], dp, 0, 0, 0);
             }
-            // padded keys need no mask here: their K rows are staged as zeros, so whatever dL they get is multiplied
-            // by K^T = 0 in the dQ product (and exp2(0 - lse2) is finite)
-            const float dels = del * scale;
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
-                const float pr = __builtin_amdgcn_exp2f(fmaf(sa[i], c2, -lse2));
+                float pr = __builtin_amdgcn_exp2f(fmaf(sa[i], c2, -lse2));
+                if (kb == NKB - 1) {               // padded keys hold a copy of the last real key: drop them
+                    if ((i & 3) + 8 * (i >> 2) >= P - kb * 32 - 4 * h) pr = 0.f;
+                }
                 sa[i] = pr * fmaf(dp[i], scale, -dels);   // dL[key][q] = P * (dP - delta) * scale
             }
 #pragma unroll
@@ -182,15 +247,16 @@ __global__ __launch_bounds__(256, 2) void traj_dq_kernel(const bf16_t* __restric
                 const bf16x8 lf = pack_acc(sa, s2);
 #pragma unroll
                 for (int dblk = 0; dblk < 2; ++dblk) {
-                    const bf16x8 kt = col_frag(sK, kb * 32 + 16 * s2 + 4 * h, dblk * 32, lane);   // K^T[d][key]
+                    const bf16x8 kt = col_frag(sK, 16 * s2 + 4 * h, dblk * 32, lane);   // K^T[d][key]
                     dq[dblk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kt, lf, dq[dblk], 0, 0, 0);
                 }
             }
         }
     }
-    // dQ^T[d][q] -> rows of dqkv through the wave's LDS slab (same scheme as the forward)
-    __syncthreads();
-    char* slab = slabs + w * 4096;
+    // dQ^T[d][q] -> rows of dqkv through the wave's LDS slab (same scheme as the forward); the ring is free now
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    char* slab = ring + w * 4096;
 #pragma unroll
     for (int dblk = 0; dblk < 2; ++dblk)
 #pragma unroll
@@ -213,25 +279,22 @@ __global__ __launch_bounds__(256, 2) void traj_dq_kernel(const bf16_t* __restric
 }
 
 // ------------------------------------------------------------------------------------------------
-// dK, dV
+// dK, dV.  Stream step = one chunk of 32 queries: ring stage = [Q rows 4 KiB | dX rows 4 KiB | lse[32] del[32]];
+// 9 DMA instructions per step (4 + 4 of 1 KiB, one of 256 B), dealt round-robin to the NKB waves.
 // ------------------------------------------------------------------------------------------------
 constexpr int QC = 32;   // queries per chunk
 
 template <int NKB>
 __global__ __launch_bounds__(64 * NKB) void traj_dkv_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dxt,
-                                                            const bf16_t* __restrict__ dxdiag,
+                                                            const bf16_t* __restrict__ dxsum,
                                                             const float* __restrict__ lse, const float* __restrict__ delta,
                                                             bf16_t* __restrict__ dqkv, int B, int F, int P, int heads) {
-    constexpr int NT = 64 * NKB;
-    __shared__ __attribute__((aligned(16))) char sQ[2][QC * 128];
-    __shared__ __attribute__((aligned(16))) char sD[2][QC * 128];
-    __shared__ __attribute__((aligned(16))) float sLse[2][QC];
-    __shared__ __attribute__((aligned(16))) float sDel[2][QC];
+    __shared__ __attribute__((aligned(1024))) char ring[4 * 8192 + 4 * 256];   // 4 x (Q | dX), then 4 x (lse | del)
 
     const int S = F * P, N = S + 1, C = heads * HD;
     const int64_t tok = 3 * (int64_t)C;
     const int f = blockIdx.x, bh = blockIdx.y, b = bh / heads, hh = bh % heads;
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
     const bf16_t* base = qkv + (int64_t)b * N * tok + hh * HD;
     const float scale = rsqrtf((float)HD), c2 = scale * LOG2E;
@@ -254,43 +317,49 @@ __global__ __launch_bounds__(64 * NKB) void traj_dkv_kernel(const bf16_t* __rest
     f32x16 dk[2], dv[2];
 #pragma unroll
     for (int i = 0; i < 16; ++i) { dk[0][i] = 0.f; dk[1][i] = 0.f; dv[0][i] = 0.f; dv[1][i] = 0.f; }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // ordinary loads done before any DMA is counted
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) { asm volatile("" : "+v"(kf[ks])); asm volatile("" : "+v"(vf[ks])); }   // (see dq)
 
     const int nchunk = (S + QC - 1) / QC;
-    auto stage = [&](int buf, int chunk) __attribute__((always_inline)) {
-        for (int e = tid; e < 2 * QC * 8; e += NT) {
-            const int which = e / (QC * 8), idx = e % (QC * 8), row = idx >> 3, c = idx & 7;
-            const int s = chunk * QC + row;
-            Pack8 v; v.u = make_uint4(0, 0, 0, 0);
-            if (s < S) {
-                if (which == 0) {
-                    v.u = *reinterpret_cast<const uint4*>(base + (int64_t)(1 + s) * tok + c * 8);
-                } else {
-                    v.u = *reinterpret_cast<const uint4*>(dxt + (((int64_t)b * S + s) * F + f) * C + hh * HD + c * 8);
-                    if (s / P == f) {
-                        Pack8 d2;
-                        d2.u = *reinterpret_cast<const uint4*>(dxdiag + ((int64_t)b * S + s) * C + hh * HD + c * 8);
+    const int drow = lane >> 3, dkey = ((drow & 2) << 1) | ((drow >> 1) & 2), dchunk = lane & 7;
+    const uint32_t ring_a = lds_addr_of(ring);
+    constexpr int MINE = (9 + NKB - 1) / NKB;              // upper bound of DMA instructions per wave per step
+    const int mine = (9 - w + NKB - 1) / NKB;              // this wave's count: instructions w, w+NKB, ... < 9
+    auto dma_chunk = [&](int ch) __attribute__((always_inline)) {
+        const uint32_t st = ring_a + (ch & 3) * 8192;
 #pragma unroll
-                        for (int j = 0; j < 8; ++j) v.e[j] = f32_to_bf16(bf16_to_f32(v.e[j]) + bf16_to_f32(d2.e[j]));
-                    }
-                }
+        for (int j = 0; j < MINE; ++j) {
+            const int i = w + j * NKB;                     // wave-uniform instruction index 0..8
+            if (i < 8) {
+                const int g = i & 3;                       // 8-row group of the Q (i < 4) or dX (i >= 4) tile
+                const int s = min(ch * QC + g * 8 + drow, S - 1);
+                const int cofs = (dchunk ^ (dkey | (g & 1))) << 3;
+                const bf16_t* src;
+                if (i < 4) src = base + (int64_t)(1 + s) * tok + cofs;
+                else src = ((s >= f * P && s < (f + 1) * P) ? dxsum + ((int64_t)b * S + s) * C
+                                                            : dxt + (((int64_t)b * S + s) * F + f) * C) + hh * HD + cofs;
+                glds16(src, __builtin_amdgcn_readfirstlane(st + i * 1024));
+            } else if (i == 8) {
+                // lanes 0-31: lse of the chunk's queries, lanes 32-63: delta (4 B per lane, 256-B piece)
+                const int s = min(ch * QC + r, S - 1);
+                const float* src = (h ? delta : lse) + (((int64_t)b * heads + hh) * S + s) * F + f;   // lse: base-2 copy
+                glds4(src, __builtin_amdgcn_readfirstlane(ring_a + 4 * 8192 + (ch & 3) * 256));
             }
-            *reinterpret_cast<uint4*>((which == 0 ? sQ[buf] : sD[buf]) + swz(row, c)) = v.u;
-        }
-        for (int e = tid; e < QC; e += NT) {
-            const int s = chunk * QC + e;
-            const int64_t sf = (((int64_t)b * heads + hh) * S + min(s, S - 1)) * F + f;
-            sLse[buf][e] = s < S ? lse[sf] * LOG2E : INFINITY;      // +inf -> P = 0 for padded queries
-            sDel[buf][e] = s < S ? delta[sf] : 0.f;
         }
     };
+    dma_chunk(0);
+    if (nchunk > 1) dma_chunk(1);
+    if (nchunk > 2) dma_chunk(2);
 
-    stage(0, 0);
-    __syncthreads();
     for (int ch = 0; ch < nchunk; ++ch) {
-        const int buf = ch & 1;
-        if (ch + 1 < nchunk) stage(buf ^ 1, ch + 1);
-        const char* tq = sQ[buf];
-        const char* td = sD[buf];
+        wait_vmcnt(mine * min(2, nchunk - 1 - ch));
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();              // chunk ch visible to all; everyone is done with stage (ch-1) & 3
+        if (ch + 3 < nchunk) dma_chunk(ch + 3);
+        const char* tq = ring + (ch & 3) * 8192;
+        const char* td = tq + 4096;
+        const float* sl = reinterpret_cast<const float*>(ring + 4 * 8192 + (ch & 3) * 256);
         // S'[q][key] and dP'[q][key]: queries on the accumulator rows, this wave's keys on the lanes
         f32x16 sa, dp;
 #pragma unroll
@@ -302,19 +371,28 @@ __global__ __launch_bounds__(64 * NKB) void traj_dkv_kernel(const bf16_t* __rest
             sa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa, kf[ks], sa, 0, 0, 0);
             dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da, vf[ks], dp, 0, 0, 0);
         }
-        // rows of the tile: q = (i&3) + 8*(i>>2) + 4*h  -> 4 consecutive floats per group of 4 registers
+        // rows of the tile: q = (i&3) + 8*(i>>2) + 4*h  -> 4 consecutive floats per group of 4 registers.
+        // lse arrives in base-2 units and delta times scale (traj_delta_kernel).  Keys past P need no mask: they only
+        // reach accumulator rows that are never stored.
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            const float4 l4 = *reinterpret_cast<const float4*>(&sLse[buf][8 * g + 4 * h]);
-            const float4 d4 = *reinterpret_cast<const float4*>(&sDel[buf][8 * g + 4 * h]);
+            const float4 l4 = *reinterpret_cast<const float4*>(sl + 8 * g + 4 * h);
+            const float4 d4 = *reinterpret_cast<const float4*>(sl + 32 + 8 * g + 4 * h);
             const float ls[4] = {l4.x, l4.y, l4.z, l4.w}, de[4] = {d4.x, d4.y, d4.z, d4.w};
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int i = 4 * g + e;
-                const float pr = key_ok ? __builtin_amdgcn_exp2f(fmaf(sa[i], c2, -ls[e])) : 0.f;
-                sa[i] = pr;                                   // P[q][key]
-                dp[i] = pr * fmaf(dp[i], scale, -de[e] * scale);   // dL[q][key]
+                const float pr = __builtin_amdgcn_exp2f(fmaf(sa[i], c2, -ls[e]));
+                sa[i] = pr;                                        // P[q][key]
+                dp[i] = pr * fmaf(dp[i], scale, -de[e]);           // dL[q][key]
             }
+        }
+        if (ch == nchunk - 1 && (S & (QC - 1))) {
+            // queries past S (rows that are copies of row S-1) must not reach dK / dV
+            const int qlim = S - ch * QC - 4 * h;
+#pragma unroll
+            for (int i = 0; i < 16; ++i)
+                if ((i & 3) + 8 * (i >> 2) >= qlim) { sa[i] = 0.f; dp[i] = 0.f; }
         }
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
@@ -327,7 +405,6 @@ __global__ __launch_bounds__(64 * NKB) void traj_dkv_kernel(const bf16_t* __rest
                 dk[dblk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lf, qc, dk[dblk], 0, 0, 0);
             }
         }
-        __syncthreads();
     }
     // dK[key][d], dV[key][d]: accumulator row = key (in-block), column (lane) = d
 #pragma unroll
@@ -344,20 +421,14 @@ __global__ __launch_bounds__(64 * NKB) void traj_dkv_kernel(const bf16_t* __rest
 }
 
 template <int NKB>
-int launch_bwd(const void* qkv, const void* dxt, const void* dxdiag, const float* lse, const float* delta, void* dqkv,
+int launch_bwd(const void* qkv, const void* dxt, const void* dxsum, const float* lse, const float* delta, void* dqkv,
                int B, int F, int P, int heads, hipStream_t s) {
     const int S = F * P;
-    {
-        const size_t lds = (size_t)2 * NKB * 32 * 128 + 4 * 4096;
-        auto k = traj_dq_kernel<NKB>;
-        static bool once = (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds) == hipSuccess);
-        (void)once;
-        hipLaunchKernelGGL(k, dim3((S + QT - 1) / QT, B * heads), dim3(256), lds, s, (const bf16_t*)qkv, (const bf16_t*)dxt,
-                           (const bf16_t*)dxdiag, lse, delta, (bf16_t*)dqkv, B, F, P, heads);
-        FOCUS_CHECK_LAUNCH();
-    }
+    hipLaunchKernelGGL((traj_dq_kernel<NKB>), dim3((S + QT - 1) / QT, B * heads), dim3(256), 0, s, (const bf16_t*)qkv,
+                       (const bf16_t*)dxt, (const bf16_t*)dxsum, lse, delta, (bf16_t*)dqkv, B, F, P, heads);
+    FOCUS_CHECK_LAUNCH();
     hipLaunchKernelGGL((traj_dkv_kernel<NKB>), dim3(F, B * heads), dim3(64 * NKB), 0, s, (const bf16_t*)qkv,
-                       (const bf16_t*)dxt, (const bf16_t*)dxdiag, lse, delta, (bf16_t*)dqkv, B, F, P, heads);
+                       (const bf16_t*)dxt, (const bf16_t*)dxsum, lse, delta, (bf16_t*)dqkv, B, F, P, heads);
     FOCUS_CHECK_LAUNCH();
     return FOCUS_OK;
 }
@@ -365,23 +436,24 @@ int launch_bwd(const void* qkv, const void* dxt, const void* dxdiag, const float
 }  // namespace
 
 // Patch-token rows of dqkv (q, k and v parts of tokens 1..N-1) are fully written; the cls row/parts are the caller's.
-// delta: [B,h,S,F] fp32 scratch.
+// delta, lse2: [B,h,S,F] fp32 scratch each; dxsum: [B,S,C] bf16 scratch.
 int focus_traj_space_bwd_mfma(const void* qkv, const void* xt, const float* lse, const void* dxt, const void* dxdiag,
-                              float* delta, void* dqkv, int B, int F, int P, int heads, hipStream_t s) {
-    if (B * heads > 65535) return FOCUS_ERR_SHAPE;
+                              float* delta, float* lse2, void* dxsum, void* dqkv, int B, int F, int P, int heads,
+                              hipStream_t s) {
+    if (B * heads > 65535 || F > MAXF) return FOCUS_ERR_SHAPE;
     const int S = F * P;
     const int64_t rows = (int64_t)B * S;
     hipLaunchKernelGGL(traj_delta_kernel, dim3((unsigned)cdiv64(rows, 4)), dim3(256), 0, s, (const bf16_t*)dxt,
-                       (const bf16_t*)dxdiag, (const bf16_t*)xt, delta, rows, S, F, P, heads);
+                       (const bf16_t*)dxdiag, (const bf16_t*)xt, lse, delta, lse2, (bf16_t*)dxsum, rows, S, F, P, heads);
     FOCUS_CHECK_LAUNCH();
-    switch ((P + 31) / 32) {
-        case 1: return launch_bwd<1>(qkv, dxt, dxdiag, lse, delta, dqkv, B, F, P, heads, s);
-        case 2: return launch_bwd<2>(qkv, dxt, dxdiag, lse, delta, dqkv, B, F, P, heads, s);
-        case 3: return launch_bwd<3>(qkv, dxt, dxdiag, lse, delta, dqkv, B, F, P, heads, s);
-        case 4: return launch_bwd<4>(qkv, dxt, dxdiag, lse, delta, dqkv, B, F, P, heads, s);
-        case 5: return launch_bwd<5>(qkv, dxt, dxdiag, lse, delta, dqkv, B, F, P, heads, s);
-        case 6: return launch_bwd<6>(qkv, dxt, dxdiag, lse, delta, dqkv, B, F, P, heads, s);
+    switch ((P + 31) / 32) {     // exact block count: the kernels rely on NKB == ceil(P/32)
+        case 1: return launch_bwd<1>(qkv, dxt, dxsum, lse2, delta, dqkv, B, F, P, heads, s);
+        case 2: return launch_bwd<2>(qkv, dxt, dxsum, lse2, delta, dqkv, B, F, P, heads, s);
+        case 3: return launch_bwd<3>(qkv, dxt, dxsum, lse2, delta, dqkv, B, F, P, heads, s);
+        case 4: return launch_bwd<4>(qkv, dxt, dxsum, lse2, delta, dqkv, B, F, P, heads, s);
+        case 5: return launch_bwd<5>(qkv, dxt, dxsum, lse2, delta, dqkv, B, F, P, heads, s);
+        case 6: return launch_bwd<6>(qkv, dxt, dxsum, lse2, delta, dqkv, B, F, P, heads, s);
         default: break;
     }
-    return launch_bwd<7>(qkv, dxt, dxdiag, lse, delta, dqkv, B, F, P, heads, s);
+    return launch_bwd<7>(qkv, dxt, dxsum, lse2, delta, dqkv, B, F, P, heads, s);
 }

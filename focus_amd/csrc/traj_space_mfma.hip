@@ -95,6 +95,9 @@ __global__ __launch_bounds__(256, 2) void traj_space_fwd_kernel(const bf16_t* __
             glds16(src, __builtin_amdgcn_readfirstlane(lds_addr_of(tile) + t * 1024));
         }
     };
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) asm volatile("" : "+v"(qf[ks]));   // Q loads retired in the compiler's bookkeeping too
     dma_tile(sK, 0, 1);
     dma_tile(sV, 0, 2);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
