@@ -17,4 +17,4 @@ int focus_gemm_mfma_ws(const focus_gemm_desc& d, hipStream_t s);
 // wave-specialised TN kernel (8 consumer + 4 loader waves); the plan also sizes the slab workspace
 struct focus_tn_plan { int kind, tiles_i, tiles_j, splits, m_per_split; };
 focus_tn_plan focus_gemm_tn_ws_plan(int M, int N, int K);
-int focus_gemm_mfma_tn_ws(const focus_gemm_desc& d, const focus_tn_plan& pl, hipStream_t s);
+int focus_gemm_mfma_tn_ws(const focus_gemm_desc& d, const focus_tn_plan& pl, float* csum, hipStream_t s);

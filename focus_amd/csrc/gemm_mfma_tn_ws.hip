@@ -50,7 +50,7 @@ struct Unit { int i0, j0, m_begin, nk, valid_last; };
 
 template <int BI, int BJ>
 __global__ __launch_bounds__(64 * (BI * BJ / 4096 + NLOAD)) void gemm_tn_ws_kernel(const focus_gemm_desc d, int tiles_i, int tiles_j,
-                                                                                  int splits, int m_per_split) {
+                                                                                  int splits, int m_per_split, float* csum) {
     constexpr int NCONS = BI * BJ / 4096;
     constexpr int WJ = BJ / 64;
     constexpr int NSP = BI / 128, NSQ = BJ / 128, NSUBT = NSP + NSQ;       // sub-tiles per stage
@@ -140,9 +140,17 @@ __global__ __launch_bounds__(64 * (BI * BJ / 4096 + NLOAD)) void gemm_tn_ws_kern
     const int poff = (wi >> 1) * SUB, pcol = (wi & 1) * 64;
     const int qoff = (NSP + (wj >> 1)) * SUB, qcol = (wj & 1) * 64;
     f32x4 acc[4][4];
+    // Optional column sums of P (bias gradient: db[i] = sum_m dY[m,i]) on the matrix pipe: D = ones^T . P gives
+    // sum_k P[k][i] in every row.  The work is dealt over the units of a row of tiles (unit tile_j takes the K-steps
+    // kt = tile_j mod tiles_j) and over the WJ waves that share the same P fragments, so it costs each unit about
+    // 1/(4*tiles_j) extra MFMAs; partial sums go to csum[split*tiles_j + tile_j][M] (summed by tn_reduce).
+    constexpr int NA = 4 / WJ;
+    f32x4 accb[NA];
+    Frag ones;
+    ones.u[0] = ones.u[1] = ones.u[2] = ones.u[3] = 0x3F803F80u;
     // valid < BKM only on the last K-step of a unit that ends at the end of the reduction: rows past it were DMA'd
     // from a clamped address, so their P elements are zeroed in the fragment (element e <-> row ks*32 + 8*fq + e)
-    auto compute = [&](const char* stage, auto masked, int valid) __attribute__((always_inline)) {
+    auto compute = [&](const char* stage, auto masked, int valid, bool cs) __attribute__((always_inline)) {
         const char* sp = stage + poff;
         const char* sq = stage + qoff;
 #pragma unroll
@@ -170,6 +178,16 @@ __global__ __launch_bounds__(64 * (BI * BJ / 4096 + NLOAD)) void gemm_tn_ws_kern
 #pragma unroll
                 for (int b = 0; b < 4; ++b)
                     acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fqv[b], fp[a], acc[a][b], 0, 0, 0);
+            if (cs) {                                   // wave-uniform; touches accb only (acc stays branch-free)
+#pragma unroll
+                for (int n = 0; n < NA; ++n) {
+                    bf16x8 sel = fp[n];
+#pragma unroll
+                    for (int j = 1; j < WJ; ++j)
+                        if (wj == j) sel = fp[j * NA + n];
+                    accb[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones.v, sel, accb[n], 0, 0, 0);
+                }
+            }
         }
     };
 
@@ -183,17 +201,29 @@ __global__ __launch_bounds__(64 * (BI * BJ / 4096 + NLOAD)) void gemm_tn_ws_kern
             for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
         // straight-line structure (no branch between compute variants inside the loop: a branch there makes the
         // compiler keep two copies of the accumulators): nk-1 plain steps, then the last step always masked
+        const int tj = cur.j0 / BJ;
+        int cs_in = tj;                                    // steps until this unit's next column-sum K-step
+#pragma unroll
+        for (int n = 0; n < NA; ++n) accb[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
         for (int kt = 0; kt + 1 < cur.nk; ++kt) {
-            compute(smem + st * STAGE, std::false_type{}, BKM);
+            compute(smem + st * STAGE, std::false_type{}, BKM, csum != nullptr && cs_in == 0);
+            cs_in = cs_in == 0 ? tiles_j - 1 : cs_in - 1;
             st = st == 2 ? 0 : st + 1;
             __builtin_amdgcn_s_barrier();                  // end of this K-step
         }
-        compute(smem + st * STAGE, std::true_type{}, cur.valid_last);
+        compute(smem + st * STAGE, std::true_type{}, cur.valid_last, csum != nullptr && cs_in == 0);
         st = st == 2 ? 0 : st + 1;
         __builtin_amdgcn_s_barrier();
         // acc[a][b][r4] = D[j = j0 + wj*64 + b*16 + fq*4 + r4][i = i0 + wi*64 + a*16 + fr]; stores straight from the
         // registers (no LDS), so the loaders keep filling the ring for the next unit meanwhile
         const int split = cur.m_begin / m_per_split;
+        if (csum && fq == 0) {
+#pragma unroll
+            for (int n = 0; n < NA; ++n) {
+                const int gi = cur.i0 + wi * 64 + (wj * NA + n) * 16 + fr;
+                if (gi < d.M) csum[(int64_t)(split * tiles_j + tj) * d.M + gi] = d.alpha * accb[n][0];
+            }
+        }
         float* C = d.aux ? static_cast<float*>(d.aux) + (int64_t)split * d.M * d.N : static_cast<float*>(d.C);
         const int64_t ldc = d.aux ? d.N : d.rsC;
 #pragma unroll
@@ -218,14 +248,14 @@ __global__ __launch_bounds__(64 * (BI * BJ / 4096 + NLOAD)) void gemm_tn_ws_kern
 }
 
 template <int BI, int BJ>
-int launch_tn_ws(const focus_gemm_desc& d, const focus_tn_plan& pl, hipStream_t s) {
+int launch_tn_ws(const focus_gemm_desc& d, const focus_tn_plan& pl, float* csum, hipStream_t s) {
     const size_t lds = (size_t)NSTAGE * (BI / 128 + BJ / 128) * SUB;
     auto k = gemm_tn_ws_kernel<BI, BJ>;
     static bool once = (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds) == hipSuccess);
     (void)once;
     const int nunits = pl.tiles_i * pl.tiles_j * pl.splits;
     hipLaunchKernelGGL(k, dim3(std::min(nunits, 256)), dim3(64 * (BI * BJ / 4096 + NLOAD)), lds, s, d, pl.tiles_i, pl.tiles_j,
-                       pl.splits, pl.m_per_split);
+                       pl.splits, pl.m_per_split, csum);
     FOCUS_CHECK_LAUNCH();
     return FOCUS_OK;
 }
@@ -257,8 +287,9 @@ focus_tn_plan focus_gemm_tn_ws_plan(int M, int N, int K) {
     return p;
 }
 
-int focus_gemm_mfma_tn_ws(const focus_gemm_desc& d, const focus_tn_plan& pl, hipStream_t s) {
-    if (pl.kind == 1) return launch_tn_ws<256, 128>(d, pl, s);
-    if (pl.kind == 2) return launch_tn_ws<128, 256>(d, pl, s);
+// csum: NULL, or [splits * tiles_j][M] fp32 partial column sums of the A operand (see the kernel)
+int focus_gemm_mfma_tn_ws(const focus_gemm_desc& d, const focus_tn_plan& pl, float* csum, hipStream_t s) {
+    if (pl.kind == 1) return launch_tn_ws<256, 128>(d, pl, csum, s);
+    if (pl.kind == 2) return launch_tn_ws<128, 256>(d, pl, csum, s);
     return FOCUS_ERR_SHAPE;
 }

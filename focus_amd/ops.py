@@ -148,6 +148,31 @@ def mm_tn(a, b):
     return c
 
 
+def linear_wgrad(dy, x, want_bias):
+    """(dw [N,K] fp32, db [N] fp32 or None) for y = x @ w^T + b from dy [M,N], x [M,K]: one pass over dy
+    (focus_linear_wgrad: the bias gradient rides on the weight-gradient GEMM's matrix pipe)."""
+    M, N = dy.shape
+    K = x.shape[1]
+    ok = (dy.dtype == torch.bfloat16 and USE_TN_GEMM and N % 8 == 0 and K % 8 == 0 and N >= 8 and K >= 8
+          and dy.stride(1) == 1 and x.stride(1) == 1 and dy.stride(0) % 8 == 0 and x.stride(0) % 8 == 0)
+    if not ok:
+        return mm_tn(dy, x), (colsum(dy) if want_bias else None)
+    L = _lib.lib()
+    dw = torch.empty(N, K, device=dy.device, dtype=torch.float32)
+    db = torch.empty(N, device=dy.device, dtype=torch.float32) if want_bias else None
+    nb = L.focus_linear_wgrad_workspace_bytes(N, K, M)
+    ws = torch.empty(max(nb, 16) // 4, device=dy.device, dtype=torch.float32)
+    if GEMM_TIMING is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    _lib.check(L.focus_linear_wgrad(_p(dy), _p(x), _p(dw), _p(db) if want_bias else None, _p(ws), nb, M, N, K,
+                                    dy.stride(0), x.stride(0), _dt(dy), _stream()), "linear_wgrad")
+    if GEMM_TIMING is not None:
+        e1.record()
+        GEMM_TIMING.append((2.0 * M * N * K, e0, e1, "tn", (N, K, M, 1, 0)))
+    return dw, db
+
+
 def colsum(x):
     M, N = x.shape
     out = torch.empty(N, device=x.device, dtype=torch.float32)
@@ -231,9 +256,10 @@ class _LinearFn(torch.autograd.Function):
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             dx = _dx_from(dy2, w, dy2.dtype).reshape(ctx.shp)
+        want_b = ctx.has_b and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
-            dw = mm_tn(dy2, x2)
-        if ctx.has_b and ctx.needs_input_grad[2]:
+            dw, db = linear_wgrad(dy2, x2, want_b)
+        elif want_b:
             db = colsum(dy2)
         return dx, dw, db, (dy if ctx.has_r else None)
 
@@ -268,12 +294,16 @@ class _MlpFn(torch.autograd.Function):
         dy2 = dy.reshape(-1, w2.shape[0])
         if not dy2.is_contiguous():
             dy2 = dy2.contiguous()
-        dw2 = mm_tn(dy2, a) if ctx.needs_input_grad[3] else None
-        db2 = colsum(dy2) if ctx.has[1] else None
+        if ctx.needs_input_grad[3]:
+            dw2, db2 = linear_wgrad(dy2, a, ctx.has[1])
+        else:
+            dw2, db2 = None, (colsum(dy2) if ctx.has[1] else None)
         # dz = (dy . w2) * act'(.) fused in the GEMM epilogue
         dz = _dx_from(dy2, w2, dy2.dtype, aux=(z if ctx.act == EPI_GELU else a), epilogue=_DEPI[ctx.act])
-        dw1 = mm_tn(dz, x2) if ctx.needs_input_grad[1] else None
-        db1 = colsum(dz) if ctx.has[0] else None
+        if ctx.needs_input_grad[1]:
+            dw1, db1 = linear_wgrad(dz, x2, ctx.has[0])
+        else:
+            dw1, db1 = None, (colsum(dz) if ctx.has[0] else None)
         dx = _dx_from(dz, w1, dz.dtype).reshape(ctx.shp) if ctx.needs_input_grad[0] else None
         return dx, dw1, db1, dw2, db2, (dy if ctx.has[2] else None), None
 

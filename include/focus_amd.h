@@ -85,6 +85,15 @@ int focus_gemm(const focus_gemm_desc* desc, void* stream);
  * overwritten). */
 size_t focus_gemm_tn_workspace_bytes(int M, int N, int K);
 
+/* nn.Linear backward w.r.t. its parameters in one pass over dy (replaces autograd's dy^T @ x and dy.sum(0) of
+ * common.py:26-34 / attention.py:506,536-537,555):  dw[N,K] = dy[M,N]^T . x[M,K],  db[N] = sum_m dy[m,:]  (db may be
+ * NULL).  bf16 operands, fp32 results, both overwritten.  The column sums ride on the matrix pipe of the
+ * weight-gradient kernel (ones^T . dy) when the wave-specialised kernel takes the shape; otherwise focus_colsum runs.
+ * ws: focus_linear_wgrad_workspace_bytes(N, K, M) bytes.  N % 8 == 0, K % 8 == 0, 16-byte aligned rows. */
+size_t focus_linear_wgrad_workspace_bytes(int N, int K, int M);
+int focus_linear_wgrad(const void* dy, const void* x, float* dw, float* db, void* ws, size_t ws_bytes, int M, int N,
+                       int K, int64_t ld_dy, int64_t ld_x, int dtype, void* stream);
+
 /* y[M,N] = act(x[M,K] . w[N,K]^T + bias) + residual -- nn.Linear forward (thin wrapper over focus_gemm). */
 int focus_linear_fwd(const void* x, const void* w, const float* bias, const void* residual, void* y,
                      void* aux, int M, int N, int K, int epilogue, int dtype, void* stream);

@@ -563,3 +563,9 @@ def test_weight_grad_gemm_ws(shape):
     want = (dy.double().t() @ x.double()).float()
     assert got.shape == (N, K) and got.dtype == torch.float32
     assert rel(got, want) < 1e-5
+    # the same product with the bias gradient (column sums of dY) riding on the matrix pipe
+    dw, db = ops.linear_wgrad(dy, x, True)
+    assert rel(dw, want) < 1e-5
+    assert db.shape == (N,) and rel(db, dy.double().sum(0).float()) < 1e-5
+    dw2, db2 = ops.linear_wgrad(dy, x, False)
+    assert db2 is None and rel(dw2, want) < 1e-5
