@@ -36,7 +36,7 @@ def parse_header(path=HEADER):
     """-> {name: (restype, [argtypes])} for every function declared in the public header."""
     src = open(path).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    src = re.sub(r"typedef struct focus_gemm_desc \{.*?\} focus_gemm_desc;", "", src, flags=re.S)
+    src = re.sub(r"typedef struct \w+ \{.*?\} \w+;", "", src, flags=re.S)
     src = re.sub(r"enum \w+ \{.*?\};", "", src, flags=re.S)
     out = {}
     for m in re.finditer(r"([\w\s\*]+?)\b(focus_\w+)\s*\(([^;{]*?)\)\s*;", src):

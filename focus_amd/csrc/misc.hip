@@ -281,6 +281,52 @@ extern "C" int focus_colsum(const void* x, float* out, int M, int N, int64_t row
     return FOCUS_OK;
 }
 
+// one 64x64 tile of one tensor per block: fp32 in, bf16 row-major out and bf16 transposed out through LDS
+__global__ __launch_bounds__(256) void shadow_refresh_kernel(const focus_shadow_item* __restrict__ items) {
+    __shared__ bf16_t tile[64][68];
+    const focus_shadow_item it = items[blockIdx.y];
+    const int tiles_c = (it.cols + 63) >> 6, tiles_r = (it.rows + 63) >> 6;
+    if ((int)blockIdx.x >= tiles_r * tiles_c) return;
+    const int tr = blockIdx.x / tiles_c, tc = blockIdx.x - tr * tiles_c;
+    const int t = threadIdx.x, lr = t >> 4, lc = (t & 15) * 4;
+    bf16_t* dst = static_cast<bf16_t*>(it.dst);
+    bf16_t* dstT = static_cast<bf16_t*>(it.dstT);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int r = tr * 64 + lr + 16 * k, c = tc * 64 + lc;
+        uint2 o = make_uint2(0, 0);
+        if (r < it.rows && c < it.cols) {
+            const float4 v = *reinterpret_cast<const float4*>(it.src + (int64_t)r * it.cols + c);
+            o.x = (uint32_t)f32_to_bf16(v.x) | ((uint32_t)f32_to_bf16(v.y) << 16);
+            o.y = (uint32_t)f32_to_bf16(v.z) | ((uint32_t)f32_to_bf16(v.w) << 16);
+            if (dst) *reinterpret_cast<uint2*>(dst + (int64_t)r * it.cols + c) = o;
+        }
+        *reinterpret_cast<uint2*>(&tile[lr + 16 * k][lc]) = o;
+    }
+    if (!dstT) return;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int oc = tc * 64 + lr + 16 * k, orr = tr * 64 + lc;      // output row = source column
+        if (oc < it.cols && orr < it.rows) {
+            uint2 o;
+            o.x = (uint32_t)tile[lc + 0][lr + 16 * k] | ((uint32_t)tile[lc + 1][lr + 16 * k] << 16);
+            o.y = (uint32_t)tile[lc + 2][lr + 16 * k] | ((uint32_t)tile[lc + 3][lr + 16 * k] << 16);
+            *reinterpret_cast<uint2*>(dstT + (int64_t)oc * it.rows + orr) = o;
+        }
+    }
+}
+
+extern "C" int focus_shadow_refresh(const focus_shadow_item* items, int n_items, int max_rows, int max_cols, void* stream) {
+    if (!items) return FOCUS_ERR_NULL;
+    if (n_items <= 0) return FOCUS_OK;
+    if (n_items > 65535 || max_rows <= 0 || max_cols <= 0) return FOCUS_ERR_SHAPE;
+    const int tiles = ((max_rows + 63) / 64) * ((max_cols + 63) / 64);
+    hipLaunchKernelGGL(shadow_refresh_kernel, dim3(tiles, n_items), dim3(256), 0, (hipStream_t)stream, items);
+    FOCUS_CHECK_LAUNCH();
+    return FOCUS_OK;
+}
+
 extern "C" int focus_cast(const void* src, int sd, void* dst, int dd, int64_t n, void* stream) {
     if (!src || !dst) return FOCUS_ERR_NULL;
     if (n <= 0) return FOCUS_OK;

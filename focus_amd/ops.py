@@ -198,9 +198,49 @@ _shadow_gen = 0
 def invalidate_shadows():
     """Fused optimizers (torch._fused_adamw_) update parameters in place WITHOUT bumping Tensor._version, so the
     version counter alone cannot tell that a bf16 shadow is stale.  construct_optimizer() registers this as an
-    optimizer post-step hook; call it yourself after any other out-of-band parameter update."""
+    optimizer post-step hook; call it yourself after any other out-of-band parameter update.
+    The bf16 shadows that already exist (row-major and transposed) are rewritten right here by ONE multi-tensor
+    launch (focus_shadow_refresh) instead of ~200 cast / transpose launches spread over the next step."""
     global _shadow_gen
     _shadow_gen += 1
+    _refresh_shadows_batched()
+
+
+_shadow_tables = {}      # device -> (signature, items tensor, max_rows, max_cols, [(key, weakref)])
+
+
+def _refresh_shadows_batched():
+    import numpy as np
+    by_dev = {}
+    for key, (ref, stamp, out) in list(_shadow_cache.items()):
+        w = ref()
+        if w is None or key[1] != torch.bfloat16 or w.dtype != torch.float32 or w.dim() != 2 or not w.is_cuda:
+            continue
+        if w.shape[0] % 4 or w.shape[1] % 4 or not w.is_contiguous() or w.data_ptr() % 16:
+            continue
+        by_dev.setdefault(w.device, {}).setdefault(id(w), [w, None, None])[2 if key[2] else 1] = (key, out)
+    for dev, ws in by_dev.items():
+        sig = tuple((i, e[0].data_ptr(), e[1][1].data_ptr() if e[1] else 0, e[2][1].data_ptr() if e[2] else 0)
+                    for i, e in sorted(ws.items()))
+        tab = _shadow_tables.get(dev)
+        if tab is None or tab[0] != sig:
+            rec = np.zeros((len(sig), 4), dtype=np.int64)       # focus_shadow_item: 3 pointers + (rows, cols)
+            mr = mc = 0
+            for n, (i, sp, dp, tp) in enumerate(sig):
+                w = ws[i][0]
+                rec[n, 0], rec[n, 1], rec[n, 2] = sp, dp, tp
+                rec[n, 3] = int(w.shape[0]) | (int(w.shape[1]) << 32)
+                mr, mc = max(mr, w.shape[0]), max(mc, w.shape[1])
+            tab = (sig, torch.from_numpy(rec).to(dev), mr, mc)
+            _shadow_tables[dev] = tab
+        with torch.cuda.device(dev):
+            _lib.check(_lib.lib().focus_shadow_refresh(_p(tab[1]), len(sig), tab[2], tab[3], _stream()), "shadow_refresh")
+        for e in ws.values():
+            w = e[0]
+            for slot in (e[1], e[2]):
+                if slot is not None:
+                    key, out = slot
+                    _shadow_cache[key] = (_shadow_cache[key][0], (w._version, w.data_ptr(), _shadow_gen), out)
 
 
 def shadow(w, dtype, transposed=False):

@@ -249,6 +249,16 @@ int focus_transpose_pad(const void* src, int src_dtype, int64_t src_ld, int64_t 
                         int dst_dtype, int64_t dst_ld, int64_t dst_bstride, int R, int Cc, int batch,
                         void* stream);
 
+/* bf16 working copies of fp32 master weights, all tensors of a model in ONE launch (what autocast does per use in
+ * the reference, train_net.py:84 `torch.cuda.amp.autocast`): for every item, dst[r,c] = bf16(src[r,c]) (row-major,
+ * optional) and dstT[c,r] = bf16(src[r,c]) (the K-contiguous operand of the dX GEMM, optional).
+ * `items` is a DEVICE array of n_items focus_shadow_item; rows % 4 == 0 and cols % 4 == 0, 16-byte aligned src. */
+typedef struct focus_shadow_item {
+    const float* src; void* dst; void* dstT;
+    int32_t rows, cols;
+} focus_shadow_item;
+int focus_shadow_refresh(const focus_shadow_item* items, int n_items, int max_rows, int max_cols, void* stream);
+
 /* xdiag[b,s,:] = xt[b,s,s/P,:] (attention.py:533-535) and its adjoint dxt[b,s,s/P,:] += dxdiag[b,s,:]. */
 int focus_diag_gather(const void* xt, void* xdiag, int B, int S, int F, int C, int dtype, void* stream);
 int focus_diag_scatter_add(const void* dxdiag, void* dxt, int B, int S, int F, int C, int dtype, void* stream);
