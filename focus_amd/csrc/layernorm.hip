@@ -53,8 +53,8 @@ template <typename T, int NV>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                      const float* __restrict__ gamma,
                                                      const float* __restrict__ mean,
-                                                     const float* __restrict__ rstd, T* __restrict__ dx,
-                                                     float* __restrict__ partial, int rows, int D) {
+                                                     const float* __restrict__ rstd, const T* __restrict__ dres,
+                                                     T* __restrict__ dx, float* __restrict__ partial, int rows, int D) {
     __shared__ float red[4][64 * 4 + 4];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     f4 dg[NV], db[NV], g[NV];
@@ -109,6 +109,10 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
                 if (c < D) {
                     f4 o = {rs * (gd[i].x - m1 - xh[i].x * m2), rs * (gd[i].y - m1 - xh[i].y * m2),
                             rs * (gd[i].z - m1 - xh[i].z * m2), rs * (gd[i].w - m1 - xh[i].w * m2)};
+                    if (dres) {      // gradient arriving on the residual path around this LayerNorm
+                        const f4 e = ld4<T>(dres + (int64_t)(rr ? row1 : row0) * D + c);
+                        o.x += e.x; o.y += e.y; o.z += e.z; o.w += e.w;
+                    }
                     st4<T>(dxr + c, o);
                 }
             }
@@ -173,11 +177,11 @@ int ln_fwd_launch(const void* x, const float* g, const float* b, void* y, float*
 }
 
 template <typename T>
-int ln_bwd_launch(const void* dy, const void* x, const float* g, const float* mean, const float* rstd, void* dx,
-                  float* partial, int rows, int D, int nblk, hipStream_t s) {
+int ln_bwd_launch(const void* dy, const void* x, const float* g, const float* mean, const float* rstd, const void* dres,
+                  void* dx, float* partial, int rows, int D, int nblk, hipStream_t s) {
     const int nv = (D + 255) / 256;
     dim3 grid(nblk), blk(256);
-#define LN_BWD(NV) hipLaunchKernelGGL((ln_bwd_kernel<T, NV>), grid, blk, 0, s, (const T*)dy, (const T*)x, g, mean, rstd, (T*)dx, partial, rows, D)
+#define LN_BWD(NV) hipLaunchKernelGGL((ln_bwd_kernel<T, NV>), grid, blk, 0, s, (const T*)dy, (const T*)x, g, mean, rstd, (const T*)dres, (T*)dx, partial, rows, D)
     if (nv <= 1) LN_BWD(1); else if (nv <= 2) LN_BWD(2); else if (nv <= 3) LN_BWD(3); else if (nv <= 4) LN_BWD(4);
     else if (nv <= 8) LN_BWD(8); else LN_BWD(16);
 #undef LN_BWD
@@ -205,14 +209,14 @@ extern "C" int focus_layernorm_bwd_blocks(int rows) {
 }
 
 extern "C" int focus_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean,
-                                   const float* rstd, void* dx, float* dgamma, float* dbeta, float* partial,
-                                   int rows, int D, int dtype, void* stream) {
+                                   const float* rstd, const void* dres, void* dx, float* dgamma, float* dbeta,
+                                   float* partial, int rows, int D, int dtype, void* stream) {
     if (!dy || !x || !gamma || !mean || !rstd || !dx || !dgamma || !dbeta || !partial) return FOCUS_ERR_NULL;
     if (D <= 0 || (D & 3) || D > MAXV * 256 || rows <= 0) return FOCUS_ERR_SHAPE;
     hipStream_t s = (hipStream_t)stream;
     const int nblk = focus_layernorm_bwd_blocks(rows);
-    int rc = dtype == FOCUS_BF16 ? ln_bwd_launch<bf16_t>(dy, x, gamma, mean, rstd, dx, partial, rows, D, nblk, s)
-                                 : ln_bwd_launch<float>(dy, x, gamma, mean, rstd, dx, partial, rows, D, nblk, s);
+    int rc = dtype == FOCUS_BF16 ? ln_bwd_launch<bf16_t>(dy, x, gamma, mean, rstd, dres, dx, partial, rows, D, nblk, s)
+                                 : ln_bwd_launch<float>(dy, x, gamma, mean, rstd, dres, dx, partial, rows, D, nblk, s);
     if (rc) return rc;
     hipLaunchKernelGGL(ln_bwd_finish, dim3((D + 15) / 16, 2), dim3(256), 0, s, partial, dgamma, dbeta, nblk, D);
     FOCUS_CHECK_LAUNCH();

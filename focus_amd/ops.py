@@ -390,45 +390,78 @@ def residual_drop_path(x, y, drop_prob, training):
 # --------------------------------------------------------------------------------------------------
 # LayerNorm
 # --------------------------------------------------------------------------------------------------
+def _ln_forward(ctx, x, gamma, beta, eps):
+    _need_gpu(x, gamma)
+    D = x.shape[-1]
+    x2 = x.reshape(-1, D)
+    if not x2.is_contiguous():
+        x2 = x2.contiguous()
+    rows = x2.shape[0]
+    y = torch.empty_like(x2)
+    mean = torch.empty(rows, device=x.device, dtype=torch.float32)
+    rstd = torch.empty(rows, device=x.device, dtype=torch.float32)
+    _lib.check(_lib.lib().focus_layernorm_fwd(_p(x2), _p(gamma), _p(beta), _p(y), _p(mean), _p(rstd), rows, D,
+                                              eps, _dt(x2), _stream()), "layernorm_fwd")
+    ctx.save_for_backward(x2, gamma, mean, rstd)
+    ctx.shp = x.shape
+    return y.reshape(x.shape)
+
+
+def _ln_backward(ctx, dy, dres):
+    x2, gamma, mean, rstd = ctx.saved_tensors
+    D = x2.shape[1]
+    rows = x2.shape[0]
+    dy2 = dy.reshape(-1, D)
+    if not dy2.is_contiguous():
+        dy2 = dy2.contiguous()
+    r2 = None
+    if dres is not None:
+        r2 = dres.reshape(-1, D)
+        if not r2.is_contiguous():
+            r2 = r2.contiguous()
+    L = _lib.lib()
+    nblk = L.focus_layernorm_bwd_blocks(rows)
+    partial = torch.empty(2, nblk, D, device=x2.device, dtype=torch.float32)
+    dx = torch.empty_like(x2)
+    dg = torch.empty(D, device=x2.device, dtype=torch.float32)
+    db = torch.empty(D, device=x2.device, dtype=torch.float32)
+    _lib.check(L.focus_layernorm_bwd(_p(dy2), _p(x2), _p(gamma), _p(mean), _p(rstd), _p(r2) if r2 is not None else None,
+                                     _p(dx), _p(dg), _p(db), _p(partial), rows, D, _dt(x2), _stream()), "layernorm_bwd")
+    return dx.reshape(ctx.shp), dg, db
+
+
 class _LayerNormFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, gamma, beta, eps):
-        _need_gpu(x, gamma)
-        D = x.shape[-1]
-        x2 = x.reshape(-1, D)
-        if not x2.is_contiguous():
-            x2 = x2.contiguous()
-        rows = x2.shape[0]
-        y = torch.empty_like(x2)
-        mean = torch.empty(rows, device=x.device, dtype=torch.float32)
-        rstd = torch.empty(rows, device=x.device, dtype=torch.float32)
-        _lib.check(_lib.lib().focus_layernorm_fwd(_p(x2), _p(gamma), _p(beta), _p(y), _p(mean), _p(rstd), rows, D,
-                                                  eps, _dt(x2), _stream()), "layernorm_fwd")
-        ctx.save_for_backward(x2, gamma, mean, rstd)
-        ctx.shp = x.shape
-        return y.reshape(x.shape)
+        return _ln_forward(ctx, x, gamma, beta, eps)
 
     @staticmethod
     def backward(ctx, dy):
-        x2, gamma, mean, rstd = ctx.saved_tensors
-        D = x2.shape[1]
-        rows = x2.shape[0]
-        dy2 = dy.reshape(-1, D)
-        if not dy2.is_contiguous():
-            dy2 = dy2.contiguous()
-        L = _lib.lib()
-        nblk = L.focus_layernorm_bwd_blocks(rows)
-        partial = torch.empty(2, nblk, D, device=x2.device, dtype=torch.float32)
-        dx = torch.empty_like(x2)
-        dg = torch.empty(D, device=x2.device, dtype=torch.float32)
-        db = torch.empty(D, device=x2.device, dtype=torch.float32)
-        _lib.check(L.focus_layernorm_bwd(_p(dy2), _p(x2), _p(gamma), _p(mean), _p(rstd), _p(dx), _p(dg), _p(db),
-                                         _p(partial), rows, D, _dt(x2), _stream()), "layernorm_bwd")
-        return dx.reshape(ctx.shp), dg, db, None
+        return (*_ln_backward(ctx, dy, None), None)
+
+
+class _LayerNormForkFn(torch.autograd.Function):
+    """(x, LayerNorm(x)) for a pre-norm residual block: the gradient that comes back on the residual path is added
+    to the LayerNorm's input gradient inside focus_layernorm_bwd instead of by a separate autograd accumulation."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps):
+        return x.view_as(x), _ln_forward(ctx, x, gamma, beta, eps)
+
+    @staticmethod
+    def backward(ctx, dres, dy):
+        if dy is None:
+            return dres, None, None, None
+        return (*_ln_backward(ctx, dy, dres), None)
 
 
 def layer_norm(x, gamma, beta, eps):
     return _LayerNormFn.apply(x, gamma, beta, eps)
+
+
+def layer_norm_fork(x, gamma, beta, eps):
+    """-> (x_res, LayerNorm(x)): use x_res for the block's residual add (see _LayerNormForkFn)."""
+    return _LayerNormForkFn.apply(x, gamma, beta, eps)
 
 
 # --------------------------------------------------------------------------------------------------

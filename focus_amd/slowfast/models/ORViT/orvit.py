@@ -97,7 +97,8 @@ class ORViT(nn.Module):
         new_tokens = torch.cat([cls_token2, new_patch], dim=1)
         x = x + self.drop_path(new_tokens)                                                   # :169
         n2 = self.norm2
-        x = x + self.drop_path(self.mlp(ops.layer_norm(x, n2.weight, n2.bias, n2.eps)))     # :170
+        xr, h = ops.layer_norm_fork(x, n2.weight, n2.bias, n2.eps)
+        x = xr + self.drop_path(self.mlp(h))                                                 # :170
         return x, thw
 
 

@@ -116,12 +116,16 @@ class TrajectoryAttentionBlock(nn.Module):
         n1, n2 = self.norm1, self.norm2
         if isinstance(self.drop_path, nn.Identity) or not self.training:
             # residual adds ride in the proj / fc2 GEMM epilogues
-            x = self.attn(ops.layer_norm(x, n1.weight, n1.bias, n1.eps), thw, with_cls_token, residual=x)[0]
-            x = self.mlp(ops.layer_norm(x, n2.weight, n2.bias, n2.eps), residual=x)
+            xr, h = ops.layer_norm_fork(x, n1.weight, n1.bias, n1.eps)
+            x = self.attn(h, thw, with_cls_token, residual=xr)[0]
+            xr, h = ops.layer_norm_fork(x, n2.weight, n2.bias, n2.eps)
+            x = self.mlp(h, residual=xr)
             return x, thw
         # training with stochastic depth: x + mask_b/keep * branch in one fused pass per residual
+        # (layer_norm_fork: the residual-path gradient is added inside the LayerNorm backward kernel)
         dp = self.drop_path.drop_prob
-        x = ops.residual_drop_path(x, self.attn(ops.layer_norm(x, n1.weight, n1.bias, n1.eps), thw, with_cls_token)[0],
-                                   dp, True)
-        x = ops.residual_drop_path(x, self.mlp(ops.layer_norm(x, n2.weight, n2.bias, n2.eps)), dp, True)
+        xr, h = ops.layer_norm_fork(x, n1.weight, n1.bias, n1.eps)
+        x = ops.residual_drop_path(xr, self.attn(h, thw, with_cls_token)[0], dp, True)
+        xr, h = ops.layer_norm_fork(x, n2.weight, n2.bias, n2.eps)
+        x = ops.residual_drop_path(xr, self.mlp(h), dp, True)
         return x, thw

@@ -108,10 +108,12 @@ int focus_colsum(const void* x, float* out, int M, int N, int64_t row_stride, in
 int focus_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean,
                         float* rstd, int rows, int D, float eps, int dtype, void* stream);
 /* dgamma/dbeta are written (not accumulated); `partial` is a [2, nblk, D] fp32 scratch with
- * nblk = focus_layernorm_bwd_blocks(rows). */
+ * nblk = focus_layernorm_bwd_blocks(rows).  dres (may be NULL): gradient arriving on the residual path around a
+ * pre-norm block (x -> x + f(LN(x)), attention.py:116-126); it is added into dx in the same pass, replacing the
+ * separate accumulation autograd would do. */
 int focus_layernorm_bwd_blocks(int rows);
 int focus_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean,
-                        const float* rstd, void* dx, float* dgamma, float* dbeta, float* partial,
+                        const float* rstd, const void* dres, void* dx, float* dgamma, float* dbeta, float* partial,
                         int rows, int D, int dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
