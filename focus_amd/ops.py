@@ -543,6 +543,65 @@ def traj_time(q2, k2, xt, heads):
     return _TrajTimeFn.apply(q2, k2, xt, heads)
 
 
+class _TrajTimeBlockFn(torch.autograd.Function):
+    """k2 = proj_kv(x~)[..., :C] and the temporal attention (attention.py:537-549) as ONE autograd node.  x~ feeds
+    both the k2 GEMM and the attention, so autograd would sum two [B,S,F,C] gradients (a 460 MB elementwise pass per
+    block); here the attention's d(x~) rides into the dX GEMM  d(x~) = dk2 . Wk + d(x~)_attn  as its residual
+    epilogue.  The dead v2 half of proj_kv gets its (zero) gradient rows written once instead of through a slice
+    backward."""
+
+    @staticmethod
+    def forward(ctx, q2, xt, w_kv, b_kv, heads):
+        _need_gpu(q2, xt, w_kv)
+        q2, xt = q2.contiguous(), xt.contiguous()
+        B, S, F_, C = xt.shape
+        d = C // heads
+        wk = shadow(w_kv, xt.dtype)[:C]
+        bk = b_kv.detach()[:C] if b_kv is not None else None
+        k2 = mm_nt(xt.view(-1, C), wk, bias=bk).view(B, S, F_, C)
+        out = torch.empty(B, S, C, device=xt.device, dtype=xt.dtype)
+        attn2 = torch.empty(B, heads, S, F_, device=xt.device, dtype=torch.float32)
+        _lib.check(_lib.lib().focus_traj_time_fwd(_p(q2), _p(k2), _p(xt), _p(out), _p(attn2), B, S, F_, heads, d,
+                                                  _dt(xt), _stream()), "traj_time_fwd")
+        ctx.save_for_backward(q2, k2, xt, attn2, w_kv)
+        ctx.heads, ctx.has_b = heads, b_kv is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        q2, k2, xt, attn2, w_kv = ctx.saved_tensors
+        B, S, F_, C = xt.shape
+        dout = dout.contiguous()
+        dq2, dk2, dxt_a = torch.empty_like(q2), torch.empty_like(k2), torch.empty_like(xt)
+        _lib.check(_lib.lib().focus_traj_time_bwd(_p(q2), _p(k2), _p(xt), _p(attn2), _p(dout), _p(dq2), _p(dk2),
+                                                  _p(dxt_a), 0, B, S, F_, ctx.heads, C // ctx.heads, _dt(xt),
+                                                  _stream()), "traj_time_bwd")
+        dk2f, xt2 = dk2.view(-1, C), xt.view(-1, C)
+        dw = db = None
+        if ctx.needs_input_grad[2]:
+            dwk, dbk = linear_wgrad(dk2f, xt2, ctx.has_b and ctx.needs_input_grad[3])
+            dw = torch.empty(2 * C, C, device=xt.device, dtype=torch.float32)
+            dw[:C].copy_(dwk)
+            dw[C:].zero_()                      # v2 half: no output use, exactly zero gradient
+            if dbk is not None:
+                db = torch.zeros(2 * C, device=xt.device, dtype=torch.float32)
+                db[:C].copy_(dbk)
+        dxt = None
+        if ctx.needs_input_grad[1]:
+            if xt.dtype == torch.bfloat16 and C % 64 == 0:
+                wt = shadow(w_kv, xt.dtype, transposed=True)            # [C_in, 2C]: columns :C are Wk^T
+                dxt = mm_nt(dk2f, wt[:, :C], residual=dxt_a.view(-1, C))
+            else:
+                dxt = mm_nn(dk2f, shadow(w_kv, xt.dtype)[:C]).add_(dxt_a.view(-1, C))
+            dxt = dxt.view(B, S, F_, C)
+        return dq2, dxt, dw, db, None
+
+
+def traj_time_block(q2, xt, w_kv, b_kv, heads):
+    """out [B,S,C] of the temporal step from q2 [B,S,C], x~ [B,S,F,C] and the proj_kv parameters."""
+    return _TrajTimeBlockFn.apply(q2, xt, w_kv, b_kv, heads)
+
+
 class _TrajTime2Fn(torch.autograd.Function):
     """Temporal step in re-associated form (include/focus_amd.h: focus_traj_time2_*): the k2 = proj_kv(x~) GEMM over
     all S*F rows is replaced by u = Wk[h]^T q2 (a per-head GEMM over S rows) + one HBM-bound kernel."""

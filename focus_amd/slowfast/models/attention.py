@@ -93,8 +93,8 @@ class TrajectoryAttention(nn.Module):
             # the softmax -- k2 [B,S,F,C] (the block's largest GEMM) is never formed
             out = ops.traj_time2(q2, xt, wk, bk, h)
         else:
-            k2 = ops.linear(xt, wk, bk)                                            # [B,S,F,C]
-            out = ops.traj_time(q2, k2, xt, h)                                     # :538-549
+            # k2 = proj_kv(x~)[:C] ([B,S,F,C]) + temporal attention as one autograd node (:537-549)
+            out = ops.traj_time_block(q2, xt, self.proj_kv.weight, self.proj_kv.bias, h)
         y = ops.linear(torch.cat((cls_out, out), dim=1), self.proj.weight, self.proj.bias, residual=residual)
         return y, thw_prev
 
