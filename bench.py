@@ -80,6 +80,16 @@ def cpu_baseline(model, cfg, seconds_budget=30.0):
             "hip_vs_oracle_rel_err_bf16": round(err, 5)}
 
 
+def pmc_traffic():
+    """HBM-side bytes per NT-GEMM launch from the committed PMC passes (bench.py cannot run rocprofv3 on itself):
+    last line of profiles/r01_pmc_hbm_traffic.txt, or None when the file is absent."""
+    try:
+        last = open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_hbm_traffic.txt")).read().strip().splitlines()[-1]
+        return round(float(last.rsplit("=", 1)[1].split("MB")[0]) * 1e6)
+    except Exception:
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -182,8 +192,13 @@ def main():
                 print("%-44s %5.1f %8.1f %7.0f %7.3f" % (k, e[0] / args.steps, 1e3 * e[1] / e[0], e[2] / e[1] / 1e9,
                                                          e[1] / args.steps), file=sys.stderr)
         tn_tf = sum(r[0] for r in tn) / (tn_ms * 1e-3) / 1e12 if tn_ms > 0 else 0.0
+        # algorithmic HBM bytes of the same launches: A + B + C (+ aux, residual are not known here: lower bound)
+        alg = sum(2.0 * r[4][3] * (r[4][0] * r[4][2] + r[4][1] * r[4][2] + r[4][0] * r[4][1]) for r in recs)
         out["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                           "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                           "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": pmc_traffic(),
+                           "traffic_unit": "bytes/launch (PMC: 2*FETCH_SIZE + WRITE_SIZE, separate rocprofv3 passes, "
+                                           "profiles/r01_pmc_hbm_traffic.txt)",
+                           "algorithmic_bytes_per_launch": round(alg / max(len(recs), 1)),
                            "kernel": "gemm_nt_ws_kernel / gemm_nt_kernel, bf16 NT GEMM (focus_amd/csrc/gemm_mfma_ws.hip, gemm_mfma.hip)",
                            "launches_per_step": len(recs) // max(args.steps, 1),
                            "avg_launch_us": round(1e3 * ms / max(len(recs), 1), 2),
