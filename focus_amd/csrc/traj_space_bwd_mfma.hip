@@ -65,44 +65,51 @@ __device__ __forceinline__ bf16x8 pack_acc(const f32x16& a, int s2) {
 // delta[b,h,s,f] = scale * sum_d (dxt[b,s,f,h,d] + [f == s/P] dxdiag[b,s,h,d]) * xt[b,s,f,h,d]
 // lse2[b,h,s,f]  = lse[b,h,s,f] * log2(e)
 // dxsum[b,s,:]   = dxt[b,s,s/P,:] + dxdiag[b,s,:]      (so the kernels below can DMA dX rows without an add)
-// one wave per (b,s); a head's 64 channels sit on 16 adjacent lanes (4 channels per lane)
+// one thread per 16-byte chunk; a head's 64 channels sit on 8 adjacent lanes
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void traj_delta_kernel(const bf16_t* __restrict__ dxt, const bf16_t* __restrict__ dxdiag,
                                                          const bf16_t* __restrict__ xt, const float* __restrict__ lse,
                                                          float* __restrict__ delta, float* __restrict__ lse2,
-                                                         bf16_t* __restrict__ dxsum, int64_t rows, int S, int F, int P,
+                                                         bf16_t* __restrict__ dxsum, int64_t nchunks, int S, int F, int P,
                                                          int heads) {
-    const int lane = threadIdx.x & 63;
-    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= rows) return;
-    const int C = heads * HD;
-    const int64_t b = row / S;
+    // one thread per 16-byte chunk (8 channels) of dx~ / x~, in memory order: both streams are read perfectly
+    // coalesced with no loop (the previous row-per-wave form issued 8-byte loads one frame at a time: 3.1 TB/s);
+    // a head's 64 channels = 8 adjacent lanes
+    const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const bool act = g < nchunks;
+    const int cpr = heads * (HD / 8);                      // chunks per (row, frame)
+    const int64_t gc = act ? g : nchunks - 1;
+    const int64_t rf = gc / cpr;
+    const int ch = (int)(gc - rf * cpr);
+    const int64_t row = rf / F;
+    const int f = (int)(rf - row * F);
     const int s = (int)(row % S), fs = s / P;
-    for (int c0 = 0; c0 < C; c0 += 256) {
-        const int c = c0 + lane * 4;
-        const bool act = c < C;
-        f4 dd = {0.f, 0.f, 0.f, 0.f};
-        if (act) dd = ld4<bf16_t>(dxdiag + row * C + c);
-        for (int f = 0; f < F; ++f) {
-            float p = 0.f;
-            if (act) {
-                f4 g = ld4<bf16_t>(dxt + (row * F + f) * C + c);
-                const f4 x = ld4<bf16_t>(xt + (row * F + f) * C + c);
-                if (f == fs) {
-                    g.x += dd.x; g.y += dd.y; g.z += dd.z; g.w += dd.w;
-                    st4<bf16_t>(dxsum + row * C + c, g);      // dX row of the query's own frame, for the dQ / dKV kernels
-                }
-                p = g.x * x.x + g.y * x.y + g.z * x.z + g.w * x.w;
-            }
+    Pack8 a, x;
+    a.u = *reinterpret_cast<const uint4*>(dxt + gc * 8);
+    x.u = *reinterpret_cast<const uint4*>(xt + gc * 8);
+    float gv[8];
 #pragma unroll
-            for (int o = 8; o > 0; o >>= 1) p += __shfl_xor(p, o, 64);
-            if (act && (lane & 15) == 0) {
-                // pre-scaled for the MFMA kernels: delta * scale, and the forward's lse in base-2 units
-                const int64_t o = ((b * heads + c / HD) * S + s) * F + f;
-                delta[o] = p * 0.125f;                     // scale = 1/sqrt(64)
-                lse2[o] = lse[o] * LOG2E;
-            }
-        }
+    for (int j = 0; j < 8; ++j) gv[j] = bf16_to_f32(a.e[j]);
+    if (f == fs) {
+        Pack8 d2;
+        d2.u = *reinterpret_cast<const uint4*>(dxdiag + (row * cpr + ch) * 8);
+        Pack8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { gv[j] += bf16_to_f32(d2.e[j]); o.e[j] = f32_to_bf16(gv[j]); }
+        if (act) *reinterpret_cast<uint4*>(dxsum + (row * cpr + ch) * 8) = o.u;   // dX row of the query's own frame
+    }
+    float p = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) p = fmaf(gv[j], bf16_to_f32(x.e[j]), p);
+    p += __shfl_xor(p, 1, 64);
+    p += __shfl_xor(p, 2, 64);
+    p += __shfl_xor(p, 4, 64);
+    if (act && (ch & 7) == 0) {
+        // pre-scaled for the MFMA kernels: delta * scale, and the forward's lse in base-2 units
+        const int64_t b = row / S;
+        const int64_t o = ((b * heads + (ch >> 3)) * S + s) * F + f;
+        delta[o] = p * 0.125f;                             // scale = 1/sqrt(64)
+        lse2[o] = lse[o] * LOG2E;
     }
 }
 
@@ -443,8 +450,9 @@ int focus_traj_space_bwd_mfma(const void* qkv, const void* xt, const float* lse,
     if (B * heads > 65535 || F > MAXF) return FOCUS_ERR_SHAPE;
     const int S = F * P;
     const int64_t rows = (int64_t)B * S;
-    hipLaunchKernelGGL(traj_delta_kernel, dim3((unsigned)cdiv64(rows, 4)), dim3(256), 0, s, (const bf16_t*)dxt,
-                       (const bf16_t*)dxdiag, (const bf16_t*)xt, lse, delta, lse2, (bf16_t*)dxsum, rows, S, F, P, heads);
+    const int64_t nchunks = rows * F * heads * (HD / 8);
+    hipLaunchKernelGGL(traj_delta_kernel, dim3((unsigned)cdiv64(nchunks, 256)), dim3(256), 0, s, (const bf16_t*)dxt,
+                       (const bf16_t*)dxdiag, (const bf16_t*)xt, lse, delta, lse2, (bf16_t*)dxsum, nchunks, S, F, P, heads);
     FOCUS_CHECK_LAUNCH();
     switch ((P + 31) / 32) {     // exact block count: the kernels rely on NKB == ceil(P/32)
         case 1: return launch_bwd<1>(qkv, dxt, dxsum, lse2, delta, dqkv, B, F, P, heads, s);
