@@ -150,12 +150,12 @@ extern "C" size_t focus_traj_space_workspace_bytes(int B, int F, int P, int head
     const size_t S = (size_t)F * P, N = S + 1, C = (size_t)heads * d, es = focus_esize(dtype);
     const bool fused = focus_traj_space_mfma_ok(P, d, heads, dtype);
     size_t bytes = (size_t)B * heads * N * es;               // cls row
+    bytes += focus_traj_cls_scratch_floats(B, (int)N, heads) * sizeof(float) + 256;   // cls kernels' scratch (fwd and bwd)
     if (!fused) bytes += (size_t)B * heads * S * S * es;     // logits / probabilities (unfused path)
     if (backward) {
         bytes += (size_t)B * heads * N * es + 4096;          // d(cls row) + alignment padding of the carve-up
         if (fused) {
             bytes += (size_t)2 * (B * heads * S * F * sizeof(float) + 256);   // delta * scale, lse in base-2 units
-            bytes += (size_t)2 * B * heads * N * sizeof(float) + 256;   // cls prob / dlog scratch
             bytes += (size_t)B * S * C * es + 256;                      // dxsum: dX rows of each query's own frame
         } else {
             bytes += (size_t)B * heads * S * S * es;         // d(prob) / d(logits)
@@ -198,7 +198,12 @@ extern "C" int focus_traj_space_fwd(const void* qkv, void* xt, void* xdiag, void
     if ((rc = focus_diag_gather(xt, xdiag, B, D.S, F, D.C, dtype, s))) return rc;
     }
     // cls row over all N keys
-    if (focus_traj_cls_ok(D.N, d)) return focus_traj_cls_fwd(qkv, cls_out, cls_lse, B, D.N, heads, dtype, s);
+    if (focus_traj_cls_ok(D.N, d)) {
+        // scratch at the end of the workspace (everything before it belongs to the unfused path's logits)
+        const size_t need = focus_traj_cls_scratch_floats(B, D.N, heads) * sizeof(float);
+        float* scratch = reinterpret_cast<float*>(static_cast<char*>(ws) + ((ws_bytes - need) & ~(size_t)255));
+        return focus_traj_cls_fwd(qkv, cls_out, cls_lse, scratch, B, D.N, heads, dtype, s);
+    }
     {
         focus_gemm_desc g = base_desc(dtype);
         g.M = 1; g.N = D.N; g.K = d; g.batch0 = B; g.batch1 = heads;
@@ -241,7 +246,7 @@ extern "C" int focus_traj_space_bwd(const void* qkv, const void* xt, const void*
         // patch rows first: fully writes the q/k/v parts of tokens 1..N-1; the cls step below adds onto k/v
         float* delta = reinterpret_cast<float*>(L);
         float* cls_scratch = delta + (((int64_t)B * heads * D.S * F + 63) & ~(int64_t)63);
-        float* lse2 = cls_scratch + (((int64_t)2 * B * heads * D.N + 63) & ~(int64_t)63);
+        float* lse2 = cls_scratch + ((focus_traj_cls_scratch_floats(B, D.N, heads) + 63) & ~(size_t)63);
         void* dxsum = lse2 + (((int64_t)B * heads * D.S * F + 63) & ~(int64_t)63);
         if ((rc = focus_traj_space_bwd_mfma(qkv, xt, lse, dxt, dxdiag, delta, lse2, dxsum, dqkv, B, F, P, heads, s)))
             return rc;

@@ -8,6 +8,8 @@ int focus_traj_space_bwd_mfma(const void* qkv, const void* xt, const float* lse,
                               hipStream_t s);
 // cls row (one query per (b,h) over all N keys); bwd ADDS onto rows 1.. of the k/v parts of dqkv, writes row 0.
 bool focus_traj_cls_ok(int N, int d);
-int focus_traj_cls_fwd(const void* qkv, void* cls_out, float* cls_lse, int B, int N, int heads, int dtype, hipStream_t s);
+size_t focus_traj_cls_scratch_floats(int B, int N, int heads);
+int focus_traj_cls_fwd(const void* qkv, void* cls_out, float* cls_lse, float* scratch, int B, int N, int heads, int dtype,
+                       hipStream_t s);
 int focus_traj_cls_bwd(const void* qkv, const float* cls_lse, const void* dcls, void* dqkv, float* scratch, int B, int N,
                        int heads, int dtype, hipStream_t s);   // scratch: 2*B*heads*N floats
