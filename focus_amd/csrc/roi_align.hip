@@ -122,6 +122,55 @@ __global__ __launch_bounds__(256) void roi_bwd_kernel(const T* __restrict__ dout
     }
 }
 
+// Backward without global atomics: one workgroup owns a (image, CS-channel slab) tile of the gradient map in LDS
+// ([H*W][CS] fp32), walks the RoIs of its image, scatters with LDS atomics and writes the finished tile once, in the
+// feature dtype.  (The atomic kernel above issues 4 global float atomics per sample and channel -- 154 M per call
+// at the bench shape, 474 us; this form reads dout once and writes dfeat once.)
+template <typename T>
+__global__ __launch_bounds__(256) void roi_bwd_tile_kernel(const T* __restrict__ dout, const float* __restrict__ rois,
+                                                           const int32_t* __restrict__ roi_img, T* __restrict__ dfeat,
+                                                           int C, int H, int W, int K, int PH, int PW, float scale,
+                                                           int sr, int aligned, int CS) {
+    extern __shared__ __attribute__((aligned(16))) float tile[];          // [H*W][CS]
+    const int img = blockIdx.y, c0 = blockIdx.x * CS;
+    const int cl = threadIdx.x % CS, grp = threadIdx.x / CS, ngrp = 256 / CS;
+    const int cells = H * W;
+    for (int i = threadIdx.x; i < cells * CS; i += 256) tile[i] = 0.f;
+    __syncthreads();
+    for (int k = 0; k < K; ++k) {
+        if (roi_img[k] != img) continue;                                  // block-uniform
+        const Geom g = roi_geometry(rois + 4 * k, scale, PH, PW, sr, aligned);
+        for (int bin = grp; bin < PH * PW; bin += ngrp) {
+            const int ph = bin / PW, pw = bin - ph * PW;
+            const float gv = ld<T>(dout + ((int64_t)k * PH * PW + bin) * C + c0 + cl) / g.count;
+            for (int iy = 0; iy < g.grid_h; ++iy) {
+                const float y = sample_coord(g.y1, ph, g.bin_h, iy, g.grid_h);
+                for (int ix = 0; ix < g.grid_w; ++ix) {
+                    const float x = sample_coord(g.x1, pw, g.bin_w, ix, g.grid_w);
+                    const Nbr n = locate(y, x, H, W);
+                    if (n.y_low < 0) continue;
+                    if (n.w1 != 0.f) unsafeAtomicAdd(&tile[(n.y_low * W + n.x_low) * CS + cl], gv * n.w1);
+                    if (n.w2 != 0.f) unsafeAtomicAdd(&tile[(n.y_low * W + n.x_high) * CS + cl], gv * n.w2);
+                    if (n.w3 != 0.f) unsafeAtomicAdd(&tile[(n.y_high * W + n.x_low) * CS + cl], gv * n.w3);
+                    if (n.w4 != 0.f) unsafeAtomicAdd(&tile[(n.y_high * W + n.x_high) * CS + cl], gv * n.w4);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < cells * CS; i += 256) {
+        const int cell = i / CS, c = i - cell * CS;
+        st<T>(dfeat + ((int64_t)img * cells + cell) * C + c0 + c, tile[i]);
+    }
+}
+
+// channel-slab width of the tile kernel for an H x W map (0: map too large for LDS, use the atomic kernel)
+static int roi_tile_cs(int C, int H, int W) {
+    for (int cs = 64; cs >= 8; cs >>= 1)
+        if ((size_t)H * W * cs * sizeof(float) <= 64 * 1024 && C % cs == 0) return cs;
+    return 0;
+}
+
 __global__ void roi_indices_kernel(const float* __restrict__ rois, int32_t* __restrict__ grid,
                                    int32_t* __restrict__ nbr, int H, int W, int K, int PH, int PW, float scale,
                                    int sr, int aligned) {
@@ -158,21 +207,46 @@ extern "C" int focus_roi_align_fwd(const void* feat, int64_t img_stride, const f
     return FOCUS_OK;
 }
 
-extern "C" int focus_roi_align_bwd(const void* dout, const float* rois, const int32_t* roi_img, float* dfeat, int NI,
-                                   int C, int H, int W, int K, int PH, int PW, float scale, int sr, int aligned,
-                                   int dtype, void* stream) {
-    (void)NI;
+extern "C" size_t focus_roi_align_bwd_workspace_bytes(int NI, int C, int H, int W) {
+    if (roi_tile_cs(C, H, W)) return 0;
+    return (size_t)NI * H * W * C * sizeof(float);
+}
+
+extern "C" int focus_roi_align_bwd(const void* dout, const float* rois, const int32_t* roi_img, void* dfeat, void* ws,
+                                   size_t ws_bytes, int NI, int C, int H, int W, int K, int PH, int PW, float scale,
+                                   int sr, int aligned, int dtype, void* stream) {
     if (!dout || !rois || !roi_img || !dfeat) return FOCUS_ERR_NULL;
-    if (K <= 0) return FOCUS_OK;
-    if ((C & 3) || PH <= 0 || PW <= 0 || K > 65535) return FOCUS_ERR_SHAPE;
-    dim3 grid(PH, K);
-    if (dtype == FOCUS_BF16)
-        hipLaunchKernelGGL((roi_bwd_kernel<bf16_t>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dout,
-                           rois, roi_img, dfeat, C, H, W, PH, PW, scale, sr, aligned);
-    else
-        hipLaunchKernelGGL((roi_bwd_kernel<float>), grid, dim3(256), 0, (hipStream_t)stream, (const float*)dout, rois,
-                           roi_img, dfeat, C, H, W, PH, PW, scale, sr, aligned);
-    FOCUS_CHECK_LAUNCH();
+    if ((C & 3) || PH <= 0 || PW <= 0 || K > 65535 || NI <= 0 || NI > 65535) return FOCUS_ERR_SHAPE;
+    hipStream_t s = (hipStream_t)stream;
+    const int cs = roi_tile_cs(C, H, W);
+    if (cs) {
+        const size_t lds = (size_t)H * W * cs * sizeof(float);
+        dim3 grid(C / cs, NI);
+        if (dtype == FOCUS_BF16)
+            hipLaunchKernelGGL((roi_bwd_tile_kernel<bf16_t>), grid, dim3(256), lds, s, (const bf16_t*)dout, rois, roi_img,
+                               (bf16_t*)dfeat, C, H, W, K, PH, PW, scale, sr, aligned, cs);
+        else
+            hipLaunchKernelGGL((roi_bwd_tile_kernel<float>), grid, dim3(256), lds, s, (const float*)dout, rois, roi_img,
+                               (float*)dfeat, C, H, W, K, PH, PW, scale, sr, aligned, cs);
+        FOCUS_CHECK_LAUNCH();
+        return FOCUS_OK;
+    }
+    // large maps: fp32 atomics into a zeroed scratch map (or into dfeat itself when it is fp32), then one cast
+    const size_t n = (size_t)NI * H * W * C;
+    float* acc = dtype == FOCUS_F32 ? static_cast<float*>(dfeat) : static_cast<float*>(ws);
+    if (dtype != FOCUS_F32 && (!ws || ws_bytes < n * sizeof(float))) return FOCUS_ERR_WORKSPACE;
+    if (hipMemsetAsync(acc, 0, n * sizeof(float), s) != hipSuccess) return FOCUS_ERR_LAUNCH;
+    if (K > 0) {
+        dim3 grid(PH, K);
+        if (dtype == FOCUS_BF16)
+            hipLaunchKernelGGL((roi_bwd_kernel<bf16_t>), grid, dim3(256), 0, s, (const bf16_t*)dout, rois, roi_img, acc, C,
+                               H, W, PH, PW, scale, sr, aligned);
+        else
+            hipLaunchKernelGGL((roi_bwd_kernel<float>), grid, dim3(256), 0, s, (const float*)dout, rois, roi_img, acc, C, H,
+                               W, PH, PW, scale, sr, aligned);
+        FOCUS_CHECK_LAUNCH();
+    }
+    if (dtype != FOCUS_F32) return focus_cast(acc, FOCUS_F32, dfeat, dtype, (int64_t)n, stream);
     return FOCUS_OK;
 }
 

@@ -752,10 +752,13 @@ class _RoiAlignFn(torch.autograd.Function):
         rois, roi_img = ctx.saved_tensors
         NI, C, H, W, K, PH, PW, scale, sr, al, dt = ctx.args
         dout = dout.contiguous()
-        dfeat = torch.zeros(NI, H * W, C, device=dout.device, dtype=torch.float32)
-        _lib.check(_lib.lib().focus_roi_align_bwd(_p(dout), _p(rois), _p(roi_img), _p(dfeat), NI, C, H, W, K, PH, PW,
-                                                  scale, sr, al, _dt(dout), _stream()), "roi_align_bwd")
-        return cast(dfeat, dt), None, None, None, None, None, None, None, None, None
+        L = _lib.lib()
+        dfeat = torch.empty(NI, H * W, C, device=dout.device, dtype=dt)
+        nb = L.focus_roi_align_bwd_workspace_bytes(NI, C, H, W)
+        ws = torch.empty(nb // 4, device=dout.device, dtype=torch.float32) if nb else None
+        _lib.check(L.focus_roi_align_bwd(_p(dout), _p(rois), _p(roi_img), _p(dfeat), _p(ws), nb, NI, C, H, W, K, PH, PW,
+                                         scale, sr, al, _dt(dout), _stream()), "roi_align_bwd")
+        return dfeat, None, None, None, None, None, None, None, None, None
 
 
 def roi_align_tokens(feat, rois, roi_img, H, W, PH, PW, spatial_scale, sampling_ratio=-1, aligned=True):
