@@ -4,6 +4,7 @@
 // HBM-bound: per output cell and channel, 4 gathered reads (L2-resident: a 14x14x768 map is 300 KB)
 // and one write.
 #include "focus_common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -122,53 +123,113 @@ __global__ __launch_bounds__(256) void roi_bwd_kernel(const T* __restrict__ dout
     }
 }
 
-// Backward without global atomics: one workgroup owns a (image, CS-channel slab) tile of the gradient map in LDS
-// ([H*W][CS] fp32), walks the RoIs of its image, scatters with LDS atomics and writes the finished tile once, in the
-// feature dtype.  (The atomic kernel above issues 4 global float atomics per sample and channel -- 154 M per call
-// at the bench shape, 474 us; this form reads dout once and writes dfeat once.)
+// Backward without atomics, using the separability of RoIAlign: a sampling point's bilinear weight on cell (y, x) is
+// wy(y) * wx(x), its validity test is (y valid) && (x valid), and the points of a RoI form a grid, so for one RoI
+//     dfeat[y][x][c] += (1/count) * sum_ph sum_pw  Ay[y][ph] * dout[ph][pw][c] * Ax[x][pw]
+// with Ay[y][ph] = sum over the bin row's sampling points of wy (a [H x PH] matrix, likewise Ax [W x PW]).
+// One workgroup = (image, 64 channels); thread = (channel, column x) keeps its H output cells in registers over all
+// RoIs of the image: T1[ph] = sum_pw dout[ph][pw] * Ax[x][pw], then acc[y] += sum_ph Ay[y][ph] * T1[ph].
+// No atomics, no zero fill, dout read once, dfeat written once in the feature dtype.  (The scatter form needs 4
+// float atomics per sampling point and channel: 154 M global atomics per call at the bench shape, 474 us; LDS float
+// atomics were slower still -- ds_add_f32 retires about one lane per clock.)
+constexpr int RB_HMAX = 16, RB_PMAX = 16, RB_CS = 64;
+
+// 1-D half of locate(): v -> (low, high, weight of low, weight of high); low < 0 when the coordinate is out of range
+__device__ __forceinline__ void locate1(float v, int L, int* low, int* high, float* w_low, float* w_high) {
+    if (v < -1.0f || v > (float)L) { *low = -1; *high = -1; *w_low = 0.f; *w_high = 0.f; return; }
+    if (v <= 0.f) v = 0.f;
+    int lo = (int)v, hi;
+    if (lo >= L - 1) { hi = lo = L - 1; v = (float)lo; } else hi = lo + 1;
+    const float l = __fsub_rn(v, (float)lo);
+    *low = lo; *high = hi; *w_low = __fsub_rn(1.0f, l); *w_high = l;
+}
+
 template <typename T>
-__global__ __launch_bounds__(256) void roi_bwd_tile_kernel(const T* __restrict__ dout, const float* __restrict__ rois,
+__global__ __launch_bounds__(1024) void roi_bwd_sep_kernel(const T* __restrict__ dout, const float* __restrict__ rois,
                                                            const int32_t* __restrict__ roi_img, T* __restrict__ dfeat,
                                                            int C, int H, int W, int K, int PH, int PW, float scale,
-                                                           int sr, int aligned, int CS) {
-    extern __shared__ __attribute__((aligned(16))) float tile[];          // [H*W][CS]
-    const int img = blockIdx.y, c0 = blockIdx.x * CS;
-    const int cl = threadIdx.x % CS, grp = threadIdx.x / CS, ngrp = 256 / CS;
-    const int cells = H * W;
-    for (int i = threadIdx.x; i < cells * CS; i += 256) tile[i] = 0.f;
-    __syncthreads();
-    for (int k = 0; k < K; ++k) {
-        if (roi_img[k] != img) continue;                                  // block-uniform
-        const Geom g = roi_geometry(rois + 4 * k, scale, PH, PW, sr, aligned);
-        for (int bin = grp; bin < PH * PW; bin += ngrp) {
-            const int ph = bin / PW, pw = bin - ph * PW;
-            const float gv = ld<T>(dout + ((int64_t)k * PH * PW + bin) * C + c0 + cl) / g.count;
-            for (int iy = 0; iy < g.grid_h; ++iy) {
-                const float y = sample_coord(g.y1, ph, g.bin_h, iy, g.grid_h);
+                                                           int sr, int aligned) {
+    extern __shared__ __attribute__((aligned(16))) float gst[];   // [bins][RB_CS]: dout / count of the current RoI
+    __shared__ float Ay[RB_HMAX][RB_PMAX], Ax[RB_HMAX][RB_PMAX];
+    __shared__ int match[1024], wcnt[16], nmatch_s;
+    const int img = blockIdx.y, c0 = blockIdx.x * RB_CS;
+    const int ch = threadIdx.x & 63, x = threadIdx.x >> 6;                 // x < W (blockDim = 64 * W)
+    const int nw = blockDim.x >> 6, bins = PH * PW;
+    float acc[RB_HMAX];
+#pragma unroll
+    for (int y = 0; y < RB_HMAX; ++y) acc[y] = 0.f;
+    for (int kb = 0; kb < K; kb += blockDim.x) {
+        // the RoIs of this image, in index order
+        const int kk = kb + threadIdx.x;
+        const bool m = kk < K && roi_img[kk] == img;
+        const unsigned long long bal = __ballot(m);
+        __syncthreads();
+        if (ch == 0) wcnt[x] = __popcll(bal);
+        __syncthreads();
+        int off = 0, tot = 0;
+        for (int j = 0; j < nw; ++j) { if (j < x) off += wcnt[j]; tot += wcnt[j]; }
+        if (m) match[off + __popcll(bal & ((1ull << ch) - 1ull))] = kk;
+        if (threadIdx.x == 0) nmatch_s = tot;
+        __syncthreads();
+        const int nmatch = nmatch_s;
+        for (int mi = 0; mi < nmatch; ++mi) {
+            const int k = match[mi];
+            const Geom g = roi_geometry(rois + 4 * k, scale, PH, PW, sr, aligned);
+            if (g.grid_h <= 0 || g.grid_w <= 0) continue;                  // block-uniform
+            __syncthreads();                                               // previous RoI's gst / Ay / Ax are free
+            for (int bin = x; bin < bins; bin += nw)
+                gst[bin * RB_CS + ch] = ld<T>(dout + ((int64_t)k * bins + bin) * C + c0 + ch) / g.count;
+            if (threadIdx.x < RB_HMAX * RB_PMAX) { (&Ay[0][0])[threadIdx.x] = 0.f; (&Ax[0][0])[threadIdx.x] = 0.f; }
+            __syncthreads();
+            // one thread per bin row / bin column: no two threads write the same Ay / Ax entry
+            if (threadIdx.x < PH) {
+                const int ph = threadIdx.x;
+                for (int iy = 0; iy < g.grid_h; ++iy) {
+                    int lo, hi; float wl, wh;
+                    locate1(sample_coord(g.y1, ph, g.bin_h, iy, g.grid_h), H, &lo, &hi, &wl, &wh);
+                    if (lo >= 0) { Ay[lo][ph] += wl; Ay[hi][ph] += wh; }
+                }
+            } else if (threadIdx.x >= 64 && threadIdx.x < 64 + PW) {
+                const int pw = threadIdx.x - 64;
                 for (int ix = 0; ix < g.grid_w; ++ix) {
-                    const float x = sample_coord(g.x1, pw, g.bin_w, ix, g.grid_w);
-                    const Nbr n = locate(y, x, H, W);
-                    if (n.y_low < 0) continue;
-                    if (n.w1 != 0.f) unsafeAtomicAdd(&tile[(n.y_low * W + n.x_low) * CS + cl], gv * n.w1);
-                    if (n.w2 != 0.f) unsafeAtomicAdd(&tile[(n.y_low * W + n.x_high) * CS + cl], gv * n.w2);
-                    if (n.w3 != 0.f) unsafeAtomicAdd(&tile[(n.y_high * W + n.x_low) * CS + cl], gv * n.w3);
-                    if (n.w4 != 0.f) unsafeAtomicAdd(&tile[(n.y_high * W + n.x_high) * CS + cl], gv * n.w4);
+                    int lo, hi; float wl, wh;
+                    locate1(sample_coord(g.x1, pw, g.bin_w, ix, g.grid_w), W, &lo, &hi, &wl, &wh);
+                    if (lo >= 0) { Ax[lo][pw] += wl; Ax[hi][pw] += wh; }
+                }
+            }
+            __syncthreads();
+            float t1[RB_PMAX];
+#pragma unroll
+            for (int ph = 0; ph < RB_PMAX; ++ph) {
+                float t = 0.f;
+                if (ph < PH) {
+#pragma unroll
+                    for (int pw = 0; pw < RB_PMAX; ++pw)
+                        if (pw < PW) t = fmaf(gst[(ph * PW + pw) * RB_CS + ch], Ax[x][pw], t);
+                }
+                t1[ph] = t;
+            }
+#pragma unroll
+            for (int y = 0; y < RB_HMAX; ++y) {
+                if (y < H) {
+                    float t = 0.f;
+#pragma unroll
+                    for (int ph = 0; ph < RB_PMAX; ++ph)
+                        if (ph < PH) t = fmaf(Ay[y][ph], t1[ph], t);
+                    acc[y] += t;
                 }
             }
         }
     }
-    __syncthreads();
-    for (int i = threadIdx.x; i < cells * CS; i += 256) {
-        const int cell = i / CS, c = i - cell * CS;
-        st<T>(dfeat + ((int64_t)img * cells + cell) * C + c0 + c, tile[i]);
-    }
+#pragma unroll
+    for (int y = 0; y < RB_HMAX; ++y)
+        if (y < H) st<T>(dfeat + (((int64_t)img * H + y) * W + x) * C + c0 + ch, acc[y]);
 }
 
-// channel-slab width of the tile kernel for an H x W map (0: map too large for LDS, use the atomic kernel)
-static int roi_tile_cs(int C, int H, int W) {
-    for (int cs = 64; cs >= 8; cs >>= 1)
-        if ((size_t)H * W * cs * sizeof(float) <= 64 * 1024 && C % cs == 0) return cs;
-    return 0;
+// 1 when the separable kernel takes the shape (else: atomic kernel + cast)
+static int roi_sep_ok(int C, int H, int W, int PH, int PW) {
+    static const int mode = getenv("FOCUS_ROI_BWD") ? atoi(getenv("FOCUS_ROI_BWD")) : 1;
+    return mode != 0 && H <= RB_HMAX && W <= 16 && W >= 2 && PH <= RB_PMAX && PW <= RB_PMAX && PH * PW * RB_CS * 4 <= 56 * 1024 && C % RB_CS == 0;
 }
 
 __global__ void roi_indices_kernel(const float* __restrict__ rois, int32_t* __restrict__ grid,
@@ -207,8 +268,8 @@ extern "C" int focus_roi_align_fwd(const void* feat, int64_t img_stride, const f
     return FOCUS_OK;
 }
 
-extern "C" size_t focus_roi_align_bwd_workspace_bytes(int NI, int C, int H, int W) {
-    if (roi_tile_cs(C, H, W)) return 0;
+extern "C" size_t focus_roi_align_bwd_workspace_bytes(int NI, int C, int H, int W, int PH, int PW) {
+    if (roi_sep_ok(C, H, W, PH, PW)) return 0;
     return (size_t)NI * H * W * C * sizeof(float);
 }
 
@@ -218,20 +279,19 @@ extern "C" int focus_roi_align_bwd(const void* dout, const float* rois, const in
     if (!dout || !rois || !roi_img || !dfeat) return FOCUS_ERR_NULL;
     if ((C & 3) || PH <= 0 || PW <= 0 || K > 65535 || NI <= 0 || NI > 65535) return FOCUS_ERR_SHAPE;
     hipStream_t s = (hipStream_t)stream;
-    const int cs = roi_tile_cs(C, H, W);
-    if (cs) {
-        const size_t lds = (size_t)H * W * cs * sizeof(float);
-        dim3 grid(C / cs, NI);
+    if (roi_sep_ok(C, H, W, PH, PW)) {
+        dim3 grid(C / RB_CS, NI), blk(64 * W);
+        const size_t lds = (size_t)PH * PW * RB_CS * sizeof(float);
         if (dtype == FOCUS_BF16)
-            hipLaunchKernelGGL((roi_bwd_tile_kernel<bf16_t>), grid, dim3(256), lds, s, (const bf16_t*)dout, rois, roi_img,
-                               (bf16_t*)dfeat, C, H, W, K, PH, PW, scale, sr, aligned, cs);
+            hipLaunchKernelGGL((roi_bwd_sep_kernel<bf16_t>), grid, blk, lds, s, (const bf16_t*)dout, rois, roi_img,
+                               (bf16_t*)dfeat, C, H, W, K, PH, PW, scale, sr, aligned);
         else
-            hipLaunchKernelGGL((roi_bwd_tile_kernel<float>), grid, dim3(256), lds, s, (const float*)dout, rois, roi_img,
-                               (float*)dfeat, C, H, W, K, PH, PW, scale, sr, aligned, cs);
+            hipLaunchKernelGGL((roi_bwd_sep_kernel<float>), grid, blk, lds, s, (const float*)dout, rois, roi_img,
+                               (float*)dfeat, C, H, W, K, PH, PW, scale, sr, aligned);
         FOCUS_CHECK_LAUNCH();
         return FOCUS_OK;
     }
-    // large maps: fp32 atomics into a zeroed scratch map (or into dfeat itself when it is fp32), then one cast
+    // other shapes: fp32 atomics into a zeroed scratch map (or into dfeat itself when it is fp32), then one cast
     const size_t n = (size_t)NI * H * W * C;
     float* acc = dtype == FOCUS_F32 ? static_cast<float*>(dfeat) : static_cast<float*>(ws);
     if (dtype != FOCUS_F32 && (!ws || ws_bytes < n * sizeof(float))) return FOCUS_ERR_WORKSPACE;

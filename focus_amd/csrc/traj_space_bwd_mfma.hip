@@ -113,21 +113,6 @@ __global__ __launch_bounds__(256) void traj_delta_kernel(const bf16_t* __restric
     }
 }
 
-// vmcnt wait with a wave-uniform run-time count (0, 1, 2, ... 8; larger values wait for 8)
-__device__ __forceinline__ void wait_vmcnt(int n) {
-    switch (n) {
-        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-        case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
-        case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
-        case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
-        case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
-        case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
-        case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
-        case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
-        default: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
-    }
-}
-
 constexpr int MAXF = 16;     // frames the per-wave lse / delta tables are sized for
 
 // ------------------------------------------------------------------------------------------------
@@ -213,9 +198,16 @@ __global__ __launch_bounds__(256, 2) void traj_dq_kernel(const bf16_t* __restric
         for (int kb = 0; kb < NKB; ++kb, ++t) {
             // ---- step t landed?  instructions issued after it: steps t+1, t+2 (2 each) and, for kb = 1..3, the
             // 4 dX instructions of frame f+1 issued at kb = 0 ----
-            const int ahead = 2 * min(2, T - 1 - t);
-            if (kb == 0) wait_vmcnt(NKB >= 4 ? ahead : 0);
-            else wait_vmcnt(ahead + ((kb <= 3 && more) ? 4 : 0));
+            // (spelled out as compile-time counts: a run-time switch here cost a maze of ~100 scalar instructions per step)
+            if (t + 2 < T) {
+                if (kb == 0) { if (NKB >= 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+                else if (kb <= 3 && more) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            } else if (t + 1 < T && NKB >= 4) {
+                asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();          // step t visible to all; everyone is done with stage (t-1) & 3
             if (kb == 0) {
@@ -332,7 +324,7 @@ __global__ __launch_bounds__(64 * NKB) void traj_dkv_kernel(const bf16_t* __rest
     const int drow = lane >> 3, dkey = ((drow & 2) << 1) | ((drow >> 1) & 2), dchunk = lane & 7;
     const uint32_t ring_a = lds_addr_of(ring);
     constexpr int MINE = (9 + NKB - 1) / NKB;              // upper bound of DMA instructions per wave per step
-    const int mine = (9 - w + NKB - 1) / NKB;              // this wave's count: instructions w, w+NKB, ... < 9
+    constexpr int MINE_MIN = 9 / NKB > 4 ? 4 : 9 / NKB;    // every wave issues at least this many (waves w < 9 % NKB one more); capped: vmcnt(N) <= 8
     auto dma_chunk = [&](int ch) __attribute__((always_inline)) {
         const uint32_t st = ring_a + (ch & 3) * 8192;
 #pragma unroll
@@ -360,7 +352,11 @@ __global__ __launch_bounds__(64 * NKB) void traj_dkv_kernel(const bf16_t* __rest
     if (nchunk > 2) dma_chunk(2);
 
     for (int ch = 0; ch < nchunk; ++ch) {
-        wait_vmcnt(mine * min(2, nchunk - 1 - ch));
+        // every wave issued at least MINE_MIN instructions per chunk: waiting down to that many per chunk still in
+        // flight is exact for the waves that issued MINE_MIN and slightly early-safe for the others
+        if (ch + 2 < nchunk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * MINE_MIN) : "memory");
+        else if (ch + 1 < nchunk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(MINE_MIN) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();              // chunk ch visible to all; everyone is done with stage (ch-1) & 3
         if (ch + 3 < nchunk) dma_chunk(ch + 3);

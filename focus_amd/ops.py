@@ -754,7 +754,7 @@ class _RoiAlignFn(torch.autograd.Function):
         dout = dout.contiguous()
         L = _lib.lib()
         dfeat = torch.empty(NI, H * W, C, device=dout.device, dtype=dt)
-        nb = L.focus_roi_align_bwd_workspace_bytes(NI, C, H, W)
+        nb = L.focus_roi_align_bwd_workspace_bytes(NI, C, H, W, PH, PW)
         ws = torch.empty(nb // 4, device=dout.device, dtype=torch.float32) if nb else None
         _lib.check(L.focus_roi_align_bwd(_p(dout), _p(rois), _p(roi_img), _p(dfeat), _p(ws), nb, NI, C, H, W, K, PH, PW,
                                          scale, sr, al, _dt(dout), _stream()), "roi_align_bwd")

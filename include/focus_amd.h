@@ -176,10 +176,10 @@ int focus_traj_time2_bwd(const void* u, const void* xt, const float* attn2, cons
 int focus_roi_align_fwd(const void* feat, int64_t img_stride, const float* rois, const int32_t* roi_img,
                         void* out, int NI, int C, int H, int W, int K, int PH, int PW, float spatial_scale,
                         int sampling_ratio, int aligned, int dtype, void* stream);
-/* dfeat [NI, H*W, C] dense, `dtype`, fully written (no zero-initialisation needed): maps that fit a workgroup's LDS
- * in channel slabs (H*W <= 2048) are accumulated there without global atomics; larger ones go through fp32 atomics
- * into `ws` (focus_roi_align_bwd_workspace_bytes, 0 for the LDS path) and one cast. */
-size_t focus_roi_align_bwd_workspace_bytes(int NI, int C, int H, int W);
+/* dfeat [NI, H*W, C] dense, `dtype`, fully written (no zero-initialisation needed).  Maps up to 16x16 with up to
+ * 14x14 bins use the separable form dfeat = sum_rois Ay . dout . Ax^T (no atomics, accumulators in registers); other
+ * shapes go through fp32 atomics into `ws` (focus_roi_align_bwd_workspace_bytes, 0 for the separable path) + a cast. */
+size_t focus_roi_align_bwd_workspace_bytes(int NI, int C, int H, int W, int PH, int PW);
 int focus_roi_align_bwd(const void* dout, const float* rois, const int32_t* roi_img, void* dfeat, void* ws,
                         size_t ws_bytes, int NI, int C, int H, int W, int K, int PH, int PW, float spatial_scale,
                         int sampling_ratio, int aligned, int dtype, void* stream);
