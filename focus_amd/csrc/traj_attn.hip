@@ -6,6 +6,7 @@
 //     workspace and runs strided batched GEMMs + per-frame row softmax -- the unfused decomposition the
 //     reference executes, kept as the precision path.  The fused MFMA kernel lives in traj_space_mfma.hip.
 #include "focus_common.h"
+#include <cstdlib>
 #include "gemm_internal.h"
 #include "softmax_internal.h"
 #include "traj_internal.h"
@@ -116,6 +117,137 @@ __global__ __launch_bounds__(256) void time_bwd_kernel(const T* __restrict__ q2,
         }
         if (act) st4<T>(dq2 + row * C + c, dq);
     }
+}
+
+// ---- bf16, head dim 64, F <= 16: 8 channels (16 bytes) per thread, a head = 8 adjacent lanes, thread = (row, 8-channel
+// group) in memory order (C/8 threads per row; groups of 8 lanes never straddle a wave since C/8 % 8 == 0).
+// Every load and store is 16 bytes and all 2F (fwd) / F (bwd) loads of a thread are in flight at once.
+union Pk8 { uint4 u; bf16_t e[8]; };
+__device__ __forceinline__ void unpack8(const uint4& r, float* v) {
+    v[0] = __uint_as_float(r.x << 16); v[1] = __uint_as_float(r.x & 0xffff0000u);
+    v[2] = __uint_as_float(r.y << 16); v[3] = __uint_as_float(r.y & 0xffff0000u);
+    v[4] = __uint_as_float(r.z << 16); v[5] = __uint_as_float(r.z & 0xffff0000u);
+    v[6] = __uint_as_float(r.w << 16); v[7] = __uint_as_float(r.w & 0xffff0000u);
+}
+__device__ __forceinline__ uint4 pack8(const float* v) {
+    uint4 o;
+    o.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
+    o.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
+    o.z = (uint32_t)f32_to_bf16(v[4]) | ((uint32_t)f32_to_bf16(v[5]) << 16);
+    o.w = (uint32_t)f32_to_bf16(v[6]) | ((uint32_t)f32_to_bf16(v[7]) << 16);
+    return o;
+}
+__device__ __forceinline__ float sum8lanes(float v) {
+    v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64);
+    return v;
+}
+
+template <int FT>
+__global__ __launch_bounds__(256) void time_fwd_vec_kernel(const bf16_t* __restrict__ q2, const bf16_t* __restrict__ k2,
+                                                           const bf16_t* __restrict__ xt, bf16_t* __restrict__ out,
+                                                           float* __restrict__ attn2, int64_t ngroups, int S, int heads,
+                                                           float scale) {
+    const int64_t gi = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const bool act = gi < ngroups;
+    const int64_t g = act ? gi : ngroups - 1;
+    const int gpr = heads * 8;                                   // 8-channel groups per row
+    const int64_t row = g / gpr;
+    const int cg = (int)(g - row * gpr);
+    const int C = gpr * 8;
+    uint4 kr[FT], xr[FT];
+#pragma unroll
+    for (int f = 0; f < FT; ++f) {
+        kr[f] = *reinterpret_cast<const uint4*>(k2 + ((row * FT + f) * C) + cg * 8);
+        xr[f] = *reinterpret_cast<const uint4*>(xt + ((row * FT + f) * C) + cg * 8);
+    }
+    float q[8];
+    unpack8(*reinterpret_cast<const uint4*>(q2 + row * C + cg * 8), q);
+    float lg[FT], m = -INFINITY;
+#pragma unroll
+    for (int f = 0; f < FT; ++f) {
+        float kv[8];
+        unpack8(kr[f], kv);
+        float p = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) p = fmaf(q[e], kv[e], p);
+        lg[f] = scale * sum8lanes(p);
+        m = fmaxf(m, lg[f]);
+    }
+    float den = 0.f;
+#pragma unroll
+    for (int f = 0; f < FT; ++f) { lg[f] = __expf(lg[f] - m); den += lg[f]; }
+    const float inv = 1.f / den;
+    float o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const int64_t b = row / S;
+    const int s = (int)(row - b * S);
+    float* arow = attn2 + (((b * heads + (cg >> 3)) * S + s) * FT);
+#pragma unroll
+    for (int f = 0; f < FT; ++f) {
+        const float a = lg[f] * inv;
+        float xv[8];
+        unpack8(xr[f], xv);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = fmaf(a, xv[e], o[e]);
+        if (act && (cg & 7) == 0) arow[f] = a;
+    }
+    if (act) *reinterpret_cast<uint4*>(out + row * C + cg * 8) = pack8(o);
+}
+
+template <int FT>
+__global__ __launch_bounds__(256) void time_bwd_vec_kernel(const bf16_t* __restrict__ q2, const bf16_t* __restrict__ k2,
+                                                           const bf16_t* __restrict__ xt, const float* __restrict__ attn2,
+                                                           const bf16_t* __restrict__ dout, bf16_t* __restrict__ dq2,
+                                                           bf16_t* __restrict__ dk2, bf16_t* __restrict__ dxt,
+                                                           int64_t ngroups, int S, int heads, float scale) {
+    const int64_t gi = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const bool act = gi < ngroups;
+    const int64_t g = act ? gi : ngroups - 1;
+    const int gpr = heads * 8;
+    const int64_t row = g / gpr;
+    const int cg = (int)(g - row * gpr);
+    const int C = gpr * 8;
+    const int64_t b = row / S;
+    const int s = (int)(row - b * S);
+    uint4 xr[FT], kr[FT];
+#pragma unroll
+    for (int f = 0; f < FT; ++f) {
+        xr[f] = *reinterpret_cast<const uint4*>(xt + ((row * FT + f) * C) + cg * 8);
+        kr[f] = *reinterpret_cast<const uint4*>(k2 + ((row * FT + f) * C) + cg * 8);
+    }
+    float gv[8], q[8];
+    unpack8(*reinterpret_cast<const uint4*>(dout + row * C + cg * 8), gv);
+    unpack8(*reinterpret_cast<const uint4*>(q2 + row * C + cg * 8), q);
+    const float* arow = attn2 + (((b * heads + (cg >> 3)) * S + s) * FT);
+    float a[FT], da[FT], dot = 0.f;
+#pragma unroll
+    for (int f = 0; f < FT; ++f) {
+        a[f] = arow[f];
+        float xv[8], dx[8];
+        unpack8(xr[f], xv);
+        float p = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { p = fmaf(gv[e], xv[e], p); dx[e] = a[f] * gv[e]; }
+        if (act) *reinterpret_cast<uint4*>(dxt + ((row * FT + f) * C) + cg * 8) = pack8(dx);
+        da[f] = sum8lanes(p);
+        dot = fmaf(a[f], da[f], dot);
+    }
+    float dq[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int f = 0; f < FT; ++f) {
+        const float dl = scale * a[f] * (da[f] - dot);
+        float kv[8], dk[8];
+        unpack8(kr[f], kv);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { dq[e] = fmaf(dl, kv[e], dq[e]); dk[e] = dl * q[e]; }
+        if (act) *reinterpret_cast<uint4*>(dk2 + ((row * FT + f) * C) + cg * 8) = pack8(dk);
+    }
+    if (act) *reinterpret_cast<uint4*>(dq2 + row * C + cg * 8) = pack8(dq);
+}
+
+static bool time_vec_ok(const void* a, const void* b, const void* c, int F, int d, int dtype) {
+    static const bool enabled = !(getenv("FOCUS_TIME_VEC") && atoi(getenv("FOCUS_TIME_VEC")) == 0);
+    return enabled && dtype == FOCUS_BF16 && d == 64 && (F == 8 || F == 4 || F == 16) && focus_aligned(a, 16) &&
+           focus_aligned(b, 16) && focus_aligned(c, 16);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -365,6 +497,15 @@ extern "C" int focus_traj_time_fwd(const void* q2, const void* k2, const void* x
     const int64_t rows = (int64_t)B * S;
     if (rows <= 0) return FOCUS_OK;
     const float scale = 1.f / sqrtf((float)d);
+    if (time_vec_ok(q2, k2, xt, F, d, dtype) && focus_aligned(out, 16)) {
+        const int64_t ng = rows * heads * 8;
+        dim3 gv((unsigned)cdiv64(ng, 256));
+#define TFV(FT) hipLaunchKernelGGL((time_fwd_vec_kernel<FT>), gv, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)q2, (const bf16_t*)k2, (const bf16_t*)xt, (bf16_t*)out, attn2, ng, S, heads, scale)
+        if (F == 8) TFV(8); else if (F == 4) TFV(4); else TFV(16);
+#undef TFV
+        FOCUS_CHECK_LAUNCH();
+        return FOCUS_OK;
+    }
     dim3 grid((unsigned)cdiv64(rows, 4));
 #define TF(T, FT) hipLaunchKernelGGL((time_fwd_kernel<T, FT>), grid, dim3(256), 0, (hipStream_t)stream, (const T*)q2, (const T*)k2, (const T*)xt, (T*)out, attn2, rows, S, F, heads, d, scale)
     if (dtype == FOCUS_BF16) { if (F == 8) TF(bf16_t, 8); else TF(bf16_t, 0); }
@@ -382,6 +523,16 @@ extern "C" int focus_traj_time_bwd(const void* q2, const void* k2, const void* x
     const int64_t rows = (int64_t)B * S;
     if (rows <= 0) return FOCUS_OK;
     const float scale = 1.f / sqrtf((float)d);
+    if (!dxt_accum && time_vec_ok(q2, k2, xt, F, d, dtype) && focus_aligned(dout, 16) && focus_aligned(dq2, 16) &&
+        focus_aligned(dk2, 16) && focus_aligned(dxt, 16)) {
+        const int64_t ng = rows * heads * 8;
+        dim3 gv((unsigned)cdiv64(ng, 256));
+#define TBV(FT) hipLaunchKernelGGL((time_bwd_vec_kernel<FT>), gv, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)q2, (const bf16_t*)k2, (const bf16_t*)xt, attn2, (const bf16_t*)dout, (bf16_t*)dq2, (bf16_t*)dk2, (bf16_t*)dxt, ng, S, heads, scale)
+        if (F == 8) TBV(8); else if (F == 4) TBV(4); else TBV(16);
+#undef TBV
+        FOCUS_CHECK_LAUNCH();
+        return FOCUS_OK;
+    }
     dim3 grid((unsigned)cdiv64(rows, 4));
 #define TB(T, FT) hipLaunchKernelGGL((time_bwd_kernel<T, FT>), grid, dim3(256), 0, (hipStream_t)stream, (const T*)q2, (const T*)k2, (const T*)xt, attn2, (const T*)dout, (T*)dq2, (T*)dk2, (T*)dxt, dxt_accum, rows, S, F, heads, d, scale)
     if (dtype == FOCUS_BF16) { if (F == 8) TB(bf16_t, 8); else TB(bf16_t, 0); }
