@@ -209,6 +209,41 @@ __global__ __launch_bounds__(256) void rows_reduce_kernel(const float* __restric
     }
 }
 
+// both reductions of focus_linear_wgrad in one launch: blocks [0, nb_main) sum the dW slabs, the rest the bias partials
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ parts, float* __restrict__ out, int64_t n4,
+                                                           int splits, int N, int64_t rsC, int nb_main,
+                                                           const float* __restrict__ bparts, float* __restrict__ bout, int bn4,
+                                                           int brows) {
+    if ((int)blockIdx.x < nb_main) {
+        const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+        if (i >= n4) return;
+        float4 s = reinterpret_cast<const float4*>(parts)[i];
+        for (int k = 1; k < splits; ++k) {
+            const float4 v = reinterpret_cast<const float4*>(parts)[(int64_t)k * n4 + i];
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+        const int64_t e = i * 4, row = e / N, col = e % N;
+        *reinterpret_cast<float4*>(out + row * rsC + col) = s;
+        return;
+    }
+    __shared__ float4 red[16][16];
+    const int c = threadIdx.x & 15, rr = threadIdx.x >> 4;
+    const int col = ((int)blockIdx.x - nb_main) * 16 + c;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (col < bn4)
+        for (int r = rr; r < brows; r += 16) {
+            const float4 v = reinterpret_cast<const float4*>(bparts)[(int64_t)r * bn4 + col];
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+    red[rr][c] = s;
+    __syncthreads();
+    if (rr == 0 && col < bn4) {
+#pragma unroll
+        for (int k = 1; k < 16; ++k) { const float4 v = red[k][c]; s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w; }
+        reinterpret_cast<float4*>(bout)[col] = s;
+    }
+}
+
 struct TnPlan { int tiles_i, tiles_j, splits, m_per_split; };
 TnPlan tn_plan(int M, int N, int K) {
     TnPlan p;
@@ -303,11 +338,9 @@ extern "C" int focus_linear_wgrad(const void* dy, const void* x, float* dw, floa
         int rc = focus_gemm_mfma_tn_ws(d, pl, csum, s);
         if (rc != FOCUS_OK) return rc;
         const int64_t n4 = (int64_t)N * K / 4;
-        hipLaunchKernelGGL(tn_reduce_kernel, dim3((unsigned)cdiv64(n4, 256)), dim3(256), 0, s, (const float*)ws, dw, n4,
-                           pl.splits, K, (int64_t)K);
-        FOCUS_CHECK_LAUNCH();
-        hipLaunchKernelGGL(rows_reduce_kernel, dim3((unsigned)cdiv64(N / 4, 16)), dim3(256), 0, s, (const float*)csum, db,
-                           N / 4, pl.splits * pl.tiles_j);
+        const int nb_main = (int)cdiv64(n4, 256), nb_bias = (int)cdiv64(N / 4, 16);
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(nb_main + nb_bias), dim3(256), 0, s, (const float*)ws, dw, n4, pl.splits,
+                           K, (int64_t)K, nb_main, (const float*)csum, db, N / 4, pl.splits * pl.tiles_j);
         FOCUS_CHECK_LAUNCH();
         return FOCUS_OK;
     }

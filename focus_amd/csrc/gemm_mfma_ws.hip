@@ -33,12 +33,12 @@ struct Unit { int m0, n0, nk; };
 // BM = 128: 4 consumer waves (2x2 of 64x64) + 4 loaders, 96 KiB ring.
 // BM = 256: 8 consumer waves (4x2 of 64x64) + 4 loaders, 144 KiB ring (85 flop per LDS-filled byte instead of 64;
 //           two consumer waves per SIMD overlap each other's ds_read latency).
-template <int BM, int BN, int EPI>
-__global__ __launch_bounds__(64 * (BM * BN / 4096 + 4)) void gemm_nt_ws_kernel(const focus_gemm_desc d, int tiles_m, int tiles_n, int GM) {
+template <int BM, int BN, int EPI, int NLOAD>
+__global__ __launch_bounds__(64 * (BM * BN / 4096 + NLOAD)) void gemm_nt_ws_kernel(const focus_gemm_desc d, int tiles_m, int tiles_n, int GM) {
     constexpr int NCONS = BM * BN / 4096;                        // consumer waves (64x64 each)
     constexpr int WN = BN / 64;                                  // consumer grid is (BM/64) x WN
     constexpr int A_BYTES = BM * 128, STAGE = (BM + BN) * 128;   // bytes per ring stage
-    constexpr int GA = BM / 8 / 4, GB = BN / 8 / 4;              // DMA pieces per loader wave per K-step
+    constexpr int GA = BM / 8 / NLOAD, GB = BN / 8 / NLOAD;      // DMA pieces per loader wave per K-step
     constexpr int PIECES = GA + GB;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int z = blockIdx.y;
@@ -263,12 +263,12 @@ bool focus_gemm_mfma_ws_ok(const focus_gemm_desc& d) {
     return true;
 }
 
-template <int BM, int BN, int EPI>
-static int launch_ws(const focus_gemm_desc& d, hipStream_t s) {
+template <int BM, int BN, int EPI, int NLOAD>
+static int launch_ws_n(const focus_gemm_desc& d, hipStream_t s) {
     const int tiles_m = (d.M + BM - 1) / BM, tiles_n = (d.N + BN - 1) / BN;
     const int nbatch = d.batch0 * d.batch1;
     const size_t lds = (size_t)NSTAGE * (BM + BN) * 128;
-    auto k = gemm_nt_ws_kernel<BM, BN, EPI>;
+    auto k = gemm_nt_ws_kernel<BM, BN, EPI, NLOAD>;
     static bool once = (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds) == hipSuccess);
     (void)once;
     const int nunits = tiles_m * tiles_n;
@@ -279,9 +279,18 @@ static int launch_ws(const focus_gemm_desc& d, hipStream_t s) {
     // wide outputs use 8-row-tile-deep groups so an XCD's resident tiles share A and B panels in its L2.
     static const int gm_env = getenv("FOCUS_GEMM_GM") ? std::max(1, atoi(getenv("FOCUS_GEMM_GM"))) : 0;
     const int gm = gm_env ? gm_env : (tiles_n <= 4 ? 1 : 8);
-    hipLaunchKernelGGL(k, grid, dim3(64 * (BM * BN / 4096 + 4)), lds, s, d, tiles_m, tiles_n, gm);
+    hipLaunchKernelGGL(k, grid, dim3(64 * (BM * BN / 4096 + NLOAD)), lds, s, d, tiles_m, tiles_n, gm);
     FOCUS_CHECK_LAUNCH();
     return FOCUS_OK;
+}
+
+template <int BM, int BN, int EPI>
+static int launch_ws(const focus_gemm_desc& d, hipStream_t s) {
+    // loader waves per workgroup: the LDS-DMA issue rate of the loaders, not the MFMA rate, bounds a K-step
+    // (~2.2k clocks per K-step with 4 loaders x 12 pieces against 1k clocks of MFMA); FOCUS_GEMM_NLOAD=4|8 for tuning
+    static const int nload = getenv("FOCUS_GEMM_NLOAD") ? atoi(getenv("FOCUS_GEMM_NLOAD")) : 4;
+    if (nload == 8) return launch_ws_n<BM, BN, EPI, 8>(d, s);
+    return launch_ws_n<BM, BN, EPI, 4>(d, s);
 }
 
 template <int BM, int BN>

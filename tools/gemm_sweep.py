@@ -1,5 +1,5 @@
 """Times the bf16 MFMA GEMM on the hot-path shapes (random data) for each tuning variant.
-usage (GPU box): python tools/gemm_sweep.py  -- spawns one subprocess per FOCUS_GEMM_VARIANT."""
+usage (GPU box): python tools/gemm_sweep.py [4 8]  -- spawns one subprocess per FOCUS_GEMM_NLOAD value."""
 import os
 import subprocess
 import sys
@@ -44,6 +44,6 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "worker":
         worker()
     else:
-        for v in (sys.argv[1:] or ["0", "1", "2", "3", "4", "5", "6"]):
-            env = dict(os.environ, FOCUS_GEMM_VARIANT=v)
+        for v in (sys.argv[1:] or ["4", "8"]):          # loader waves per workgroup (FOCUS_GEMM_NLOAD)
+            env = dict(os.environ, FOCUS_GEMM_NLOAD=v, FOCUS_GEMM_VARIANT=v)
             subprocess.call([sys.executable, os.path.abspath(__file__), "worker"], env=env)
