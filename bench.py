@@ -165,7 +165,7 @@ def main():
                    "parallelism": "dp%d" % world, "optimizer": "adamw+clipnorm", "drop_path": cfg.MF.DROP_PATH},
         "clips_per_sec_per_gpu": round(value / world, 3),
         "model_mfma_frac_algorithmic": round(value / world * ALG_GF_PER_CLIP * 1e9 / (PEAK_BF16_TFLOPS * 1e12), 5),
-        "final_loss": round(float(loss), 4),
+        "final_loss": round(float(loss.detach()), 4),
     }
 
     if rank == 0 and not args.no_roofline and not args.fp32:

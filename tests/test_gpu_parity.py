@@ -569,3 +569,107 @@ def test_weight_grad_gemm_ws(shape):
     assert db.shape == (N,) and rel(db, dy.double().sum(0).float()) < 1e-5
     dw2, db2 = ops.linear_wgrad(dy, x, False)
     assert db2 is None and rel(dw2, want) < 1e-5
+
+
+@pytest.mark.parametrize("F_,P", [(4, 9), (16, 5), (8, 33), (3, 40)])
+def test_trajectory_attention_frame_counts(oracle, F_, P):
+    """Frame counts other than the bench's 8: F = 4 / 16 take the vectorised time kernels and the DMA-ring space
+    kernels with 1-2 key blocks, F = 3 the generic time kernel; P = 33 and 40 leave a ragged last key block."""
+    from focus_amd.slowfast.models.attention import TrajectoryAttention
+    g = torch.Generator().manual_seed(100 * F_ + P)
+    C, heads, B = 128, 2, 2
+    m = TrajectoryAttention(C, num_heads=heads, qkv_bias=True)
+    with torch.no_grad():
+        for prm in m.parameters():
+            prm.copy_(0.08 * torch.randn(prm.shape, generator=g))
+    x = torch.randn(B, 1 + F_ * P, C, generator=g)
+    ct = torch.randn(B, 1 + F_ * P, C, generator=g)
+    p = {("." + k): v.detach().clone().requires_grad_() for k, v in m.state_dict().items()}
+    xr = x.clone().requires_grad_()
+    ref = oracle.trajectory_attention(p, "", xr, [F_, P, 1], heads)
+    (ref * ct).sum().backward()
+    m = m.to(dev())
+    for dtype in DTYPES:
+        m.zero_grad()
+        xg = x.to(dev(), dtype).requires_grad_()
+        y, _ = m(xg, [F_, P, 1])
+        (y.float() * ct.to(dev())).sum().backward()
+        close(y, ref, TOL[dtype], "y F=%d P=%d" % (F_, P))
+        close(xg.grad, xr.grad, TOL[dtype] * 2, "dx")
+        for name in ("qkv.weight", "proj_q.weight", "proj_kv.weight", "proj.weight", "qkv.bias"):
+            gref = p["." + name].grad
+            close(dict(m.named_parameters())[name].grad, gref, TOL[dtype] * 3, "d" + name,
+                  floor=max(1e-3, 1e-2 * float(gref.abs().max())))
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("H,W,PH,PW", [(14, 14, 14, 14), (14, 14, 7, 7), (16, 16, 8, 5), (7, 9, 7, 9)])
+def test_roi_align_separable_backward(oracle, dtype, H, W, PH, PW):
+    """The separable backward (Ay . dout . Ax^T, channel count a multiple of 64) against the oracle's scatter form,
+    with degenerate, off-map and whole-map boxes and several RoIs (or none) per image."""
+    from focus_amd import ops
+    g = torch.Generator().manual_seed(H * 100 + PH)
+    NI, C, K = 5, 128, 17
+    feat = torch.randn(NI, C, H, W, generator=g)
+    if dtype == torch.bfloat16:
+        feat = feat.bfloat16().float()
+    size = 16.0 * max(H, W)
+    rois = _rand_rois(g, K, size)
+    rois[0] = torch.tensor([0.0, 0.0, size, size])                   # whole map
+    rois[1] = torch.tensor([30.0, 40.0, 30.0, 40.0])                 # zero area
+    rois[2] = torch.tensor([-50.0, -60.0, 20.0, 25.0])               # partly off the map
+    rois[3] = torch.tensor([size + 40.0, size + 40.0, size + 90.0, size + 80.0])   # entirely off the map
+    img = torch.randint(0, NI - 1, (K,), generator=g, dtype=torch.int32)            # image NI-1 gets no RoI
+    fr = feat.clone().requires_grad_()
+    ref = oracle.roi_align(fr, rois, img, (PH, PW), 1 / 16, -1, True)
+    ct = torch.randn(ref.shape, generator=g)
+    (ref * ct).sum().backward()
+    d = dev()
+    ft = feat.permute(0, 2, 3, 1).reshape(NI, H * W, C).to(d, dtype).requires_grad_()
+    out = ops.roi_align_tokens(ft, rois.to(d), img.to(d), H, W, PH, PW, 1 / 16, -1, True)
+    (out.view(K, PH, PW, C).permute(0, 3, 1, 2).float() * ct.to(d)).sum().backward()
+    got = ft.grad.view(NI, H, W, C).permute(0, 3, 1, 2)
+    close(got, fr.grad, 1e-4 if dtype == torch.float32 else 2e-2, "dfeat separable")
+    assert float(got[NI - 1].abs().max()) == 0.0                     # untouched image: written, and exactly zero
+
+
+def test_cell_amax_vectorised():
+    """Max over the cells of each RoI (orvit.py:138): vectorised bf16 kernels against torch, ties included."""
+    from focus_amd import ops
+    g = torch.Generator().manual_seed(9)
+    K, cells, C = 6, 50, 768
+    x = torch.randn(K, cells, C, generator=g).bfloat16()
+    x[0, 7] = x[0, 3]                                                 # exact ties: the first cell wins
+    xg = x.to(dev()).requires_grad_()
+    y = ops.cell_amax(xg)
+    ref = x.float().amax(dim=1)
+    assert torch.equal(y.float().cpu(), ref)
+    ct = torch.randn(K, C, generator=g).bfloat16()
+    y.backward(ct.to(dev()))
+    arg = x.float().argmax(dim=1)                                     # first maximal index
+    want = torch.zeros(K, cells, C)
+    want.scatter_(1, arg.unsqueeze(1), ct.float().unsqueeze(1))
+    assert torch.equal(xg.grad.float().cpu(), want)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_layer_norm_fork_adds_residual_gradient(dtype):
+    """layer_norm_fork returns (x, LN(x)); the gradient arriving on the x output is added inside the LN backward."""
+    from focus_amd import ops
+    g = torch.Generator().manual_seed(4)
+    rows, D = 333, 192
+    x = torch.randn(rows, D, generator=g)
+    w, b = torch.randn(D, generator=g), torch.randn(D, generator=g)
+    c1, c2 = torch.randn(rows, D, generator=g), torch.randn(rows, D, generator=g)
+    xr, wr, br = x.clone().requires_grad_(), w.clone().requires_grad_(), b.clone().requires_grad_()
+    ref = torch.nn.functional.layer_norm(xr, (D,), wr, br, 1e-6)
+    ((ref * c1).sum() + (xr * c2).sum()).backward()
+    d = dev()
+    xg = x.to(d, dtype).requires_grad_()
+    wg, bg = w.to(d).requires_grad_(), b.to(d).requires_grad_()
+    xres, h = ops.layer_norm_fork(xg, wg, bg, 1e-6)
+    ((h.float() * c1.to(d)).sum() + (xres.float() * c2.to(d)).sum()).backward()
+    close(h, ref, TOL[dtype], "ln fork out")
+    close(xg.grad, xr.grad, TOL[dtype], "ln fork dx")
+    close(wg.grad, wr.grad, TOL[dtype], "ln fork dgamma")
+    close(bg.grad, br.grad, TOL[dtype], "ln fork dbeta")
