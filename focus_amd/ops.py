@@ -148,6 +148,37 @@ def mm_tn(a, b):
     return c
 
 
+# Weight gradients on a second HIP stream (opt-in, FOCUS_SIDE_STREAM=1): dW (TN GEMM + reduce) and dX (NT GEMM) of a
+# Linear are independent, and both kernels run one persistent workgroup per CU, so each leaves CUs idle in its last
+# round of tiles; on separate streams the other kernel's workgroups can fill them.  Measured on the bench step it
+# LOSES 4-5 % (195 vs 204 clips/s, A/B on one box: the two kernels evict each other's operand panels from L2), so the
+# default keeps everything on the current stream.
+import os as _os
+_SIDE_ON = _os.environ.get("FOCUS_SIDE_STREAM", "0") == "1"
+_side_streams = {}
+
+
+def wgrad_async(dy, x, want_bias):
+    """linear_wgrad on the side stream -> (dw, db, join); call join() before the results are handed to autograd."""
+    if not _SIDE_ON or GEMM_TIMING is not None or not dy.is_cuda:
+        dw, db = linear_wgrad(dy, x, want_bias)
+        return dw, db, (lambda: None)
+    main = torch.cuda.current_stream()
+    side = _side_streams.get(dy.device)
+    if side is None:
+        side = _side_streams[dy.device] = torch.cuda.Stream(device=dy.device)
+    side.wait_stream(main)                       # dy / x were produced on the main stream
+    with torch.cuda.stream(side):
+        dw, db = linear_wgrad(dy, x, want_bias)
+    for t in (dw, db):
+        if t is not None:
+            t.record_stream(main)                # allocated on the side stream, consumed on the main one
+
+    def join():
+        main.wait_stream(side)
+    return dw, db, join
+
+
 def linear_wgrad(dy, x, want_bias):
     """(dw [N,K] fp32, db [N] fp32 or None) for y = x @ w^T + b from dy [M,N], x [M,K]: one pass over dy
     (focus_linear_wgrad: the bias gradient rides on the weight-gradient GEMM's matrix pipe)."""
@@ -294,13 +325,16 @@ class _LinearFn(torch.autograd.Function):
         if not dy2.is_contiguous():
             dy2 = dy2.contiguous()
         dx = dw = db = None
-        if ctx.needs_input_grad[0]:
-            dx = _dx_from(dy2, w, dy2.dtype).reshape(ctx.shp)
+        join = None
         want_b = ctx.has_b and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
-            dw, db = linear_wgrad(dy2, x2, want_b)
+            dw, db, join = wgrad_async(dy2, x2, want_b)
         elif want_b:
             db = colsum(dy2)
+        if ctx.needs_input_grad[0]:
+            dx = _dx_from(dy2, w, dy2.dtype).reshape(ctx.shp)
+        if join is not None:
+            join()
         return dx, dw, db, (dy if ctx.has_r else None)
 
 
@@ -334,17 +368,21 @@ class _MlpFn(torch.autograd.Function):
         dy2 = dy.reshape(-1, w2.shape[0])
         if not dy2.is_contiguous():
             dy2 = dy2.contiguous()
+        join2 = join1 = None
         if ctx.needs_input_grad[3]:
-            dw2, db2 = linear_wgrad(dy2, a, ctx.has[1])
+            dw2, db2, join2 = wgrad_async(dy2, a, ctx.has[1])
         else:
             dw2, db2 = None, (colsum(dy2) if ctx.has[1] else None)
         # dz = (dy . w2) * act'(.) fused in the GEMM epilogue
         dz = _dx_from(dy2, w2, dy2.dtype, aux=(z if ctx.act == EPI_GELU else a), epilogue=_DEPI[ctx.act])
         if ctx.needs_input_grad[1]:
-            dw1, db1 = linear_wgrad(dz, x2, ctx.has[0])
+            dw1, db1, join1 = wgrad_async(dz, x2, ctx.has[0])
         else:
             dw1, db1 = None, (colsum(dz) if ctx.has[0] else None)
         dx = _dx_from(dz, w1, dz.dtype).reshape(ctx.shp) if ctx.needs_input_grad[0] else None
+        for j in (join2, join1):
+            if j is not None:
+                j()
         return dx, dw1, db1, dw2, db2, (dy if ctx.has[2] else None), None
 
 
@@ -577,15 +615,10 @@ class _TrajTimeBlockFn(torch.autograd.Function):
                                                   _p(dxt_a), 0, B, S, F_, ctx.heads, C // ctx.heads, _dt(xt),
                                                   _stream()), "traj_time_bwd")
         dk2f, xt2 = dk2.view(-1, C), xt.view(-1, C)
-        dw = db = None
+        dw = db = dwk = dbk = None
+        join = None
         if ctx.needs_input_grad[2]:
-            dwk, dbk = linear_wgrad(dk2f, xt2, ctx.has_b and ctx.needs_input_grad[3])
-            dw = torch.empty(2 * C, C, device=xt.device, dtype=torch.float32)
-            dw[:C].copy_(dwk)
-            dw[C:].zero_()                      # v2 half: no output use, exactly zero gradient
-            if dbk is not None:
-                db = torch.zeros(2 * C, device=xt.device, dtype=torch.float32)
-                db[:C].copy_(dbk)
+            dwk, dbk, join = wgrad_async(dk2f, xt2, ctx.has_b and ctx.needs_input_grad[3])
         dxt = None
         if ctx.needs_input_grad[1]:
             if xt.dtype == torch.bfloat16 and C % 64 == 0:
@@ -594,6 +627,15 @@ class _TrajTimeBlockFn(torch.autograd.Function):
             else:
                 dxt = mm_nn(dk2f, shadow(w_kv, xt.dtype)[:C]).add_(dxt_a.view(-1, C))
             dxt = dxt.view(B, S, F_, C)
+        if join is not None:
+            join()
+        if dwk is not None:
+            dw = torch.empty(2 * C, C, device=xt.device, dtype=torch.float32)
+            dw[:C].copy_(dwk)
+            dw[C:].zero_()                      # v2 half: no output use, exactly zero gradient
+            if dbk is not None:
+                db = torch.zeros(2 * C, device=xt.device, dtype=torch.float32)
+                db[:C].copy_(dbk)
         return dq2, dxt, dw, db, None
 
 
