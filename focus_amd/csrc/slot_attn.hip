@@ -4,10 +4,11 @@
 // update sum_n (attn+eps)[n,k] * v[n,:] in registers (K x D/64 per lane).  A finish kernel reduces the
 // per-chunk partials and applies the 1/sum_n normalisation.  HBM-bound: 2*N*D*esize read per (b,t,iter).
 #include "focus_common.h"
+#include <cstdlib>
 
 namespace {
 
-constexpr int ROWS_PER_BLOCK = 256;
+constexpr int ROWS_PER_BLOCK = 64;    // 16 rows per wave: 8 waves/SIMD in flight (256 left the loads latency-bound: 404 us fwd)
 
 template <typename T, int KP, int DV>
 __global__ __launch_bounds__(256) void slot_fwd_kernel(const T* __restrict__ kt, const T* __restrict__ vt,
@@ -226,12 +227,288 @@ __global__ void slot_bwd_finish(const float* __restrict__ partial, T* __restrict
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// bf16, K <= 16 slots, D % 32 == 0, D <= 256: slot logits (and, backward, dupd . v) on the matrix pipe.
+// A wave owns 64 input rows.  Phase 1: four v_mfma_f32_16x16x32_bf16 tiles D[slot][row] = sum_d q[slot][d] * k[row][d]
+// (A operand q from registers, B operand straight from global: a lane's 8 consecutive d of one row is one 16-byte
+// load), softmax over the slots = 4 registers + 2 cross-lane steps per row instead of K full wave reductions; the
+// per-(row, slot) scalars go to a wave-private LDS table.  Phase 2: lanes own 4 channels (8-byte row accesses) and
+// run the rank-1 updates with the scalars broadcast from LDS.  (The all-VALU kernels above spend ~66 shuffles and
+// 6 two-byte loads per row: 404 / 709 us per call at B=32, N=4096, D=192 -- ~20x off the HBM bound.)
+// ------------------------------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(8))) __bf16 sbf16x8;
+typedef __attribute__((ext_vector_type(4))) float sf32x4;
+union SPk8 { sbf16x8 v; uint4 u; bf16_t e[8]; };
+constexpr int MROWS = 256;                        // rows per block (4 waves x 64)
+
+__device__ __forceinline__ sbf16x8 slot_frag(const bf16_t* base, int slot, int K, int D, int ks, int g) {
+    SPk8 f;
+    f.u = make_uint4(0, 0, 0, 0);
+    if (slot < K) f.u = *reinterpret_cast<const uint4*>(base + (int64_t)slot * D + ks * 32 + g * 8);
+    return f.v;
+}
+
+template <int KS>   // KS = D / 32
+__global__ __launch_bounds__(256) void slot_fwd_mfma_kernel(const bf16_t* __restrict__ kt, const bf16_t* __restrict__ vt,
+                                                            int64_t kv_bs, const bf16_t* __restrict__ q,
+                                                            bf16_t* __restrict__ attn, int64_t attn_bs,
+                                                            float* __restrict__ partial, int N, int K, float eps) {
+    constexpr int D = KS * 32;
+    __shared__ __attribute__((aligned(16))) float sA[4][64][16];          // (attn + eps) per (row, slot), 0 for padding
+    __shared__ float red[4][16][D + 1];
+    const int b = blockIdx.y, chunk = blockIdx.x, nchunk = gridDim.x;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int t16 = lane & 15, g = lane >> 4;
+    const int n0 = chunk * MROWS + w * 64;
+    const bf16_t* kb = kt + (int64_t)b * kv_bs;
+    const bf16_t* vb = vt + (int64_t)b * kv_bs;
+    sbf16x8 qf[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) qf[ks] = slot_frag(q + (int64_t)b * K * D, t16, K, D, ks, g);
+    // ---- phase 1: logits and softmax over slots, 16 rows per MFMA tile ----
+#pragma unroll
+    for (int tb = 0; tb < 4; ++tb) {
+        const int n = n0 + tb * 16 + t16;
+        const bf16_t* row = kb + (int64_t)min(n, N - 1) * D;
+        sf32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        SPk8 kf[KS];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) kf[ks].u = *reinterpret_cast<const uint4*>(row + ks * 32 + g * 8);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf[ks], kf[ks].v, acc, 0, 0, 0);
+        // acc[r] = logit[slot 4g + r][row t16 of this tile]
+        float m = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { if (4 * g + r >= K) acc[r] = -INFINITY; m = fmaxf(m, acc[r]); }
+        m = fmaxf(m, __shfl_xor(m, 16, 64));
+        m = fmaxf(m, __shfl_xor(m, 32, 64));
+        float e[4], den = 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { e[r] = __expf(acc[r] - m); den += e[r]; }
+        den += __shfl_xor(den, 16, 64);
+        den += __shfl_xor(den, 32, 64);
+        const float inv = 1.f / den;
+        const bool valid = n < N;
+        float4 ae;
+        float a[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            a[r] = e[r] * inv;
+            if (valid && 4 * g + r < K) attn[(int64_t)b * attn_bs + (int64_t)n * K + 4 * g + r] = f32_to_bf16(a[r]);
+        }
+        ae.x = valid && 4 * g + 0 < K ? a[0] + eps : 0.f;
+        ae.y = valid && 4 * g + 1 < K ? a[1] + eps : 0.f;
+        ae.z = valid && 4 * g + 2 < K ? a[2] + eps : 0.f;
+        ae.w = valid && 4 * g + 3 < K ? a[3] + eps : 0.f;
+        *reinterpret_cast<float4*>(&sA[w][tb * 16 + t16][4 * g]) = ae;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // the table is wave-private
+    // ---- phase 2: U[k][c] += ae[row][k] * v[row][c]; lane = 4 channels ----
+    constexpr int NL = D / 4;                                // active lanes
+    float U[16][4], cs[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { cs[k] = 0.f; U[k][0] = U[k][1] = U[k][2] = U[k][3] = 0.f; }
+    const bool lact = lane < NL;
+    for (int t0 = 0; t0 < 64; t0 += 8) {
+        uint2 vr[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int n = min(n0 + t0 + u, N - 1);
+            vr[u] = lact ? *reinterpret_cast<const uint2*>(vb + (int64_t)n * D + lane * 4) : make_uint2(0, 0);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const float v0 = __uint_as_float(vr[u].x << 16), v1 = __uint_as_float(vr[u].x & 0xffff0000u);
+            const float v2 = __uint_as_float(vr[u].y << 16), v3 = __uint_as_float(vr[u].y & 0xffff0000u);
+            const float4* ar = reinterpret_cast<const float4*>(&sA[w][t0 + u][0]);
+            float aw[16];
+#pragma unroll
+            for (int c4 = 0; c4 < 4; ++c4) {
+                const float4 x = ar[c4];
+                aw[c4 * 4 + 0] = x.x; aw[c4 * 4 + 1] = x.y; aw[c4 * 4 + 2] = x.z; aw[c4 * 4 + 3] = x.w;
+            }
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                cs[k] += aw[k];
+                U[k][0] = fmaf(aw[k], v0, U[k][0]); U[k][1] = fmaf(aw[k], v1, U[k][1]);
+                U[k][2] = fmaf(aw[k], v2, U[k][2]); U[k][3] = fmaf(aw[k], v3, U[k][3]);
+            }
+        }
+    }
+    // ---- combine the 4 waves: partial[b][chunk][k][0..D-1], column sum at [..][D] ----
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        if (lact) { red[w][k][lane * 4 + 0] = U[k][0]; red[w][k][lane * 4 + 1] = U[k][1]; red[w][k][lane * 4 + 2] = U[k][2]; red[w][k][lane * 4 + 3] = U[k][3]; }
+        if (lane == 0) red[w][k][D] = cs[k];
+    }
+    __syncthreads();
+    float* out = partial + ((int64_t)b * nchunk + chunk) * K * (D + 1);
+    for (int i = threadIdx.x; i < K * (D + 1); i += 256) {
+        const int k = i / (D + 1), e = i - k * (D + 1);
+        out[i] = red[0][k][e] + red[1][k][e] + red[2][k][e] + red[3][k][e];
+    }
+}
+
+template <int KS>
+__global__ __launch_bounds__(256) void slot_bwd_mfma_kernel(const bf16_t* __restrict__ kt, const bf16_t* __restrict__ vt,
+                                                            int64_t kv_bs, const bf16_t* __restrict__ q,
+                                                            const bf16_t* __restrict__ attn, int64_t attn_bs,
+                                                            const float* __restrict__ colsum, const bf16_t* __restrict__ upd,
+                                                            const bf16_t* __restrict__ dupd, const bf16_t* __restrict__ dattn,
+                                                            bf16_t* __restrict__ dkt, bf16_t* __restrict__ dvt, int accumulate,
+                                                            float* __restrict__ partial, int N, int K, float eps) {
+    constexpr int D = KS * 32;
+    __shared__ __attribute__((aligned(16))) float sW[4][64][16];          // (attn + eps) / colsum per (row, slot)
+    __shared__ __attribute__((aligned(16))) float sL[4][64][16];          // d logits per (row, slot)
+    __shared__ float sr[16], scs[16];
+    __shared__ float red[4][16][D];
+    const int b = blockIdx.y, chunk = blockIdx.x, nchunk = gridDim.x;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int t16 = lane & 15, g = lane >> 4;
+    const int n0 = chunk * MROWS + w * 64;
+    const bf16_t* kb = kt + (int64_t)b * kv_bs;
+    const bf16_t* vb = vt + (int64_t)b * kv_bs;
+    const bf16_t* qb = q + (int64_t)b * K * D;
+    const bf16_t* dub = dupd + (int64_t)b * K * D;
+    // r[k] = dupd[k,:] . upd[k,:]  (one wave per slot, round robin), colsum
+    for (int k = w; k < K; k += 4) {
+        float p = 0.f;
+        for (int e = lane; e < D; e += 64) p += bf16_to_f32(dub[k * D + e]) * bf16_to_f32(upd[((int64_t)b * K + k) * D + e]);
+        p = wave_sum(p);
+        if (lane == 0) { sr[k] = p; scs[k] = colsum[b * K + k]; }
+    }
+    __syncthreads();
+    sbf16x8 df[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) df[ks] = slot_frag(dub, t16, K, D, ks, g);
+    // ---- phase 1: dw[slot][row] = dupd[slot] . v[row] on the matrix pipe; softmax backward per row ----
+#pragma unroll
+    for (int tb = 0; tb < 4; ++tb) {
+        const int n = n0 + tb * 16 + t16;
+        const bool valid = n < N;
+        const bf16_t* row = vb + (int64_t)min(n, N - 1) * D;
+        sf32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        SPk8 vf[KS];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) vf[ks].u = *reinterpret_cast<const uint4*>(row + ks * 32 + g * 8);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(df[ks], vf[ks].v, acc, 0, 0, 0);
+        float av[4], dav[4], dot = 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int k = 4 * g + r;
+            av[r] = 0.f; dav[r] = 0.f;
+            if (valid && k < K) {
+                const int64_t o = (int64_t)b * attn_bs + (int64_t)n * K + k;
+                av[r] = bf16_to_f32(attn[o]);
+                dav[r] = (acc[r] - sr[k]) / scs[k];
+                if (dattn) dav[r] += bf16_to_f32(dattn[o]);
+                dot += av[r] * dav[r];
+            }
+        }
+        dot += __shfl_xor(dot, 16, 64);
+        dot += __shfl_xor(dot, 32, 64);
+        float4 wg, dl;
+        float wv[4], lv[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int k = 4 * g + r;
+            const bool ok = valid && k < K;
+            wv[r] = ok ? (av[r] + eps) / scs[k] : 0.f;
+            lv[r] = ok ? av[r] * (dav[r] - dot) : 0.f;
+        }
+        wg.x = wv[0]; wg.y = wv[1]; wg.z = wv[2]; wg.w = wv[3];
+        dl.x = lv[0]; dl.y = lv[1]; dl.z = lv[2]; dl.w = lv[3];
+        *reinterpret_cast<float4*>(&sW[w][tb * 16 + t16][4 * g]) = wg;
+        *reinterpret_cast<float4*>(&sL[w][tb * 16 + t16][4 * g]) = dl;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    // ---- phase 2: lane = 4 channels.  dv[c] = sum_k w[k] dupd[k][c], dk[c] = sum_k dl[k] q[k][c], dQ[k][c] += dl[k] k[c]
+    constexpr int NL = D / 4;
+    const bool lact = lane < NL;
+    float sq[16][4], sd[16][4], dQ[16][4];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const bool ok = lact && k < K;
+            sq[k][c] = ok ? bf16_to_f32(qb[k * D + lane * 4 + c]) : 0.f;
+            sd[k][c] = ok ? bf16_to_f32(dub[k * D + lane * 4 + c]) : 0.f;
+            dQ[k][c] = 0.f;
+        }
+    }
+    for (int t0 = 0; t0 < 64; t0 += 4) {
+        uint2 kr[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int n = min(n0 + t0 + u, N - 1);
+            kr[u] = lact ? *reinterpret_cast<const uint2*>(kb + (int64_t)n * D + lane * 4) : make_uint2(0, 0);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int n = n0 + t0 + u;
+            const float k0 = __uint_as_float(kr[u].x << 16), k1 = __uint_as_float(kr[u].x & 0xffff0000u);
+            const float k2 = __uint_as_float(kr[u].y << 16), k3 = __uint_as_float(kr[u].y & 0xffff0000u);
+            const float4* wr = reinterpret_cast<const float4*>(&sW[w][t0 + u][0]);
+            const float4* lr = reinterpret_cast<const float4*>(&sL[w][t0 + u][0]);
+            float ww[16], ll[16];
+#pragma unroll
+            for (int c4 = 0; c4 < 4; ++c4) {
+                const float4 x = wr[c4], y = lr[c4];
+                ww[c4 * 4 + 0] = x.x; ww[c4 * 4 + 1] = x.y; ww[c4 * 4 + 2] = x.z; ww[c4 * 4 + 3] = x.w;
+                ll[c4 * 4 + 0] = y.x; ll[c4 * 4 + 1] = y.y; ll[c4 * 4 + 2] = y.z; ll[c4 * 4 + 3] = y.w;
+            }
+            float dv[4] = {0.f, 0.f, 0.f, 0.f}, dk[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) { dv[c] = fmaf(ww[k], sd[k][c], dv[c]); dk[c] = fmaf(ll[k], sq[k][c], dk[c]); }
+                dQ[k][0] = fmaf(ll[k], k0, dQ[k][0]); dQ[k][1] = fmaf(ll[k], k1, dQ[k][1]);
+                dQ[k][2] = fmaf(ll[k], k2, dQ[k][2]); dQ[k][3] = fmaf(ll[k], k3, dQ[k][3]);
+            }
+            if (lact && n < N) {
+                const int64_t ro = (int64_t)b * kv_bs + (int64_t)n * D + lane * 4;
+                if (accumulate) {
+                    const uint2 ok = *reinterpret_cast<const uint2*>(dkt + ro), ov = *reinterpret_cast<const uint2*>(dvt + ro);
+                    dk[0] += __uint_as_float(ok.x << 16); dk[1] += __uint_as_float(ok.x & 0xffff0000u);
+                    dk[2] += __uint_as_float(ok.y << 16); dk[3] += __uint_as_float(ok.y & 0xffff0000u);
+                    dv[0] += __uint_as_float(ov.x << 16); dv[1] += __uint_as_float(ov.x & 0xffff0000u);
+                    dv[2] += __uint_as_float(ov.y << 16); dv[3] += __uint_as_float(ov.y & 0xffff0000u);
+                }
+                uint2 o1, o2;
+                o1.x = (uint32_t)f32_to_bf16(dk[0]) | ((uint32_t)f32_to_bf16(dk[1]) << 16);
+                o1.y = (uint32_t)f32_to_bf16(dk[2]) | ((uint32_t)f32_to_bf16(dk[3]) << 16);
+                o2.x = (uint32_t)f32_to_bf16(dv[0]) | ((uint32_t)f32_to_bf16(dv[1]) << 16);
+                o2.y = (uint32_t)f32_to_bf16(dv[2]) | ((uint32_t)f32_to_bf16(dv[3]) << 16);
+                *reinterpret_cast<uint2*>(dkt + ro) = o1;
+                *reinterpret_cast<uint2*>(dvt + ro) = o2;
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 16; ++k)
+        if (lact) { red[w][k][lane * 4 + 0] = dQ[k][0]; red[w][k][lane * 4 + 1] = dQ[k][1]; red[w][k][lane * 4 + 2] = dQ[k][2]; red[w][k][lane * 4 + 3] = dQ[k][3]; }
+    __syncthreads();
+    float* out = partial + ((int64_t)b * nchunk + chunk) * K * D;
+    for (int i = threadIdx.x; i < K * D; i += 256) {
+        const int k = i / D, e = i - k * D;
+        out[i] = red[0][k][e] + red[1][k][e] + red[2][k][e] + red[3][k][e];
+    }
+}
+
+inline bool slot_mfma_ok(const void* a, const void* b, const void* c, int64_t kv_bs, int K, int D, int dtype) {
+    static const bool enabled = !(getenv("FOCUS_SLOT_MFMA") && atoi(getenv("FOCUS_SLOT_MFMA")) == 0);
+    return enabled && dtype == FOCUS_BF16 && K <= 16 && (D == 64 || D == 128 || D == 192 || D == 256) && (kv_bs & 7) == 0 &&
+           focus_aligned(a, 16) && focus_aligned(b, 16) && focus_aligned(c, 16);
+}
+
 inline int nchunks(int N) { return (N + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK; }
+inline int nchunks_mfma(int N) { return (N + MROWS - 1) / MROWS; }
 
 }  // namespace
 
 extern "C" size_t focus_slot_attn_workspace_bytes(int B, int N, int K, int D) {
-    return (size_t)B * nchunks(N) * K * (D + 1) * sizeof(float);
+    return (size_t)B * nchunks(N) * K * (D + 1) * sizeof(float);     // nchunks(N) >= nchunks_mfma(N)
 }
 
 #define SLOT_DISPATCH(KERNEL_CALL)                                                          \
@@ -253,6 +530,17 @@ extern "C" int focus_slot_attn_fwd(const void* k_t, const void* v_t, int64_t kv_
     if (B <= 0 || N <= 0 || K <= 0 || K > 32 || D <= 0 || D > 256 || B > 65535) return FOCUS_ERR_SHAPE;
     if (partial_bytes < focus_slot_attn_workspace_bytes(B, N, K, D)) return FOCUS_ERR_WORKSPACE;
     hipStream_t s = (hipStream_t)stream;
+    if (slot_mfma_ok(k_t, v_t, q, kv_bs, K, D, dtype)) {
+        dim3 gm(nchunks_mfma(N), B);
+#define SFM(KS) hipLaunchKernelGGL((slot_fwd_mfma_kernel<KS>), gm, dim3(256), 0, s, (const bf16_t*)k_t, (const bf16_t*)v_t, kv_bs, (const bf16_t*)q, (bf16_t*)attn_vis, attn_bs, (float*)partial, N, K, eps)
+        if (D == 64) SFM(2); else if (D == 128) SFM(4); else if (D == 192) SFM(6); else SFM(8);
+#undef SFM
+        FOCUS_CHECK_LAUNCH();
+        hipLaunchKernelGGL((slot_fwd_finish<bf16_t>), dim3(K, B), dim3(64), 0, s, (const float*)partial, (bf16_t*)upd, colsum,
+                           nchunks_mfma(N), K, D);
+        FOCUS_CHECK_LAUNCH();
+        return FOCUS_OK;
+    }
     dim3 grid(nchunks(N), B);
     const size_t lds = ((size_t)K * D + 256) * sizeof(float);
 #define SLOT_CASE(KP_, DV_)                                                                                   \
@@ -290,6 +578,17 @@ extern "C" int focus_slot_attn_bwd(const void* k_t, const void* v_t, int64_t kv_
     if (B <= 0 || N <= 0 || K <= 0 || K > 32 || D <= 0 || D > 256 || B > 65535) return FOCUS_ERR_SHAPE;
     if (partial_bytes < focus_slot_attn_workspace_bytes(B, N, K, D)) return FOCUS_ERR_WORKSPACE;
     hipStream_t s = (hipStream_t)stream;
+    if (slot_mfma_ok(k_t, v_t, q, kv_bs, K, D, dtype) && focus_aligned(dk_t, 8) && focus_aligned(dv_t, 8)) {
+        dim3 gm(nchunks_mfma(N), B);
+#define SBM(KS) hipLaunchKernelGGL((slot_bwd_mfma_kernel<KS>), gm, dim3(256), 0, s, (const bf16_t*)k_t, (const bf16_t*)v_t, kv_bs, (const bf16_t*)q, (const bf16_t*)attn_vis, attn_bs, colsum, (const bf16_t*)upd, (const bf16_t*)dupd, (const bf16_t*)dattn_vis, (bf16_t*)dk_t, (bf16_t*)dv_t, accumulate, (float*)partial, N, K, eps)
+        if (D == 64) SBM(2); else if (D == 128) SBM(4); else if (D == 192) SBM(6); else SBM(8);
+#undef SBM
+        FOCUS_CHECK_LAUNCH();
+        hipLaunchKernelGGL((slot_bwd_finish<bf16_t>), dim3(K, B), dim3(64), 0, s, (const float*)partial, (bf16_t*)dq,
+                           nchunks_mfma(N), K, D);
+        FOCUS_CHECK_LAUNCH();
+        return FOCUS_OK;
+    }
     dim3 grid(nchunks(N), B);
     const size_t lds = ((size_t)2 * K * D + 64 + 256) * sizeof(float);
 #define SLOT_CASE(KP_, DV_)                                                                                    \
