@@ -47,10 +47,11 @@ class SlotAttentionVideo(nn.Module):
         ni, ns, nm = self.norm_inputs, self.norm_slots, self.norm_mlp
         k_scale = Ds ** -0.5
         attns_collect, slots_collect = [], []
+        frames = ops.unbind_frames(inputs) if inputs.requires_grad else [inputs[:, t] for t in range(T)]
         for t in range(T):
             # LayerNorm + k/v projections of frame t (per frame instead of whole-video: same values, and the
             # per-frame gradients need no zero-padded whole-video buffers)
-            x_t = ops.layer_norm(inputs[:, t], ni.weight, ni.bias, ni.eps)
+            x_t = ops.layer_norm(frames[t], ni.weight, ni.bias, ni.eps)
             k_t = ops.linear(x_t, self.project_k.weight) * k_scale
             v_t = ops.linear(x_t, self.project_v.weight)
             for i in range(self.num_iterations):

@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol(built):
     # pure host-side queries work without a GPU
     assert lib.focus_layernorm_bwd_blocks(10) == 3 and lib.focus_layernorm_bwd_blocks(10 ** 6) == 512
     assert lib.focus_traj_space_workspace_bytes(1, 8, 196, 12, 64, 0, 0) >= 12 * 1568 * 1568 * 4
-    assert lib.focus_slot_attn_workspace_bytes(2, 4096, 11, 192) == 2 * 16 * 11 * 193 * 4
+    assert lib.focus_slot_attn_workspace_bytes(2, 4096, 11, 192) == 2 * 64 * 11 * 193 * 4     # 64-row chunks
 
 
 def test_gemm_desc_layout_matches_header():
