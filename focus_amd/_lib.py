@@ -71,6 +71,10 @@ def lib():
             raise RuntimeError(
                 "focus_amd: %s is missing -- build it with `python -m focus_amd.build` "
                 "(there is no CPU/PyTorch fallback for the hot path)" % LIB_PATH)
+        # torch first: libfocus_amd.so needs libamdhip64, and the process must end up with ONE HIP runtime -- the copy
+        # PyTorch-ROCm ships and initialises.  Loaded the other way round (this library before torch) the kernels
+        # register with /opt/rocm's runtime while the streams come from torch's: every launch then fails.
+        import torch  # noqa: F401
         L = ctypes.CDLL(LIB_PATH)
         for name, (restype, argtypes) in parse_header().items():
             fn = getattr(L, name)          # AttributeError here = header/library mismatch
