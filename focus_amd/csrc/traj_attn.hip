@@ -23,7 +23,7 @@ constexpr int MAXF = 16;
 
 template <typename T, int FT>
 __global__ __launch_bounds__(256) void time_fwd_kernel(const T* __restrict__ q2, const T* __restrict__ k2,
-                                                       const T* __restrict__ xt, T* __restrict__ out,
+                                                       const T* __restrict__ xt, T* __restrict__ out, int64_t obs,
                                                        float* __restrict__ attn2, int64_t rows, int S, int F,
                                                        int heads, int d, float scale) {
     const int lane = threadIdx.x & 63;
@@ -65,14 +65,14 @@ __global__ __launch_bounds__(256) void time_fwd_kernel(const T* __restrict__ q2,
             o.x += a * xv[f].x; o.y += a * xv[f].y; o.z += a * xv[f].z; o.w += a * xv[f].w;
             if (act && (lane % lph) == 0) attn2[((b * heads + h) * S + s) * F + f] = a;
         }
-        if (act) st4<T>(out + row * C + c, o);
+        if (act) st4<T>(out + b * obs + (int64_t)s * C + c, o);
     }
 }
 
 template <typename T, int FT>
 __global__ __launch_bounds__(256) void time_bwd_kernel(const T* __restrict__ q2, const T* __restrict__ k2,
                                                        const T* __restrict__ xt, const float* __restrict__ attn2,
-                                                       const T* __restrict__ dout, T* __restrict__ dq2,
+                                                       const T* __restrict__ dout, int64_t dobs, T* __restrict__ dq2,
                                                        T* __restrict__ dk2, T* __restrict__ dxt, int dxt_accum,
                                                        int64_t rows, int S, int F, int heads, int d, float scale) {
     const int lane = threadIdx.x & 63;
@@ -88,7 +88,7 @@ __global__ __launch_bounds__(256) void time_bwd_kernel(const T* __restrict__ q2,
         const bool act = c < C;
         const int h = act ? c / d : 0;
         f4 g = {0.f, 0.f, 0.f, 0.f}, q = g;
-        if (act) { g = ld4<T>(dout + row * C + c); q = ld4<T>(q2 + row * C + c); }
+        if (act) { g = ld4<T>(dout + b * dobs + (int64_t)s * C + c); q = ld4<T>(q2 + row * C + c); }
         float a[FA], da[FA];
         float dot = 0.f;
 #pragma unroll
@@ -144,7 +144,7 @@ __device__ __forceinline__ float sum8lanes(float v) {
 
 template <int FT>
 __global__ __launch_bounds__(256) void time_fwd_vec_kernel(const bf16_t* __restrict__ q2, const bf16_t* __restrict__ k2,
-                                                           const bf16_t* __restrict__ xt, bf16_t* __restrict__ out,
+                                                           const bf16_t* __restrict__ xt, bf16_t* __restrict__ out, int64_t obs,
                                                            float* __restrict__ attn2, int64_t ngroups, int S, int heads,
                                                            float scale) {
     const int64_t gi = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -190,13 +190,13 @@ __global__ __launch_bounds__(256) void time_fwd_vec_kernel(const bf16_t* __restr
         for (int e = 0; e < 8; ++e) o[e] = fmaf(a, xv[e], o[e]);
         if (act && (cg & 7) == 0) arow[f] = a;
     }
-    if (act) *reinterpret_cast<uint4*>(out + row * C + cg * 8) = pack8(o);
+    if (act) *reinterpret_cast<uint4*>(out + b * obs + (int64_t)s * C + cg * 8) = pack8(o);
 }
 
 template <int FT>
 __global__ __launch_bounds__(256) void time_bwd_vec_kernel(const bf16_t* __restrict__ q2, const bf16_t* __restrict__ k2,
                                                            const bf16_t* __restrict__ xt, const float* __restrict__ attn2,
-                                                           const bf16_t* __restrict__ dout, bf16_t* __restrict__ dq2,
+                                                           const bf16_t* __restrict__ dout, int64_t dobs, bf16_t* __restrict__ dq2,
                                                            bf16_t* __restrict__ dk2, bf16_t* __restrict__ dxt,
                                                            int64_t ngroups, int S, int heads, float scale) {
     const int64_t gi = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -215,7 +215,7 @@ __global__ __launch_bounds__(256) void time_bwd_vec_kernel(const bf16_t* __restr
         kr[f] = *reinterpret_cast<const uint4*>(k2 + ((row * FT + f) * C) + cg * 8);
     }
     float gv[8], q[8];
-    unpack8(*reinterpret_cast<const uint4*>(dout + row * C + cg * 8), gv);
+    unpack8(*reinterpret_cast<const uint4*>(dout + b * dobs + (int64_t)s * C + cg * 8), gv);
     unpack8(*reinterpret_cast<const uint4*>(q2 + row * C + cg * 8), q);
     const float* arow = attn2 + (((b * heads + (cg >> 3)) * S + s) * FT);
     float a[FT], da[FT], dot = 0.f;
@@ -490,24 +490,25 @@ extern "C" int focus_traj_space_bwd(const void* qkv, const void* xt, const void*
     return FOCUS_OK;
 }
 
-extern "C" int focus_traj_time_fwd(const void* q2, const void* k2, const void* xt, void* out, float* attn2, int B,
-                                   int S, int F, int heads, int d, int dtype, void* stream) {
+extern "C" int focus_traj_time_fwd(const void* q2, const void* k2, const void* xt, void* out, int64_t out_bstride,
+                                   float* attn2, int B, int S, int F, int heads, int d, int dtype, void* stream) {
     if (!q2 || !k2 || !xt || !out || !attn2) return FOCUS_ERR_NULL;
     if (F > MAXF || F <= 0 || (d & 3) || (d >> 2) > 64 || ((d >> 2) & ((d >> 2) - 1))) return FOCUS_ERR_SHAPE;
     const int64_t rows = (int64_t)B * S;
     if (rows <= 0) return FOCUS_OK;
     const float scale = 1.f / sqrtf((float)d);
-    if (time_vec_ok(q2, k2, xt, F, d, dtype) && focus_aligned(out, 16)) {
+    if (out_bstride < (int64_t)S * heads * d) return FOCUS_ERR_SHAPE;
+    if (time_vec_ok(q2, k2, xt, F, d, dtype) && focus_aligned(out, 16) && (out_bstride & 7) == 0) {
         const int64_t ng = rows * heads * 8;
         dim3 gv((unsigned)cdiv64(ng, 256));
-#define TFV(FT) hipLaunchKernelGGL((time_fwd_vec_kernel<FT>), gv, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)q2, (const bf16_t*)k2, (const bf16_t*)xt, (bf16_t*)out, attn2, ng, S, heads, scale)
+#define TFV(FT) hipLaunchKernelGGL((time_fwd_vec_kernel<FT>), gv, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)q2, (const bf16_t*)k2, (const bf16_t*)xt, (bf16_t*)out, out_bstride, attn2, ng, S, heads, scale)
         if (F == 8) TFV(8); else if (F == 4) TFV(4); else TFV(16);
 #undef TFV
         FOCUS_CHECK_LAUNCH();
         return FOCUS_OK;
     }
     dim3 grid((unsigned)cdiv64(rows, 4));
-#define TF(T, FT) hipLaunchKernelGGL((time_fwd_kernel<T, FT>), grid, dim3(256), 0, (hipStream_t)stream, (const T*)q2, (const T*)k2, (const T*)xt, (T*)out, attn2, rows, S, F, heads, d, scale)
+#define TF(T, FT) hipLaunchKernelGGL((time_fwd_kernel<T, FT>), grid, dim3(256), 0, (hipStream_t)stream, (const T*)q2, (const T*)k2, (const T*)xt, (T*)out, out_bstride, attn2, rows, S, F, heads, d, scale)
     if (dtype == FOCUS_BF16) { if (F == 8) TF(bf16_t, 8); else TF(bf16_t, 0); }
     else { if (F == 8) TF(float, 8); else TF(float, 0); }
 #undef TF
@@ -516,25 +517,26 @@ extern "C" int focus_traj_time_fwd(const void* q2, const void* k2, const void* x
 }
 
 extern "C" int focus_traj_time_bwd(const void* q2, const void* k2, const void* xt, const float* attn2,
-                                   const void* dout, void* dq2, void* dk2, void* dxt, int dxt_accum, int B, int S,
-                                   int F, int heads, int d, int dtype, void* stream) {
+                                   const void* dout, int64_t dout_bstride, void* dq2, void* dk2, void* dxt, int dxt_accum,
+                                   int B, int S, int F, int heads, int d, int dtype, void* stream) {
     if (!q2 || !k2 || !xt || !attn2 || !dout || !dq2 || !dk2 || !dxt) return FOCUS_ERR_NULL;
     if (F > MAXF || F <= 0 || (d & 3) || (d >> 2) > 64 || ((d >> 2) & ((d >> 2) - 1))) return FOCUS_ERR_SHAPE;
     const int64_t rows = (int64_t)B * S;
     if (rows <= 0) return FOCUS_OK;
     const float scale = 1.f / sqrtf((float)d);
-    if (!dxt_accum && time_vec_ok(q2, k2, xt, F, d, dtype) && focus_aligned(dout, 16) && focus_aligned(dq2, 16) &&
+    if (dout_bstride < (int64_t)S * heads * d) return FOCUS_ERR_SHAPE;
+    if (!dxt_accum && (dout_bstride & 7) == 0 && time_vec_ok(q2, k2, xt, F, d, dtype) && focus_aligned(dout, 16) && focus_aligned(dq2, 16) &&
         focus_aligned(dk2, 16) && focus_aligned(dxt, 16)) {
         const int64_t ng = rows * heads * 8;
         dim3 gv((unsigned)cdiv64(ng, 256));
-#define TBV(FT) hipLaunchKernelGGL((time_bwd_vec_kernel<FT>), gv, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)q2, (const bf16_t*)k2, (const bf16_t*)xt, attn2, (const bf16_t*)dout, (bf16_t*)dq2, (bf16_t*)dk2, (bf16_t*)dxt, ng, S, heads, scale)
+#define TBV(FT) hipLaunchKernelGGL((time_bwd_vec_kernel<FT>), gv, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)q2, (const bf16_t*)k2, (const bf16_t*)xt, attn2, (const bf16_t*)dout, dout_bstride, (bf16_t*)dq2, (bf16_t*)dk2, (bf16_t*)dxt, ng, S, heads, scale)
         if (F == 8) TBV(8); else if (F == 4) TBV(4); else TBV(16);
 #undef TBV
         FOCUS_CHECK_LAUNCH();
         return FOCUS_OK;
     }
     dim3 grid((unsigned)cdiv64(rows, 4));
-#define TB(T, FT) hipLaunchKernelGGL((time_bwd_kernel<T, FT>), grid, dim3(256), 0, (hipStream_t)stream, (const T*)q2, (const T*)k2, (const T*)xt, attn2, (const T*)dout, (T*)dq2, (T*)dk2, (T*)dxt, dxt_accum, rows, S, F, heads, d, scale)
+#define TB(T, FT) hipLaunchKernelGGL((time_bwd_kernel<T, FT>), grid, dim3(256), 0, (hipStream_t)stream, (const T*)q2, (const T*)k2, (const T*)xt, attn2, (const T*)dout, dout_bstride, (T*)dq2, (T*)dk2, (T*)dxt, dxt_accum, rows, S, F, heads, d, scale)
     if (dtype == FOCUS_BF16) { if (F == 8) TB(bf16_t, 8); else TB(bf16_t, 0); }
     else { if (F == 8) TB(float, 8); else TB(float, 0); }
 #undef TB

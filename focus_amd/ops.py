@@ -586,7 +586,7 @@ class _TrajTimeFn(torch.autograd.Function):
         d = C // heads
         out = torch.empty(B, S, C, device=xt.device, dtype=xt.dtype)
         attn2 = torch.empty(B, heads, S, F_, device=xt.device, dtype=torch.float32)
-        _lib.check(_lib.lib().focus_traj_time_fwd(_p(q2), _p(k2), _p(xt), _p(out), _p(attn2), B, S, F_, heads, d,
+        _lib.check(_lib.lib().focus_traj_time_fwd(_p(q2), _p(k2), _p(xt), _p(out), S * C, _p(attn2), B, S, F_, heads, d,
                                                   _dt(xt), _stream()), "traj_time_fwd")
         ctx.save_for_backward(q2, k2, xt, attn2)
         ctx.heads = heads
@@ -598,7 +598,7 @@ class _TrajTimeFn(torch.autograd.Function):
         B, S, F_, C = xt.shape
         dout = dout.contiguous()
         dq2, dk2, dxt = torch.empty_like(q2), torch.empty_like(k2), torch.empty_like(xt)
-        _lib.check(_lib.lib().focus_traj_time_bwd(_p(q2), _p(k2), _p(xt), _p(attn2), _p(dout), _p(dq2), _p(dk2),
+        _lib.check(_lib.lib().focus_traj_time_bwd(_p(q2), _p(k2), _p(xt), _p(attn2), _p(dout), S * C, _p(dq2), _p(dk2),
                                                   _p(dxt), 0, B, S, F_, ctx.heads, C // ctx.heads, _dt(xt),
                                                   _stream()), "traj_time_bwd")
         return dq2, dk2, dxt, None
@@ -616,7 +616,7 @@ class _TrajTimeBlockFn(torch.autograd.Function):
     backward."""
 
     @staticmethod
-    def forward(ctx, q2, xt, w_kv, b_kv, heads):
+    def forward(ctx, q2, xt, w_kv, b_kv, cls_out, heads):
         _need_gpu(q2, xt, w_kv)
         q2, xt = q2.contiguous(), xt.contiguous()
         B, S, F_, C = xt.shape
@@ -624,22 +624,25 @@ class _TrajTimeBlockFn(torch.autograd.Function):
         wk = shadow(w_kv, xt.dtype)[:C]
         bk = b_kv.detach()[:C] if b_kv is not None else None
         k2 = mm_nt(xt.view(-1, C), wk, bias=bk).view(B, S, F_, C)
-        out = torch.empty(B, S, C, device=xt.device, dtype=xt.dtype)
+        # the attention rows are written straight into tokens 1.. of the [B, 1+S, C] input of `proj`; token 0 is the
+        # cls row (attention.py:551 concatenates them)
+        out = torch.empty(B, S + 1, C, device=xt.device, dtype=xt.dtype)
+        out[:, 0].copy_(cls_out.reshape(B, C))
         attn2 = torch.empty(B, heads, S, F_, device=xt.device, dtype=torch.float32)
-        _lib.check(_lib.lib().focus_traj_time_fwd(_p(q2), _p(k2), _p(xt), _p(out), _p(attn2), B, S, F_, heads, d,
-                                                  _dt(xt), _stream()), "traj_time_fwd")
+        _lib.check(_lib.lib().focus_traj_time_fwd(_p(q2), _p(k2), _p(xt), _p(out, C), (S + 1) * C, _p(attn2), B, S, F_,
+                                                  heads, d, _dt(xt), _stream()), "traj_time_fwd")
         ctx.save_for_backward(q2, k2, xt, attn2, w_kv)
-        ctx.heads, ctx.has_b = heads, b_kv is not None
+        ctx.heads, ctx.has_b, ctx.cls_shape = heads, b_kv is not None, cls_out.shape
         return out
 
     @staticmethod
-    def backward(ctx, dout):
+    def backward(ctx, dcat):
         q2, k2, xt, attn2, w_kv = ctx.saved_tensors
         B, S, F_, C = xt.shape
-        dout = dout.contiguous()
+        dcat = dcat.contiguous()                 # [B, 1+S, C]: rows 1.. are read in place (batch stride (S+1)*C)
         dq2, dk2, dxt_a = torch.empty_like(q2), torch.empty_like(k2), torch.empty_like(xt)
-        _lib.check(_lib.lib().focus_traj_time_bwd(_p(q2), _p(k2), _p(xt), _p(attn2), _p(dout), _p(dq2), _p(dk2),
-                                                  _p(dxt_a), 0, B, S, F_, ctx.heads, C // ctx.heads, _dt(xt),
+        _lib.check(_lib.lib().focus_traj_time_bwd(_p(q2), _p(k2), _p(xt), _p(attn2), _p(dcat, C), (S + 1) * C, _p(dq2),
+                                                  _p(dk2), _p(dxt_a), 0, B, S, F_, ctx.heads, C // ctx.heads, _dt(xt),
                                                   _stream()), "traj_time_bwd")
         dk2f, xt2 = dk2.view(-1, C), xt.view(-1, C)
         dw = db = dwk = dbk = None
@@ -663,12 +666,14 @@ class _TrajTimeBlockFn(torch.autograd.Function):
             if dbk is not None:
                 db = torch.zeros(2 * C, device=xt.device, dtype=torch.float32)
                 db[:C].copy_(dbk)
-        return dq2, dxt, dw, db, None
+        dcls = dcat[:, :1].reshape(ctx.cls_shape) if ctx.needs_input_grad[4] else None
+        return dq2, dxt, dw, db, dcls, None
 
 
-def traj_time_block(q2, xt, w_kv, b_kv, heads):
-    """out [B,S,C] of the temporal step from q2 [B,S,C], x~ [B,S,F,C] and the proj_kv parameters."""
-    return _TrajTimeBlockFn.apply(q2, xt, w_kv, b_kv, heads)
+def traj_time_block(q2, xt, w_kv, b_kv, cls_out, heads):
+    """[B,1+S,C] input of `proj`: row 0 = cls_out, rows 1.. = the temporal step from q2 [B,S,C], x~ [B,S,F,C] and
+    the proj_kv parameters."""
+    return _TrajTimeBlockFn.apply(q2, xt, w_kv, b_kv, cls_out, heads)
 
 
 class _TrajTime2Fn(torch.autograd.Function):

@@ -94,7 +94,9 @@ class TrajectoryAttention(nn.Module):
             out = ops.traj_time2(q2, xt, wk, bk, h)
         else:
             # k2 = proj_kv(x~)[:C] ([B,S,F,C]) + temporal attention as one autograd node (:537-549)
-            out = ops.traj_time_block(q2, xt, self.proj_kv.weight, self.proj_kv.bias, h)
+            # (its output already is cat(cls_out, out): the attention rows are written into tokens 1.. in place)
+            y_in = ops.traj_time_block(q2, xt, self.proj_kv.weight, self.proj_kv.bias, cls_out, h)
+            return ops.linear(y_in, self.proj.weight, self.proj.bias, residual=residual), thw_prev
         y = ops.linear(torch.cat((cls_out, out), dim=1), self.proj.weight, self.proj.bias, residual=residual)
         return y, thw_prev
 

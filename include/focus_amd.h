@@ -145,12 +145,14 @@ int focus_traj_space_bwd(const void* qkv, const void* xt, const void* cls_out, c
                          const float* cls_lse, const void* dxt, const void* dxdiag, const void* dcls,
                          void* dqkv, void* workspace, size_t workspace_bytes, int B, int F, int P,
                          int heads, int d, int dtype, void* stream);
-int focus_traj_time_fwd(const void* q2, const void* k2, const void* xt, void* out, float* attn2, int B,
-                        int S, int F, int heads, int d, int dtype, void* stream);
-/* dxt_accum: 1 => dxt += (it already holds another cotangent of xt), 0 => dxt is overwritten. */
-int focus_traj_time_bwd(const void* q2, const void* k2, const void* xt, const float* attn2,
-                        const void* dout, void* dq2, void* dk2, void* dxt, int dxt_accum, int B, int S,
-                        int F, int heads, int d, int dtype, void* stream);
+/* out_bstride / dout_bstride: elements between consecutive batches of out / dout (S*C when dense; (S+1)*C when the
+ * rows live in tokens 1.. of a [B,1+S,C] buffer whose token 0 is the cls row -- saves the concatenation of
+ * attention.py:551 and the slice copy of its backward). */
+int focus_traj_time_fwd(const void* q2, const void* k2, const void* xt, void* out, int64_t out_bstride, float* attn2,
+                        int B, int S, int F, int heads, int d, int dtype, void* stream);
+int focus_traj_time_bwd(const void* q2, const void* k2, const void* xt, const float* attn2, const void* dout,
+                        int64_t dout_bstride, void* dq2, void* dk2, void* dxt, int dxt_accumulate, int B, int S, int F,
+                        int heads, int d, int dtype, void* stream);
 
 /* Re-associated time step.  With use_original_code=True the temporal logits are
  *   scale * q2[s,h,:] . (Wk[h] x~[s,f,:] + bk[h])  =  scale * (Wk[h]^T q2[s,h,:]) . x~[s,f,:]  + (a term constant in f),
