@@ -7,7 +7,9 @@
 // with a 16-B chunk swizzle (swz below) applied on the source address); the MFMA fragments, whose k index
 // runs over tile ROWS, are gathered with ds_read_b64_tr_b16 (cdna_hip_programming.md T10; semantics pinned by
 // tests/test_gpu_parity.py::test_tr16_probe...).  128x128 output tile, 4 waves (2x2), v_mfma_f32_16x16x32_bf16,
-// double-buffered, split over m with fp32 atomics into a zero-initialised C (the output is tiny, the reduction long).
+// double-buffered; the reduction over m is split over workgroups (the output is tiny, the reduction long): partial
+// tiles go to per-split fp32 slabs summed by a reduce kernel (or, without a workspace, fp32 atomics into a zeroed C).
+// Large outputs with long reductions take the wave-specialised kernel of gemm_mfma_tn_ws.hip; this one serves the rest.
 #include "focus_common.h"
 #include "gemm_internal.h"
 #include <algorithm>

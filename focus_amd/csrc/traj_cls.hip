@@ -1,6 +1,6 @@
 // traj_cls.hip -- the cls query row of trajectory attention (attention.py:514-519): one query per (batch, head)
 // attending over all N keys (cls + every patch token); head dim 64.
-// Replaces ~10 latency-bound M=1 GEMM/softmax launches per call by one kernel forward and one backward.
+// Replaces ~10 latency-bound M=1 GEMM/softmax launches per call by two small kernels forward and two backward.
 #include "focus_common.h"
 #include "traj_internal.h"
 

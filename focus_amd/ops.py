@@ -124,14 +124,14 @@ def transpose_pad(x, pad_to=64, dtype=None):
 
 
 def mm_tn(a, b):
-    """a[M,N]^T . b[M,K] -> [N,K] fp32 (weight gradients).  bf16: both operands are re-laid K(=M)-contiguous
-    by focus_transpose_pad and fed to the MFMA kernel; fp32: strided generic kernel."""
+    """a[M,N]^T . b[M,K] -> [N,K] fp32 (weight gradients).  bf16 with N, K multiples of 8: the TN MFMA kernels read both
+    operands row-major (no transposed copies); other bf16 shapes are re-laid K(=M)-contiguous by focus_transpose_pad
+    for the NT kernel; fp32: strided generic kernel."""
     M, N = a.shape
     K = b.shape[1]
     if a.dtype == torch.bfloat16 and USE_TN_GEMM and N % 8 == 0 and K % 8 == 0 and N >= 8 and K >= 8:
-        # both operands stay row-major: the TN MFMA kernel gathers its fragments with transposed LDS reads.
-        # zero-initialised + accumulate: the long reduction is split over workgroups (fp32 atomics)
-        # the long reduction is split over workgroups; partial tiles go to slabs and are summed by a second kernel
+        # both operands stay row-major: the TN MFMA kernel gathers its fragments with transposed LDS reads; the long
+        # reduction is split over workgroups, partial tiles go to slabs and are summed by a second kernel
         c = torch.empty(N, K, device=a.device, dtype=torch.float32)
         nb = _lib.lib().focus_gemm_tn_workspace_bytes(N, K, M)
         ws = torch.empty(nb // 4, device=a.device, dtype=torch.float32)
