@@ -150,7 +150,7 @@ __global__ __launch_bounds__(1024) void roi_bwd_sep_kernel(const T* __restrict__
                                                            int C, int H, int W, int K, int PH, int PW, float scale,
                                                            int sr, int aligned) {
     extern __shared__ __attribute__((aligned(16))) float gst[];   // [bins][RB_CS]: dout / count of the current RoI
-    __shared__ float Ay[RB_HMAX][RB_PMAX], Ax[RB_HMAX][RB_PMAX];
+    __shared__ __attribute__((aligned(16))) float Ay[RB_HMAX][RB_PMAX], Ax[RB_HMAX][RB_PMAX];
     __shared__ int match[1024], wcnt[16], nmatch_s;
     const int img = blockIdx.y, c0 = blockIdx.x * RB_CS;
     const int ch = threadIdx.x & 63, x = threadIdx.x >> 6;                 // x < W (blockDim = 64 * W)
@@ -198,6 +198,13 @@ __global__ __launch_bounds__(1024) void roi_bwd_sep_kernel(const T* __restrict__
                 }
             }
             __syncthreads();
+            // this thread's row of Ax in registers (4 x ds_read_b128 instead of PH*PW broadcast reads)
+            float ax[RB_PMAX];
+#pragma unroll
+            for (int q4 = 0; q4 < RB_PMAX / 4; ++q4) {
+                const float4 v = *reinterpret_cast<const float4*>(&Ax[x][q4 * 4]);
+                ax[q4 * 4 + 0] = v.x; ax[q4 * 4 + 1] = v.y; ax[q4 * 4 + 2] = v.z; ax[q4 * 4 + 3] = v.w;
+            }
             float t1[RB_PMAX];
 #pragma unroll
             for (int ph = 0; ph < RB_PMAX; ++ph) {
@@ -205,7 +212,7 @@ __global__ __launch_bounds__(1024) void roi_bwd_sep_kernel(const T* __restrict__
                 if (ph < PH) {
 #pragma unroll
                     for (int pw = 0; pw < RB_PMAX; ++pw)
-                        if (pw < PW) t = fmaf(gst[(ph * PW + pw) * RB_CS + ch], Ax[x][pw], t);
+                        if (pw < PW) t = fmaf(gst[(ph * PW + pw) * RB_CS + ch], ax[pw], t);
                 }
                 t1[ph] = t;
             }
@@ -214,8 +221,11 @@ __global__ __launch_bounds__(1024) void roi_bwd_sep_kernel(const T* __restrict__
                 if (y < H) {
                     float t = 0.f;
 #pragma unroll
-                    for (int ph = 0; ph < RB_PMAX; ++ph)
-                        if (ph < PH) t = fmaf(Ay[y][ph], t1[ph], t);
+                    for (int q4 = 0; q4 < RB_PMAX / 4; ++q4) {
+                        const float4 a = *reinterpret_cast<const float4*>(&Ay[y][q4 * 4]);   // zero beyond PH
+                        t = fmaf(a.x, t1[q4 * 4 + 0], t); t = fmaf(a.y, t1[q4 * 4 + 1], t);
+                        t = fmaf(a.z, t1[q4 * 4 + 2], t); t = fmaf(a.w, t1[q4 * 4 + 3], t);
+                    }
                     acc[y] += t;
                 }
             }
