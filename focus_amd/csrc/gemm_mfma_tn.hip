@@ -253,6 +253,7 @@ TnPlan tn_plan(int M, int N, int K) {
     p.tiles_j = (N + BJ - 1) / BJ;
     const int tiles = p.tiles_i * p.tiles_j;
     p.splits = std::max(1, std::min((2 * 256 + tiles - 1) / tiles, (K + 4 * BKM - 1) / (4 * BKM)));
+    if (K <= 1024) p.splits = 1;        // short reductions (slot / object-token layers): one unit per tile, no reduce launch
     p.m_per_split = ((K + p.splits - 1) / p.splits + BKM - 1) / BKM * BKM;
     p.splits = (K + p.m_per_split - 1) / p.m_per_split;
     return p;
@@ -300,9 +301,13 @@ int focus_gemm_mfma_tn(const focus_gemm_desc& d, hipStream_t s) {
     const size_t lds = 4 * TILE;
     static bool once = (hipFuncSetAttribute((const void*)gemm_tn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds) == hipSuccess);
     (void)once;
-    hipLaunchKernelGGL(gemm_tn_kernel, dim3(tiles * splits), dim3(256), lds, s, d, tiles_i, tiles_j, splits, m_per_split);
+    // one split and a dense output: the "slab" is C itself, no reduce launch
+    const bool direct = d.aux && splits == 1 && d.rsC == d.N;
+    focus_gemm_desc dd = d;
+    if (direct) dd.aux = d.C;
+    hipLaunchKernelGGL(gemm_tn_kernel, dim3(tiles * splits), dim3(256), lds, s, dd, tiles_i, tiles_j, splits, m_per_split);
     FOCUS_CHECK_LAUNCH();
-    if (d.aux) {
+    if (d.aux && !direct) {
         const int64_t n4 = (int64_t)d.M * d.N / 4;
         hipLaunchKernelGGL(tn_reduce_kernel, dim3((unsigned)cdiv64(n4, 256)), dim3(256), 0, s, (const float*)d.aux,
                            (float*)d.C, n4, splits, d.N, d.rsC);
