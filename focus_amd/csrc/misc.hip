@@ -9,7 +9,7 @@ namespace {
 // grid (ceil(N/64), MB): each block sums a strip of rows for 64 columns, 256 threads = 4 row-lanes x 64.
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, float* __restrict__ out, int M, int N,
-                                                     int64_t ld_, int rows_per_block) {
+                                                     int64_t ld_, int rows_per_block, int accumulate) {
     __shared__ float red[4][64];
     const int c = blockIdx.x * 64 + (threadIdx.x & 63), r4 = threadIdx.x >> 6;
     const int m_begin = blockIdx.y * rows_per_block;
@@ -21,13 +21,14 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, fl
     __syncthreads();
     if (r4 == 0 && c < N) {
         const int l = threadIdx.x;
-        atomicAdd(out + c, red[0][l] + red[1][l] + red[2][l] + red[3][l]);
+        const float t = red[0][l] + red[1][l] + red[2][l] + red[3][l];
+        if (gridDim.y == 1 && !accumulate) out[c] = t; else atomicAdd(out + c, t);
     }
 }
 
 // 16-byte loads: thread (tx, ty) sums columns 8*tx..8*tx+7 over rows ty, ty+8, ... of its strip
 __global__ __launch_bounds__(256) void colsum_bf16_vec_kernel(const bf16_t* __restrict__ x, float* __restrict__ out,
-                                                              int M, int N, int64_t ld_, int rows_per_block) {
+                                                              int M, int N, int64_t ld_, int rows_per_block, int accumulate) {
     __shared__ float red[8][32][9];
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
     const int c = (blockIdx.x * 32 + tx) * 8;
@@ -50,7 +51,7 @@ __global__ __launch_bounds__(256) void colsum_bf16_vec_kernel(const bf16_t* __re
         float t = 0.f;
 #pragma unroll
         for (int y = 0; y < 8; ++y) t += red[y][t2][j];
-        atomicAdd(out + cc, t);
+        if (gridDim.y == 1 && !accumulate) out[cc] = t; else atomicAdd(out + cc, t);
     }
 }
 
@@ -324,18 +325,21 @@ extern "C" int focus_colsum(const void* x, float* out, int M, int N, int64_t row
     if (!x || !out) return FOCUS_ERR_NULL;
     if (M <= 0 || N <= 0) return FOCUS_OK;
     hipStream_t s = (hipStream_t)stream;
-    if (!accumulate && hipMemsetAsync(out, 0, sizeof(float) * N, s) != hipSuccess) return FOCUS_ERR_LAUNCH;
-    if (dtype == FOCUS_BF16 && (N & 7) == 0 && (row_stride & 7) == 0 && focus_aligned(x, 16)) {
+    // a single row strip stores its sums directly: no zero fill, no atomics (short matrices: slot / object-token layers)
+    const bool vec = dtype == FOCUS_BF16 && (N & 7) == 0 && (row_stride & 7) == 0 && focus_aligned(x, 16);
+    const bool one_strip = M <= (vec ? 512 : 256);
+    if (!accumulate && !one_strip && hipMemsetAsync(out, 0, sizeof(float) * N, s) != hipSuccess) return FOCUS_ERR_LAUNCH;
+    if (vec) {
         const int rpb = 512;
         hipLaunchKernelGGL(colsum_bf16_vec_kernel, dim3((N + 255) / 256, (M + rpb - 1) / rpb), dim3(256), 0, s,
-                           (const bf16_t*)x, out, M, N, row_stride, rpb);
+                           (const bf16_t*)x, out, M, N, row_stride, rpb, accumulate);
         FOCUS_CHECK_LAUNCH();
         return FOCUS_OK;
     }
     const int rpb = 256;
     dim3 grid((N + 63) / 64, (M + rpb - 1) / rpb);
     DISPATCH_T(dtype, hipLaunchKernelGGL((colsum_kernel<T>), grid, dim3(256), 0, s, (const T*)x, out, M, N,
-                                         row_stride, rpb));
+                                         row_stride, rpb, accumulate));
     FOCUS_CHECK_LAUNCH();
     return FOCUS_OK;
 }
