@@ -37,7 +37,7 @@ def worker():
         torch.cuda.synchronize()
         us = e0.elapsed_time(e1) * 1e3 / n
         out.append("%dx%dx%d: %.1f us %.0f TF/s err=%.1e" % (M, N, K, us, 2.0 * M * N * K / us / 1e6, err))
-    print("variant %s | " % os.environ.get("FOCUS_GEMM_VARIANT", "0") + " | ".join(out), flush=True)
+    print("loaders %s | " % os.environ.get("FOCUS_GEMM_NLOAD", "4") + " | ".join(out), flush=True)
 
 
 if __name__ == "__main__":
@@ -45,5 +45,5 @@ if __name__ == "__main__":
         worker()
     else:
         for v in (sys.argv[1:] or ["4", "8"]):          # loader waves per workgroup (FOCUS_GEMM_NLOAD)
-            env = dict(os.environ, FOCUS_GEMM_NLOAD=v, FOCUS_GEMM_VARIANT=v)
+            env = dict(os.environ, FOCUS_GEMM_NLOAD=v)
             subprocess.call([sys.executable, os.path.abspath(__file__), "worker"], env=env)
