@@ -1,31 +1,39 @@
 #!/usr/bin/env python3
 """bench.py -- clips/sec (forward + backward + optimizer step) of ORViT-Motionformer 16x224, bf16, on N MI355X.
 
-  python bench.py --gpus N --steps K --warmup W            (N>1: launched by torch.distributed.run)
+  python bench.py --gpus N --steps K --warmup W
+
+N > 1 launches itself: the parent (which never touches the GPU) spawns one process per GPU through the mirror of the
+reference's launcher (focus_amd/slowfast/utils/misc.py:launch_job -> multiprocessing.run, slowfast/utils/misc.py:285-313)
+and exits non-zero if any child fails.  Under `python -m torch.distributed.run ... bench.py --gpus N` (RANK/WORLD_SIZE in
+the environment) each process joins the group it was given instead.
 
 One step = one pass of the hot path over one synthetic minibatch (batch 8 clips per GPU, 4 boxes/frame):
 build_model(cfg) -> model(inputs, meta) -> label-smoothing CE -> backward (DDP/RCCL all-reduce overlapped) ->
 clip-norm -> AdamW.  Prints ONE JSON line on rank 0 (contract in the task statement), with
   roofline     : the dominant kernel (bf16 MFMA GEMM), executed 2*M*N*K FLOPs / HIP-event time, vs 2.5 PF/s
-  cpu_baseline : the CPU oracle (oracle/focus_oracle.py, fp32) timed on this box's host cores on 1 clip.
+  cpu_baseline : the CPU oracle (oracle/focus_oracle.py, fp32) timed on this box's host cores on a bounded sample
+  steve / hr   : sub-records for BASELINE configs[2] (slot-attention update at B=32,T=24,N=4096,K=11) and the
+                 configs[4] shape (16x336, 6 objects, EK heads) on one GPU  (N == 1 only; --workload picks one alone).
 """
 import argparse
 import json
 import os
+import socket
 import sys
 import time
-
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 PEAK_BF16_TFLOPS = 2500.0                 # MI355X dense bf16 MFMA (MI355X_MICROARCH.md chip table)
+PEAK_HBM_GBS = 8000.0                     # MI355X HBM3E spec
 ALG_GF_PER_CLIP = 1894.9                  # fwd+bwd GFLOP per clip, 16x224, O=4
+ALG_GF_PER_CLIP_HR = 5099.0               # 16x336, O=6
 
 
-def make_cfg(n_gpus, per_gpu_batch, mixed=True):
+def make_cfg(n_gpus, per_gpu_batch, mixed=True, hr=False):
     from focus_amd.slowfast.config.defaults import get_cfg
     cfg = get_cfg()
     # configs/ORViT/SSv2_ORViT-MF_224_16x4.yaml (hot-path keys) with the synthetic-run overrides of SURVEY 8(d)
@@ -40,189 +48,428 @@ def make_cfg(n_gpus, per_gpu_batch, mixed=True):
         "MODEL.LOSS_FUNC", "label_smoothing_cross_entropy", "SOLVER.BASE_LR", 5e-5, "SOLVER.WEIGHT_DECAY", 5e-2,
         "SOLVER.OPTIMIZING_METHOD", "adamw", "NUM_GPUS", n_gpus, "RNG_SEED", 0,
     ])
+    if hr:
+        # configs/ORViT/EK_ORVIT_MF_HR.yaml:3,11,15,22 with ORVIT.O 6 (BASELINE configs[4])
+        cfg.merge_from_list(["DATA.TRAIN_CROP_SIZE", 336, "DATA.TEST_CROP_SIZE", 336, "ORVIT.O", 6,
+                             "TRAIN.DATASET", "epickitchens", "MODEL.NUM_CLASSES", [97, 300],
+                             "MODEL.LOSS_FUNC", "ek_loss"])
     return cfg
 
 
-def cpu_baseline(model, cfg, seconds_budget=30.0):
-    """The CPU oracle on a bounded sample (1 clip, fwd+bwd, fp32), on this host's cores."""
+def host_cores():
+    """(threads this process may use, physical cores among them)."""
+    try:
+        allowed = sorted(os.sched_getaffinity(0))
+    except AttributeError:
+        allowed = list(range(os.cpu_count() or 1))
+    phys = set()
+    try:
+        cur = {}
+        for line in open("/proc/cpuinfo"):
+            if ":" in line:
+                k, v = [s.strip() for s in line.split(":", 1)]
+                cur[k] = v
+            elif cur:
+                if int(cur.get("processor", -1)) in allowed:
+                    phys.add((cur.get("physical id", "0"), cur.get("core id", cur.get("processor"))))
+                cur = {}
+        if cur and int(cur.get("processor", -1)) in allowed:
+            phys.add((cur.get("physical id", "0"), cur.get("core id", cur.get("processor"))))
+    except Exception:
+        pass
+    return len(allowed), (len(phys) or len(allowed))
+
+
+def cpu_baseline(model, cfg, seconds_budget=25.0):
+    """the CPU oracle, fp32, B=2 clips fwd+bwd on the physical cores of this host (1 warm-up + up to 3
+    timed iterations inside a bounded budget), plus a 1-thread figure on one TrajectoryAttentionBlock of the same
+    sample (the whole model on one thread would take minutes)."""
+    import torch
     from focus_amd.train import synthetic_batch
     from oracle import focus_oracle as fo
-    cores = min(os.cpu_count() or 1, 32)
+    nthreads, phys = host_cores()
+    cores = max(1, min(phys, nthreads, 64))
     torch.set_num_threads(cores)
     base = model.module if hasattr(model, "module") else model
     params = {k: v.detach().float().cpu().clone().requires_grad_(v.is_floating_point())
               for k, v in base.state_dict().items()}
-    inputs, labels, meta = synthetic_batch(cfg, 1, "cpu", seed=123)
+    Bc = 2
+    inputs, labels, meta = synthetic_batch(cfg, Bc, "cpu", seed=123)
     ocfg = dict(depth=cfg.MF.DEPTH, heads=cfg.MF.NUM_HEADS, orvit_layers=list(cfg.ORVIT.LAYERS),
                 temporal_resolution=cfg.MF.TEMPORAL_RESOLUTION,
                 patch=(cfg.MF.PATCH_SIZE_TEMP, cfg.MF.PATCH_SIZE, cfg.MF.PATCH_SIZE), crop=cfg.DATA.TRAIN_CROP_SIZE)
     times, logits = [], None
     t_all = time.time()
-    for it in range(3):
+    for it in range(4):
         t0 = time.time()
         logits = fo.motionformer_forward(params, inputs[0], meta["orvit_bboxes"], ocfg, training=True)
         fo.label_smoothing_ce(logits, labels).backward()
         times.append(time.time() - t0)
-        if time.time() - t_all > seconds_budget:
+        if time.time() - t_all + times[-1] > seconds_budget:
             break
-    t = min(times[1:]) if len(times) > 1 else times[0]
-    # the same clip through the HIP path (fp32 masters, bf16 compute): a full-size parity figure
+    timed = times[1:] if len(times) > 1 else times
+    t = sum(timed) / len(timed)
+    # one block, same sample size, all cores vs one thread (thread-scaling normalisation)
+    D = cfg.MF.EMBED_DIM
+    N = 1 + cfg.MF.TEMPORAL_RESOLUTION * (cfg.DATA.TRAIN_CROP_SIZE // cfg.MF.PATCH_SIZE) ** 2
+    bp = {k: v.detach().clone().requires_grad_(True) for k, v in params.items() if k.startswith("blocks.0.")}
+    xb = torch.randn(1, N, D, generator=torch.Generator().manual_seed(5))
+    side = cfg.DATA.TRAIN_CROP_SIZE // cfg.MF.PATCH_SIZE
+
+    def block_once():
+        t0 = time.time()
+        y = fo.trajectory_block(bp, "blocks.0", xb.clone().requires_grad_(True),
+                                [cfg.MF.TEMPORAL_RESOLUTION, side, side], cfg.MF.NUM_HEADS)
+        y.sum().backward()
+        return time.time() - t0
+    one = None
+    try:
+        block_once()
+        t_all_block = block_once()
+        torch.set_num_threads(1)
+        t_one_block = block_once()
+        one = {"block": "TrajectoryAttentionBlock fwd+bwd, 1 clip", "all_core_s": round(t_all_block, 3),
+               "one_thread_s": round(t_one_block, 3),
+               "clips_per_s_one_thread_extrapolated": round(Bc / t * t_all_block / t_one_block, 5)}
+    except Exception as e:       # the normalisation figure must never lose the baseline
+        one = {"failed": repr(e)}
+    finally:
+        torch.set_num_threads(cores)
+    # the same clips through the HIP path (fp32 masters, bf16 compute): a full-size parity figure
     was_training = base.training
     base.eval()
     with torch.no_grad():
-        gi, _, gm = synthetic_batch(cfg, 1, "cuda", seed=123)
+        gi, _, gm = synthetic_batch(cfg, Bc, "cuda", seed=123)
         probs = base(gi, gm).float().cpu()
     base.train(was_training)
     ref = torch.softmax(logits.detach(), dim=-1)
     err = float((probs - ref).abs().max() / ref.abs().max())
-    return {"value": round(1.0 / t, 4), "unit": "clips/s", "cores": cores, "kind": "port",
-            "sample": "1 clip ORViT-MF 16x224 O=4 fwd+bwd fp32 through oracle/focus_oracle.py, best of %d" % max(1, len(times) - 1),
-            "hip_vs_oracle_rel_err_bf16": round(err, 5)}
+    return {"value": round(Bc / t, 4), "unit": "clips/s", "cores": cores, "kind": "port",
+            "sample": "B=2 clips ORViT-MF 16x224 O=4 fwd+bwd fp32 through oracle/focus_oracle.py, 1 warm-up + %d timed "
+                      "iteration(s), mean; %d physical cores of %d usable threads" % (len(timed), phys, nthreads),
+            "one_thread": one, "hip_vs_oracle_rel_err_bf16": round(err, 5)}
 
 
 def pmc_traffic():
-    """HBM-side bytes per NT-GEMM launch from the committed PMC passes (bench.py cannot run rocprofv3 on itself):
-    last line of profiles/r01_pmc_hbm_traffic.txt, or None when the file is absent."""
+    """HBM-side bytes per NT-GEMM launch from the newest committed PMC pass (bench.py cannot run rocprofv3 on itself):
+    profiles/r*_pmc_hbm_traffic.txt, last line `... = <MB> MB @ <git head>`.  Returns (bytes, source) or (None, None):
+    the figure is a recorded constant, so its source commit travels with it."""
+    import glob
     try:
-        last = open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_hbm_traffic.txt")).read().strip().splitlines()[-1]
-        return round(float(last.rsplit("=", 1)[1].split("MB")[0]) * 1e6)
+        files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm_traffic.txt")))
+        path = files[-1]
+        last = open(path).read().strip().splitlines()[-1]
+        mb = float(last.rsplit("=", 1)[1].split("MB")[0])
+        head = last.split("@", 1)[1].strip() if "@" in last else "8b61332 (round 1)"
+        return round(mb * 1e6), "%s @ %s" % (os.path.basename(path), head)
     except Exception:
-        return None
+        return None, None
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=8, help="clips per GPU")
-    ap.add_argument("--fp32", action="store_true", help="TRAIN.MIXED_PRECISION False (precision path)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--gemm-shapes", action="store_true", help="print per-shape GEMM timings to stderr")
-    ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--backend", default="nccl", help="process-group backend (nccl = RCCL; gloo for a rehearsal)")
-    ap.add_argument("--same-device", action="store_true",
-                    help="rehearsal only: every rank uses cuda:0 (needs --backend gloo; RCCL wants one GPU per rank)")
-    args = ap.parse_args()
-
+# ----------------------------------------------------------------------------------------------------------------
+# the job every rank runs
+# ----------------------------------------------------------------------------------------------------------------
+def bench_job(cfg):
+    import torch
     import torch.distributed as dist
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 and world != args.gpus:
-        raise SystemExit("--gpus %d needs `python -m torch.distributed.run --nproc-per-node %d bench.py ...`"
-                         % (args.gpus, args.gpus))
-    if args.same_device:
-        local_rank = 0
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend=args.backend, rank=rank, world_size=world)   # "nccl" == RCCL on ROCm
+    a = cfg.BENCH
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    dev = torch.device("cuda", torch.cuda.current_device())
 
     from focus_amd import ops
     from focus_amd.slowfast.models import build_model
     from focus_amd.slowfast.models.losses import get_loss_func
     from focus_amd.slowfast.models.optimizer import construct_optimizer
+    from focus_amd.slowfast.utils import distributed as du
     from focus_amd.train import synthetic_batch, train_step
 
-    cfg = make_cfg(world if world > 1 else 1, args.batch, mixed=not args.fp32)
-    cfg.DIST_BACKEND = args.backend
+    du.init_distributed_training(cfg)
     torch.manual_seed(cfg.RNG_SEED)
-    model = build_model(cfg, gpu_id=local_rank)
-    model.train()
-    optimizer = construct_optimizer(model, cfg)
-    loss_fun = get_loss_func(cfg)(reduction="mean")
-    inputs, labels, meta = synthetic_batch(cfg, args.batch, dev, seed=1000 + rank)   # resident in HBM
+    out = None
+    if a.workload in ("orvit", "all"):
+        model = build_model(cfg, gpu_id=dev.index)
+        model.train()
+        optimizer = construct_optimizer(model, cfg)
+        loss_fun = get_loss_func(cfg)(reduction="mean")
+        inputs, labels, meta = synthetic_batch(cfg, a.batch, dev, seed=1000 + rank)   # resident in HBM
 
-    def sync():
+        def sync():
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize()
+
+        def timed(n, ctx=None):
+            sync()
+            t0 = time.perf_counter()
+            loss = None
+            for _ in range(n):
+                if ctx is not None:
+                    with ctx():
+                        _, loss = train_step(model, optimizer, loss_fun, inputs, labels, meta, cfg)
+                else:
+                    _, loss = train_step(model, optimizer, loss_fun, inputs, labels, meta, cfg)
+            sync()
+            dt = time.perf_counter() - t0
+            if world > 1:
+                tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                dt = float(tt.item())
+            return dt, loss
+
+        for _ in range(a.warmup):
+            train_step(model, optimizer, loss_fun, inputs, labels, meta, cfg)
+        dt, loss = timed(a.steps)
+
+        clips = a.batch * world * a.steps
+        value = clips / dt
+        out = {
+            "metric": "clips/sec (fwd+bwd+opt step) ORViT-MF 16x224", "value": round(value, 3), "unit": "clips/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * dt / a.steps, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32" if a.fp32 else "bf16", "data": "synthetic",
+            "config": {"workload": "ORViT-Motionformer 16x224, 4 objects, batch=%d per GPU (BASELINE configs[1])" % a.batch,
+                       "global_batch": a.batch * world, "frames": 16, "crop": 224, "objects": 4,
+                       "parallelism": "dp%d" % world, "optimizer": "adamw+clipnorm", "drop_path": cfg.MF.DROP_PATH,
+                       "backend": (cfg.DIST_BACKEND if world > 1 else None),
+                       "grad_allreduce": ("bf16" if cfg.DDP_BF16_GRADS else "fp32") if world > 1 else None},
+            "clips_per_sec_per_gpu": round(value / world, 3),
+            "model_mfma_frac_algorithmic": round(value / world * ALG_GF_PER_CLIP * 1e9 / (PEAK_BF16_TFLOPS * 1e12), 5),
+            "final_loss": round(float(loss.detach()), 4),
+        }
         if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
+            # exposed (non-overlapped) all-reduce: the same K steps with DDP's reducer switched off
+            dt_ns, _ = timed(a.steps, ctx=model.no_sync)
+            out["ms_per_step_no_allreduce"] = round(1e3 * dt_ns / a.steps, 3)
+            out["exposed_allreduce_ms"] = round(max(0.0, 1e3 * (dt - dt_ns) / a.steps), 3)
 
-    for _ in range(args.warmup):
-        train_step(model, optimizer, loss_fun, inputs, labels, meta, cfg)
-    sync()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        _, loss = train_step(model, optimizer, loss_fun, inputs, labels, meta, cfg)
-    sync()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+        if rank == 0 and not a.no_roofline and not a.fp32:
+            # second pass over the same K steps with HIP events around every launch of the dominant kernel
+            ops.GEMM_TIMING = []
+            for _ in range(a.steps):
+                train_step(model, optimizer, loss_fun, inputs, labels, meta, cfg)
+            torch.cuda.synchronize()
+            allrecs, ops.GEMM_TIMING = ops.GEMM_TIMING, None
+            recs = [r for r in allrecs if r[3] == "nt"]          # the dominant kernel: forward / dX GEMMs
+            tn = [r for r in allrecs if r[3] == "tn"]            # weight-gradient kernel, reported beside it
+            fl = sum(r[0] for r in recs)
+            ms = sum(r[1].elapsed_time(r[2]) for r in recs)
+            ach = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+            tn_ms = sum(r[1].elapsed_time(r[2]) for r in tn)
+            if a.gemm_shapes:
+                import collections
+                by = collections.defaultdict(lambda: [0, 0.0, 0.0])
+                for r in allrecs:
+                    e = by[(r[3],) + r[4]]
+                    e[0] += 1; e[1] += r[1].elapsed_time(r[2]); e[2] += r[0]
+                print("kind (M,N,K,batch,epi)  calls/step  avg_us  TF/s  ms/step", file=sys.stderr)
+                for k, e in sorted(by.items(), key=lambda kv: -kv[1][1]):
+                    print("%-44s %5.1f %8.1f %7.0f %7.3f" % (k, e[0] / a.steps, 1e3 * e[1] / e[0], e[2] / e[1] / 1e9,
+                                                             e[1] / a.steps), file=sys.stderr)
+            tn_tf = sum(r[0] for r in tn) / (tn_ms * 1e-3) / 1e12 if tn_ms > 0 else 0.0
+            # algorithmic HBM bytes of the same launches: A + B + C (+ aux, residual are not known here: lower bound)
+            alg = sum(2.0 * r[4][3] * (r[4][0] * r[4][2] + r[4][1] * r[4][2] + r[4][0] * r[4][1]) for r in recs)
+            traffic, traffic_src = pmc_traffic()
+            out["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                               "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
+                               "traffic_unit": "bytes/launch (PMC: 2*FETCH_SIZE + WRITE_SIZE, separate rocprofv3 passes)",
+                               "traffic_source": traffic_src,
+                               "algorithmic_bytes_per_launch": round(alg / max(len(recs), 1)),
+                               "kernel": "bf16 NT GEMM (focus_amd/csrc/gemm_mfma_ws.hip, gemm_mfma.hip)",
+                               "launches_per_step": len(recs) // max(a.steps, 1),
+                               "avg_launch_us": round(1e3 * ms / max(len(recs), 1), 2),
+                               "kernel_ms_per_step": round(ms / max(a.steps, 1), 3),
+                               "weight_grad_kernel": {"kernel": "bf16 TN GEMM (gemm_mfma_tn_ws.hip, gemm_mfma_tn.hip)",
+                                                      "achieved": round(tn_tf, 2),
+                                                      "ms_per_step": round(tn_ms / max(a.steps, 1), 3)}}
+        elif world > 1 and not a.no_roofline and not a.fp32:
+            for _ in range(a.steps):       # keep ranks in lock-step with rank 0's instrumented pass
+                train_step(model, optimizer, loss_fun, inputs, labels, meta, cfg)
+            torch.cuda.synchronize()
 
-    clips = args.batch * world * args.steps
-    value = clips / dt
-    out = {
-        "metric": "clips/sec (fwd+bwd+opt step) ORViT-MF 16x224", "value": round(value, 3), "unit": "clips/s",
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32" if args.fp32 else "bf16", "data": "synthetic",
-        "config": {"workload": "ORViT-Motionformer 16x224, 4 objects, batch=%d per GPU (BASELINE configs[1])" % args.batch,
-                   "global_batch": args.batch * world, "frames": 16, "crop": 224, "objects": 4,
-                   "parallelism": "dp%d" % world, "optimizer": "adamw+clipnorm", "drop_path": cfg.MF.DROP_PATH},
-        "clips_per_sec_per_gpu": round(value / world, 3),
-        "model_mfma_frac_algorithmic": round(value / world * ALG_GF_PER_CLIP * 1e9 / (PEAK_BF16_TFLOPS * 1e12), 5),
-        "final_loss": round(float(loss.detach()), 4),
-    }
+        if rank == 0 and world == 1 and not a.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline(model, cfg)
+            except Exception as e:  # the baseline is a reported figure; never lose the bench line to it
+                out["cpu_baseline"] = {"value": None, "unit": "clips/s", "cores": host_cores()[1], "kind": "port",
+                                       "sample": "failed: %r" % (e,)}
+        del model, optimizer, inputs
+        ops.drop_caches()
+        torch.cuda.empty_cache()
 
-    if rank == 0 and not args.no_roofline and not args.fp32:
-        # second pass over the same K steps with HIP events around every launch of the dominant kernel
-        ops.GEMM_TIMING = []
-        for _ in range(args.steps):
-            train_step(model, optimizer, loss_fun, inputs, labels, meta, cfg)
-        torch.cuda.synchronize()
-        allrecs, ops.GEMM_TIMING = ops.GEMM_TIMING, None
-        recs = [r for r in allrecs if r[3] == "nt"]          # the dominant kernel: forward / dX GEMMs
-        tn = [r for r in allrecs if r[3] == "tn"]            # weight-gradient kernel, reported beside it
-        fl = sum(r[0] for r in recs)
-        ms = sum(r[1].elapsed_time(r[2]) for r in recs)
-        ach = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-        tn_ms = sum(r[1].elapsed_time(r[2]) for r in tn)
-        if args.gemm_shapes:
-            import collections
-            by = collections.defaultdict(lambda: [0, 0.0, 0.0])
-            for r in allrecs:
-                e = by[(r[3],) + r[4]]
-                e[0] += 1; e[1] += r[1].elapsed_time(r[2]); e[2] += r[0]
-            print("kind (M,N,K,batch,epi)  calls/step  avg_us  TF/s  ms/step", file=sys.stderr)
-            for k, e in sorted(by.items(), key=lambda kv: -kv[1][1]):
-                print("%-44s %5.1f %8.1f %7.0f %7.3f" % (k, e[0] / args.steps, 1e3 * e[1] / e[0], e[2] / e[1] / 1e9,
-                                                         e[1] / args.steps), file=sys.stderr)
-        tn_tf = sum(r[0] for r in tn) / (tn_ms * 1e-3) / 1e12 if tn_ms > 0 else 0.0
-        # algorithmic HBM bytes of the same launches: A + B + C (+ aux, residual are not known here: lower bound)
-        alg = sum(2.0 * r[4][3] * (r[4][0] * r[4][2] + r[4][1] * r[4][2] + r[4][0] * r[4][1]) for r in recs)
-        out["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                           "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": pmc_traffic(),
-                           "traffic_unit": "bytes/launch (PMC: 2*FETCH_SIZE + WRITE_SIZE, separate rocprofv3 passes, "
-                                           "profiles/r01_pmc_hbm_traffic.txt)",
-                           "algorithmic_bytes_per_launch": round(alg / max(len(recs), 1)),
-                           "kernel": "gemm_nt_ws_kernel / gemm_nt_kernel, bf16 NT GEMM (focus_amd/csrc/gemm_mfma_ws.hip, gemm_mfma.hip)",
-                           "launches_per_step": len(recs) // max(args.steps, 1),
-                           "avg_launch_us": round(1e3 * ms / max(len(recs), 1), 2),
-                           "kernel_ms_per_step": round(ms / max(args.steps, 1), 3),
-                           "weight_grad_kernel": {"kernel": "gemm_tn_ws_kernel / gemm_tn_kernel (gemm_mfma_tn_ws.hip, gemm_mfma_tn.hip)",
-                                                  "achieved": round(tn_tf, 2),
-                                                  "ms_per_step": round(tn_ms / max(args.steps, 1), 3)}}
-    elif world > 1 and not args.no_roofline and not args.fp32:
-        for _ in range(args.steps):       # keep ranks in lock-step with rank 0's instrumented pass
-            train_step(model, optimizer, loss_fun, inputs, labels, meta, cfg)
-        torch.cuda.synchronize()
-
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        try:
-            out["cpu_baseline"] = cpu_baseline(model, cfg)
-        except Exception as e:  # the baseline is a reported figure; never lose the bench line to it
-            out["cpu_baseline"] = {"value": None, "unit": "clips/s", "cores": os.cpu_count(), "kind": "port",
-                                   "sample": "failed: %r" % (e,)}
+    if world == 1 and a.workload in ("steve", "all") and not a.fp32:
+        rec = _guard(lambda: bench_steve(a, dev))
+        if out is None:
+            out = rec
+        else:
+            out["steve"] = rec
+    if world == 1 and a.workload in ("hr", "all") and not a.fp32:
+        rec = _guard(lambda: bench_hr(a, dev))
+        if out is None:
+            out = rec
+        else:
+            out["hr"] = rec
     if rank == 0:
         print(json.dumps(out), flush=True)
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+    return 0
+
+
+def _guard(fn):
+    try:
+        return fn()
+    except Exception as e:          # a sub-record must never lose the headline line
+        import traceback
+        traceback.print_exc(file=sys.stderr)
+        return {"failed": repr(e)}
+
+
+def bench_steve(a, dev):
+    """BASELINE configs[2]: SlotAttentionVideo update at B=32, T=24, N=4096 (64x64 feature map of 128x128 frames),
+    D=192, K=11, 3 iterations, fwd+bwd, bf16.  HBM-bound: algorithmic bytes from SURVEY 8(d) (6.11 GB forward;
+    backward re-reads inputs/k/v and writes their gradients: x3 in total)."""
+    import torch
+    from focus_amd import ops
+    from focus_amd.slowfast.models.STEVE.steve import SlotAttentionVideo
+    B, T, N, D, K, IT = a.steve_batch, 24, 4096, 192, 11, 3
+    torch.manual_seed(0)
+    m = SlotAttentionVideo(IT, K, D, D, 4 * D, num_predictor_blocks=1, num_predictor_heads=4, dropout=0.0).to(dev)
+    g = torch.Generator(device=dev).manual_seed(0)
+    x = torch.randn(B, T, N, D, device=dev, dtype=torch.bfloat16, generator=g).requires_grad_(True)
+    noise = torch.randn(B, K, D, device=dev, generator=g)
+
+    def step():
+        slots, attn = m(x, noise=noise)
+        (slots.float().square().mean() + attn.float().mean()).backward()
+        x.grad = None
+        for p in m.parameters():
+            p.grad = None
+        return slots, attn
+    for _ in range(max(1, min(a.warmup, 2))):
+        step()
+    torch.cuda.synchronize()
+    n = max(2, min(a.steps, 5))
+    t0 = time.perf_counter()
+    for _ in range(n):
+        slots, attn = step()
+    torch.cuda.synchronize()
+    ms = 1e3 * (time.perf_counter() - t0) / n
+    fwd_bytes = (B * T * N * D * 2) * (1 + 2 + 2) + B * T * N * K * 2         # inputs, write k/v, read k/v, attn out
+    alg = 3.0 * fwd_bytes
+    ach = alg / (ms * 1e-3) / 1e9
+    rowsum = float(attn.float().sum(-1).sub(1).abs().max())
+    ops.drop_caches()
+    return {"workload": "STEVE slot-attention update, movi_e 24x128x128 (N=4096 tokens/frame), 11 slots, 3 iters, "
+                        "batch=%d, fwd+bwd bf16 (BASELINE configs[2])" % B,
+            "ms_per_step": round(ms, 3), "clips_per_s": round(B / (ms * 1e-3), 2),
+            "slot_updates_per_s": round(B * T * IT * K / (ms * 1e-3), 1), "steps": n,
+            "roofline": {"bound": "hbm", "achieved": round(ach, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                         "frac": round(ach / PEAK_HBM_GBS, 4), "traffic": None,
+                         "algorithmic_bytes_per_step": int(alg),
+                         "note": "6.11 GB forward (SURVEY 8d) x3 for forward+backward"},
+            "attn_rowsum_max_err": round(rowsum, 5), "finite": bool(torch.isfinite(slots.float()).all())}
+
+
+def bench_hr(a, dev):
+    """BASELINE configs[4] shape on one GPU: ORViT-Motionformer-HR 16x336, 6 objects, EK verb+noun heads, bf16,
+    batch 4 per GPU, fwd+bwd+clip+AdamW.  (fp8 weights: not built; bf16 roofline is used.)"""
+    import torch
+    from focus_amd import ops
+    from focus_amd.slowfast.models import build_model
+    from focus_amd.slowfast.models.losses import get_loss_func
+    from focus_amd.slowfast.models.optimizer import construct_optimizer
+    from focus_amd.train import synthetic_batch, train_step
+    Bh = a.hr_batch
+    cfg = make_cfg(1, Bh, hr=True)
+    torch.manual_seed(0)
+    model = build_model(cfg, gpu_id=dev.index)
+    model.train()
+    opt = construct_optimizer(model, cfg)
+    loss_fun = get_loss_func(cfg)(reduction="mean")
+    inputs, labels, meta = synthetic_batch(cfg, Bh, dev, seed=77)
+    for _ in range(max(1, min(a.warmup, 2))):
+        train_step(model, opt, loss_fun, inputs, labels, meta, cfg)
+    torch.cuda.synchronize()
+    n = max(2, min(a.steps, 5))
+    t0 = time.perf_counter()
+    for _ in range(n):
+        _, loss = train_step(model, opt, loss_fun, inputs, labels, meta, cfg)
+    torch.cuda.synchronize()
+    ms = 1e3 * (time.perf_counter() - t0) / n
+    cps = Bh / (ms * 1e-3)
+    del model, opt
+    ops.drop_caches()
+    torch.cuda.empty_cache()
+    return {"workload": "ORViT-Motionformer-HR 16x336, 6 objects, EK heads (97+300), batch=%d, bf16 "
+                        "(BASELINE configs[4] shape on 1 GPU; fp8 weights not built)" % Bh,
+            "ms_per_step": round(ms, 3), "clips_per_s": round(cps, 3), "steps": n,
+            "model_mfma_frac_algorithmic": round(cps * ALG_GF_PER_CLIP_HR * 1e9 / (PEAK_BF16_TFLOPS * 1e12), 5),
+            "final_loss": round(float(loss.detach()), 4)}
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def main(argv=None, job=None):
+    """`job(cfg)` is what every rank runs (bench_job; tests pass a CPU stand-in to exercise the launch path)."""
+    job = job or bench_job
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=8, help="clips per GPU")
+    ap.add_argument("--workload", default="all", choices=["all", "orvit", "steve", "hr"],
+                    help="all = the headline ORViT-MF line with the steve / hr sub-records (N == 1)")
+    ap.add_argument("--steve-batch", type=int, default=32)
+    ap.add_argument("--hr-batch", type=int, default=4)
+    ap.add_argument("--fp32", action="store_true", help="TRAIN.MIXED_PRECISION False (precision path)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--gemm-shapes", action="store_true", help="print per-shape GEMM timings to stderr")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="process-group backend (nccl = RCCL; gloo for a rehearsal)")
+    ap.add_argument("--bf16-grads", action="store_true", help="cfg.DDP_BF16_GRADS: bf16 gradient buckets on the wire")
+    ap.add_argument("--same-device", action="store_true",
+                    help="rehearsal only: every rank uses cuda:0 (needs --backend gloo; RCCL wants one GPU per rank)")
+    args = ap.parse_args(argv)
+    if args.same_device and args.backend == "nccl":
+        raise SystemExit("--same-device needs --backend gloo")
+
+    env_world = os.environ.get("WORLD_SIZE")
+    n = int(env_world) if env_world is not None else max(args.gpus, 1)
+    if env_world is not None and args.gpus > 1 and n != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, n))
+
+    from focus_amd.slowfast.config.defaults import CfgNode
+    cfg = make_cfg(n, args.batch, mixed=not args.fp32)
+    cfg.DIST_BACKEND = args.backend
+    cfg.DDP_BF16_GRADS = bool(args.bf16_grads)
+    cfg.BENCH = CfgNode(vars(args))
+    if args.same_device:
+        os.environ["FOCUS_SAME_DEVICE"] = "1"
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+    if env_world is not None and n > 1:
+        # launched by torch.distributed.run: this process is one rank already
+        from focus_amd.slowfast.utils import multiprocessing as mpu
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        # one machine: shard 0 of 1, local rank == rank (env:// rendezvous)
+        mpu.run(local_rank, n, job, "env://", 0, 1, args.backend, cfg)
+        return 0
+    if n > 1:
+        # self-launch through the reference's launcher surface; the parent has not touched the GPU
+        from focus_amd.slowfast.utils.misc import launch_job
+        launch_job(cfg, "tcp://127.0.0.1:%d" % _free_port(), job)
+        return 0
+    if job is bench_job:
+        import torch
+        torch.cuda.set_device(0)
+    return job(cfg)
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

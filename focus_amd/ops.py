@@ -274,6 +274,12 @@ def _refresh_shadows_batched():
                     _shadow_cache[key] = (_shadow_cache[key][0], (w._version, w.data_ptr(), _shadow_gen), out)
 
 
+def drop_caches():
+    """Forget every bf16 weight shadow (frees their memory when a model is dropped between workloads)."""
+    _shadow_cache.clear()
+    _shadow_tables.clear()
+
+
 def shadow(w, dtype, transposed=False):
     if dtype == torch.float32 and not transposed:
         return w.detach()

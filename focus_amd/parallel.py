@@ -1,14 +1,15 @@
 """Data-parallel wrapper: one process per GPU, gradient all-reduce over RCCL/xGMI (build.py:79-83).
 
 torch's DistributedDataParallel is kept as the reducer (bucketed, overlapped with backward by autograd hooks);
-the custom HIP autograd Functions return ordinary .grad tensors, so its hooks fire unchanged.  Buckets are
-all-reduced in bf16 on GPUs (halves the per-link xGMI bytes: 295 MB instead of 590 MB per step for the
-147.5 M parameter model) and gradients stay views into the buckets."""
+the custom HIP autograd Functions return ordinary .grad tensors, so its hooks fire unchanged.  Gradients stay views
+into the buckets.  The all-reduce is fp32, as in the reference (plain DDP); cfg.DDP_BF16_GRADS = True (a build-owned
+key, default False) compresses the buckets to bf16 on the wire (295 MB instead of 590 MB per step for the
+147.5 M-parameter model) -- a numerics change against the reference, opt-in only."""
 import torch
 import torch.distributed as dist
 
 
-def wrap_ddp(model, device, cfg=None, bucket_cap_mb=64, compress=True):
+def wrap_ddp(model, device, cfg=None, bucket_cap_mb=64, compress=None):
     on_gpu = device is not None and device != "cpu" and torch.cuda.is_available()
     kwargs = dict(bucket_cap_mb=bucket_cap_mb, gradient_as_bucket_view=True, find_unused_parameters=False)
     if on_gpu:
@@ -16,6 +17,8 @@ def wrap_ddp(model, device, cfg=None, bucket_cap_mb=64, compress=True):
     else:
         ddp = torch.nn.parallel.DistributedDataParallel(model, **kwargs)
     backend = getattr(cfg, "DIST_BACKEND", "nccl") if cfg is not None else "nccl"
+    if compress is None:
+        compress = bool(cfg.get("DDP_BF16_GRADS", False)) if cfg is not None else False
     if compress and on_gpu and backend == "nccl":      # gloo has no bf16 reductions
         from torch.distributed.algorithms.ddp_comm_hooks import default_hooks
         ddp.register_comm_hook(dist.group.WORLD, default_hooks.bf16_compress_hook)

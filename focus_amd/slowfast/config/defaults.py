@@ -150,6 +150,7 @@ def _defaults():
     C.LOG_PERIOD = 10
     C.LOG_MODEL_INFO = False
     C.DIST_BACKEND = "nccl"
+    C.DDP_BF16_GRADS = False     # build-owned: bf16 gradient buckets on the wire (focus_amd/parallel.py)
     return C
 
 
