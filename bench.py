@@ -51,8 +51,7 @@ def make_cfg(n_gpus, per_gpu_batch, mixed=True, hr=False):
     if hr:
         # configs/ORViT/EK_ORVIT_MF_HR.yaml:3,11,15,22 with ORVIT.O 6 (BASELINE configs[4])
         cfg.merge_from_list(["DATA.TRAIN_CROP_SIZE", 336, "DATA.TEST_CROP_SIZE", 336, "ORVIT.O", 6,
-                             "TRAIN.DATASET", "epickitchens", "MODEL.NUM_CLASSES", [97, 300],
-                             "MODEL.LOSS_FUNC", "ek_loss"])
+                             "TRAIN.DATASET", "epickitchens", "MODEL.NUM_CLASSES", 97])
     return cfg
 
 

@@ -1,6 +1,10 @@
 #pragma once
 #include <hip/hip_runtime.h>
+// fused space-attention kernels: up to 14 blocks of 32 keys per frame (P <= 448: the HR 16x336 grid of 21x21 patches
+// + objects); the dQ kernel is instantiated per block count
+#define FOCUS_TRAJ_MAX_KEY_BLOCKS 14
 bool focus_traj_space_mfma_ok(int P, int d, int heads, int dtype);
+void focus_traj_space_tiling(int P, int* nkb, int* nt);
 int focus_traj_space_fwd_mfma(const void* qkv, void* xt, void* xdiag, float* lse, int B, int F, int P, int heads,
                               hipStream_t s);
 int focus_traj_space_bwd_mfma(const void* qkv, const void* xt, const float* lse, const void* dxt, const void* dxdiag,

@@ -287,19 +287,22 @@ template <int NKB>
 __global__ __launch_bounds__(64 * NKB) void traj_dkv_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dxt,
                                                             const bf16_t* __restrict__ dxsum,
                                                             const float* __restrict__ lse, const float* __restrict__ delta,
-                                                            bf16_t* __restrict__ dqkv, int B, int F, int P, int heads) {
+                                                            bf16_t* __restrict__ dqkv, int B, int F, int P, int heads,
+                                                            int NT) {
     __shared__ __attribute__((aligned(1024))) char ring[4 * 8192 + 4 * 256];   // 4 x (Q | dX), then 4 x (lse | del)
 
     const int S = F * P, N = S + 1, C = heads * HD;
     const int64_t tok = 3 * (int64_t)C;
-    const int f = blockIdx.x, bh = blockIdx.y, b = bh / heads, hh = bh % heads;
+    // workgroup = key tile jt (NKB blocks of 32 keys) of frame f; a frame has NT tiles (1 unless P > 224)
+    const int f = blockIdx.x / NT, jt = blockIdx.x - f * NT, bh = blockIdx.y, b = bh / heads, hh = bh % heads;
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
     const bf16_t* base = qkv + (int64_t)b * N * tok + hh * HD;
     const float scale = rsqrtf((float)HD), c2 = scale * LOG2E;
 
     // this wave's 32 keys as B operands [k=d][col=key]: kept in registers for the whole sweep
-    const int key = w * 32 + r;
+    const int kw = (jt * NKB + w) * 32;                   // first key (in the frame) of this wave's block
+    const int key = kw + r;
     const bool key_ok = key < P;
     bf16x8 kf[4], vf[4];
 #pragma unroll
@@ -414,7 +417,7 @@ __global__ __launch_bounds__(64 * NKB) void traj_dkv_kernel(const bf16_t* __rest
     for (int dblk = 0; dblk < 2; ++dblk)
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-            const int kl = w * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+            const int kl = kw + (i & 3) + 8 * (i >> 2) + 4 * h;
             if (kl < P) {
                 bf16_t* row = dqkv + ((int64_t)b * N + 1 + f * P + kl) * tok + hh * HD + dblk * 32 + r;
                 row[C] = f32_to_bf16(dk[dblk][i]);
@@ -423,15 +426,21 @@ __global__ __launch_bounds__(64 * NKB) void traj_dkv_kernel(const bf16_t* __rest
         }
 }
 
-template <int NKB>
-int launch_bwd(const void* qkv, const void* dxt, const void* dxsum, const float* lse, const float* delta, void* dqkv,
-               int B, int F, int P, int heads, hipStream_t s) {
+template <int NB>
+int launch_dq(const void* qkv, const void* dxt, const void* dxsum, const float* lse, const float* delta, void* dqkv,
+              int B, int F, int P, int heads, hipStream_t s) {
     const int S = F * P;
-    hipLaunchKernelGGL((traj_dq_kernel<NKB>), dim3((S + QT - 1) / QT, B * heads), dim3(256), 0, s, (const bf16_t*)qkv,
+    hipLaunchKernelGGL((traj_dq_kernel<NB>), dim3((S + QT - 1) / QT, B * heads), dim3(256), 0, s, (const bf16_t*)qkv,
                        (const bf16_t*)dxt, (const bf16_t*)dxsum, lse, delta, (bf16_t*)dqkv, B, F, P, heads);
     FOCUS_CHECK_LAUNCH();
-    hipLaunchKernelGGL((traj_dkv_kernel<NKB>), dim3(F, B * heads), dim3(64 * NKB), 0, s, (const bf16_t*)qkv,
-                       (const bf16_t*)dxt, (const bf16_t*)dxsum, lse, delta, (bf16_t*)dqkv, B, F, P, heads);
+    return FOCUS_OK;
+}
+
+template <int NKB>
+int launch_dkv(const void* qkv, const void* dxt, const void* dxsum, const float* lse, const float* delta, void* dqkv,
+               int B, int F, int P, int heads, int NT, hipStream_t s) {
+    hipLaunchKernelGGL((traj_dkv_kernel<NKB>), dim3(F * NT, B * heads), dim3(64 * NKB), 0, s, (const bf16_t*)qkv,
+                       (const bf16_t*)dxt, (const bf16_t*)dxsum, lse, delta, (bf16_t*)dqkv, B, F, P, heads, NT);
     FOCUS_CHECK_LAUNCH();
     return FOCUS_OK;
 }
@@ -443,21 +452,30 @@ int launch_bwd(const void* qkv, const void* dxt, const void* dxsum, const float*
 int focus_traj_space_bwd_mfma(const void* qkv, const void* xt, const float* lse, const void* dxt, const void* dxdiag,
                               float* delta, float* lse2, void* dxsum, void* dqkv, int B, int F, int P, int heads,
                               hipStream_t s) {
-    if (B * heads > 65535 || F > MAXF) return FOCUS_ERR_SHAPE;
+    if (B * heads > 65535 || F > MAXF || P > 32 * FOCUS_TRAJ_MAX_KEY_BLOCKS) return FOCUS_ERR_SHAPE;
     const int S = F * P;
     const int64_t rows = (int64_t)B * S;
     const int64_t nchunks = rows * F * heads * (HD / 8);
     hipLaunchKernelGGL(traj_delta_kernel, dim3((unsigned)cdiv64(nchunks, 256)), dim3(256), 0, s, (const bf16_t*)dxt,
                        (const bf16_t*)dxdiag, (const bf16_t*)xt, lse, delta, lse2, (bf16_t*)dxsum, nchunks, S, F, P, heads);
     FOCUS_CHECK_LAUNCH();
-    switch ((P + 31) / 32) {     // exact block count: the kernels rely on NKB == ceil(P/32)
-        case 1: return launch_bwd<1>(qkv, dxt, dxsum, lse2, delta, dqkv, B, F, P, heads, s);
-        case 2: return launch_bwd<2>(qkv, dxt, dxsum, lse2, delta, dqkv, B, F, P, heads, s);
-        case 3: return launch_bwd<3>(qkv, dxt, dxsum, lse2, delta, dqkv, B, F, P, heads, s);
-        case 4: return launch_bwd<4>(qkv, dxt, dxsum, lse2, delta, dqkv, B, F, P, heads, s);
-        case 5: return launch_bwd<5>(qkv, dxt, dxsum, lse2, delta, dqkv, B, F, P, heads, s);
-        case 6: return launch_bwd<6>(qkv, dxt, dxsum, lse2, delta, dqkv, B, F, P, heads, s);
+    int rc = FOCUS_ERR_SHAPE;
+    // dQ streams the frame's ceil(P/32) key blocks (exact count: the tail mask sits in the last one)
+#define DQ(K) case K: rc = launch_dq<K>(qkv, dxt, dxsum, lse2, delta, dqkv, B, F, P, heads, s); break
+    switch ((P + 31) / 32) {
+        DQ(1); DQ(2); DQ(3); DQ(4); DQ(5); DQ(6); DQ(7); DQ(8); DQ(9); DQ(10); DQ(11); DQ(12); DQ(13); DQ(14);
         default: break;
     }
-    return launch_bwd<7>(qkv, dxt, dxsum, lse2, delta, dqkv, B, F, P, heads, s);
+#undef DQ
+    if (rc) return rc;
+    // dK/dV: one workgroup per (frame, key tile of NKB blocks), one wave per block
+    int nkb, nt;
+    focus_traj_space_tiling(P, &nkb, &nt);
+#define DKV(K) case K: return launch_dkv<K>(qkv, dxt, dxsum, lse2, delta, dqkv, B, F, P, heads, nt, s)
+    switch (nkb) {
+        DKV(1); DKV(2); DKV(3); DKV(4); DKV(5); DKV(6); DKV(7);
+        default: break;
+    }
+#undef DKV
+    return FOCUS_ERR_SHAPE;
 }

@@ -7,7 +7,10 @@
 // accumulator rows, queries on the lanes), so the whole per-(query,frame) softmax is lane-local (one exchange with
 // the partner half-wave), and the normalised probabilities feed the P.V product straight from the accumulator
 // registers as the B operand (cdna_hip_programming.md section 3, "accumulator tile as the next MFMA's operand").
-// Exact softmax per frame (P <= 224 keys fit the register tile): no online rescaling.  Outputs x~ [B,S,F,C],
+// P <= 224: the frame's keys fit the register tile and the softmax is exact in one pass.  224 < P <= 448 (the HR
+// 16x336 config: 21x21 patches + objects): the frame is cut into NT key tiles of NKB*32 keys (NKB*NT == ceil(P/32),
+// so only the last block of the last tile is ragged) that are merged by an online softmax (one rescale of the 32
+// output accumulators per extra tile; frames never share a tile, attention.py:524-529).  Outputs x~ [B,S,F,C],
 // x_diag [B,S,C] (= x~ at the query's own frame) and the per-(query,frame) log-sum-exp for backward; rows leave
 // through a per-wave LDS slab so every global store is a 16-byte piece of a 128-byte row.
 #include "focus_common.h"
@@ -50,10 +53,10 @@ __device__ __forceinline__ bf16x8 col_frag(const char* tile, int r0, int c0, int
     return p.v;
 }
 
-template <int NKB>
+template <int NKB, bool MULTI>
 __global__ __launch_bounds__(256, 2) void traj_space_fwd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ xt,
                                                                 bf16_t* __restrict__ xdiag, float* __restrict__ lse,
-                                                                int B, int F, int P, int heads) {
+                                                                int B, int F, int P, int heads, int NTarg) {
     constexpr int KROWS = NKB * 32;
     // K and V tiles are SEPARATE LDS objects on purpose: with one array the compiler cannot tell a ds_read of K from
     // an LDS-DMA to V in flight and drains vmcnt(0) before every first read (cdna_hip_programming.md section 5)
@@ -70,6 +73,8 @@ __global__ __launch_bounds__(256, 2) void traj_space_fwd_kernel(const bf16_t* __
     const bool q_valid = blockIdx.x * QT + w * 32 + r < S;
     const bf16_t* base = qkv + (int64_t)b * N * tok + hh * HD;
     const float c2 = rsqrtf((float)HD) * 1.44269504088896341f;   // scale * log2(e)
+    const int NT = MULTI ? NTarg : 1;                            // key tiles per frame
+    const int U = F * NT;                                        // stream steps: (frame, key tile)
 
     // Q fragments: B operand of the swapped product, lane (r,h) holds Q[q=r][16*ks + 8h + j]
     bf16x8 qf[4];
@@ -85,25 +90,32 @@ __global__ __launch_bounds__(256, 2) void traj_space_fwd_kernel(const bf16_t* __
     // Waits are counted: a wave's only other vector-memory traffic is stores, and loads retire in order, so
     // "at most NKB outstanding" means every load older than the last NKB has landed.
     const int drow = lane >> 3, dkey = ((drow & 2) << 1) | ((drow >> 1) & 2);          // key bits of row&7 (see swz)
-    auto dma_tile = [&](char* tile, int f, int part) __attribute__((always_inline)) {
+    auto dma_tile = [&](char* tile, int f, int kbase, int part) __attribute__((always_inline)) {
 #pragma unroll
         for (int g = 0; g < NKB; ++g) {
             const int t = g * 4 + w;                                  // 8-row group of the tile
             const int row = t * 8 + drow;
             const int key = dkey | ((t & 1));                         // bit 3 of the row = bit 0 of t
-            const bf16_t* src = base + (int64_t)(1 + f * P + min(row, P - 1)) * tok + part * C + (((lane & 7) ^ key) << 3);
+            const bf16_t* src = base + (int64_t)(1 + f * P + min(kbase + row, P - 1)) * tok + part * C + (((lane & 7) ^ key) << 3);
             glds16(src, __builtin_amdgcn_readfirstlane(lds_addr_of(tile) + t * 1024));
         }
     };
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) asm volatile("" : "+v"(qf[ks]));   // Q loads retired in the compiler's bookkeeping too
-    dma_tile(sK, 0, 1);
-    dma_tile(sV, 0, 2);
+    dma_tile(sK, 0, 0, 1);
+    dma_tile(sV, 0, 0, 2);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    for (int f = 0; f < F; ++f) {
-        const bool more = f + 1 < F;
+    // online-softmax state of the current frame (MULTI): running max (raw logits), this lane's partial sum, outputs
+    float m_run = -INFINITY, sum_run = 0.f;
+    f32x16 y[2];
+    int f = 0, j = 0;                                 // frame and key tile of step u
+    for (int u = 0; u < U; ++u) {
+        const bool more = u + 1 < U;
+        const int jn = (MULTI && j + 1 < NT) ? j + 1 : 0, fn = jn ? f : f + 1;   // step u+1
+        const int kbase = MULTI ? j * KROWS : 0;
+        const bool first = !MULTI || j == 0, last = !MULTI || j == NT - 1;
         // ---- logits: acc[kb][reg] = sum_d K[kb*32 + row(reg,h)][d] * Q[q=r][d] ----
         f32x16 acc[NKB];
 #pragma unroll
@@ -118,7 +130,7 @@ __global__ __launch_bounds__(256, 2) void traj_space_fwd_kernel(const bf16_t* __
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                 // A: every wave has read K_f
-        if (more) dma_tile(sK, f + 1, 1);
+        if (more) dma_tile(sK, fn, jn * KROWS, 1);
         // ---- per-(query, frame) softmax over the P keys: this lane holds half of its query's keys.
         // VALU-lean form (the kernel is softmax-bound, not MFMA-bound): raw-logit max, one fma + one exp2 per
         // element, only the tail key block is masked, and the 1/sum normalisation is applied to the 32 outputs
@@ -130,7 +142,7 @@ __global__ __launch_bounds__(256, 2) void traj_space_fwd_kernel(const bf16_t* __
             // is known at compile time -- a run-time test per block made the compiler materialise all 16*NKB key
             // masks (cmp + s_or + cndmask + SGPR spills: ~900 of the ~2000 instructions per frame)
             if (kb == NKB - 1) {
-                const int lim = P - kb * 32 - 4 * h;      // row (i&3) + 8*(i>>2) of this lane's half is real iff < lim
+                const int lim = P - kbase - kb * 32 - 4 * h;   // row (i&3) + 8*(i>>2) of this lane's half is real iff < lim
 #pragma unroll
                 for (int i = 0; i < 16; ++i)
                     if ((i & 3) + 8 * (i >> 2) >= lim) acc[kb][i] = -INFINITY;
@@ -139,6 +151,15 @@ __global__ __launch_bounds__(256, 2) void traj_space_fwd_kernel(const bf16_t* __
             for (int i = 0; i < 16; ++i) m = fmaxf(m, acc[kb][i]);
         }
         m = fmaxf(m, __shfl_xor(m, 32, 64));
+        float alpha = 1.f;                            // rescale of what earlier key tiles of this frame accumulated
+        if (MULTI) {
+            if (first) { m_run = m; sum_run = 0.f; }
+            else {
+                const float mn = fmaxf(m_run, m);
+                alpha = __builtin_amdgcn_exp2f((m_run - mn) * c2);
+                m_run = mn; m = mn;
+            }
+        }
         const float m2 = m * c2;
         float sum = 0.f;
 #pragma unroll
@@ -149,19 +170,27 @@ __global__ __launch_bounds__(256, 2) void traj_space_fwd_kernel(const bf16_t* __
                 acc[kb][i] = pexp;
                 sum += pexp;
             }
-        sum += __shfl_xor(sum, 32, 64);
-        const float inv = 1.f / sum;
-        if (h == 0 && q_valid)
-            lse[(((int64_t)b * heads + hh) * S + s_q) * F + f] = (m2 + __builtin_amdgcn_logf(sum)) * 0.69314718055994531f;
+        if (MULTI) { sum_run = fmaf(sum_run, alpha, sum); sum = sum_run; }
+        float inv = 0.f;
+        if (last) {
+            sum += __shfl_xor(sum, 32, 64);
+            inv = 1.f / sum;
+            if (h == 0 && q_valid)
+                lse[(((int64_t)b * heads + hh) * S + s_q) * F + f] = (m2 + __builtin_amdgcn_logf(sum)) * 0.69314718055994531f;
+        }
 
         // V_f was issued before the K_{f+1} pieces above: at most NKB loads outstanding <=> V_f has landed
         if (more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NKB) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                 // D: V_f is visible to every wave
         // ---- y[dblk][reg] = sum_key V^T[d][key] * P[key][q]  (P straight from the accumulators) ----
-        f32x16 y[2];
+        if (first) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) { y[0][i] = 0.f; y[1][i] = 0.f; }
+            for (int i = 0; i < 16; ++i) { y[0][i] = 0.f; y[1][i] = 0.f; }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { y[0][i] *= alpha; y[1][i] *= alpha; }
+        }
 #pragma unroll
         for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
@@ -180,10 +209,11 @@ __global__ __launch_bounds__(256, 2) void traj_space_fwd_kernel(const bf16_t* __
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                 // B: every wave has read V_f
         if (more) {
-            dma_tile(sV, f + 1, 2);
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NKB) : "memory");   // K_{f+1} (issued after A) has landed
-            __builtin_amdgcn_s_barrier();             // C: K_{f+1} is visible to every wave
+            dma_tile(sV, fn, jn * KROWS, 2);
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NKB) : "memory");   // K_{u+1} (issued after A) has landed
+            __builtin_amdgcn_s_barrier();             // C: K_{u+1} is visible to every wave
         }
+        if (!last) { f = fn; j = jn; continue; }      // (MULTI) the frame's next key tile; rows leave after its last one
         // ---- rows out through the wave's LDS slab: [32 q][16 chunks of 8 B], chunk ^= q & 15 ----
 #pragma unroll
         for (int dblk = 0; dblk < 2; ++dblk)
@@ -208,27 +238,35 @@ __global__ __launch_bounds__(256, 2) void traj_space_fwd_kernel(const bf16_t* __
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // slab reads done before the next frame overwrites it
+        f = fn; j = jn;
     }
 }
 
-template <int NKB>
-int launch_fwd(const void* qkv, void* xt, void* xdiag, float* lse, int B, int F, int P, int heads, hipStream_t s) {
+template <int NKB, bool MULTI>
+int launch_fwd(const void* qkv, void* xt, void* xdiag, float* lse, int B, int F, int P, int heads, int NT, hipStream_t s) {
     const int S = F * P;
-    const size_t lds = 0;            // all LDS is static (separate objects, see the kernel)
-    auto k = traj_space_fwd_kernel<NKB>;
-    static bool once = (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds) == hipSuccess);
-    (void)once;
     dim3 grid((S + QT - 1) / QT, B * heads);
-    hipLaunchKernelGGL(k, grid, dim3(256), lds, s, (const bf16_t*)qkv, (bf16_t*)xt, (bf16_t*)xdiag, lse, B, F, P, heads);
+    hipLaunchKernelGGL((traj_space_fwd_kernel<NKB, MULTI>), grid, dim3(256), 0, s, (const bf16_t*)qkv, (bf16_t*)xt,
+                       (bf16_t*)xdiag, lse, B, F, P, heads, NT);
     FOCUS_CHECK_LAUNCH();
     return FOCUS_OK;
 }
 
 }  // namespace
 
+// Key tiling of one frame: NB = ceil(P/32) blocks of 32 keys = NT tiles of NKB blocks, NKB <= 7 the largest divisor of
+// NB (so every tile is full except the last block of the last tile).  P <= 224 -> one tile.
+void focus_traj_space_tiling(int P, int* nkb, int* nt) {
+    const int NB = (P + 31) / 32;
+    int k = NB < 7 ? NB : 7;
+    while (NB % k) --k;
+    *nkb = k; *nt = NB / k;
+}
+
 bool focus_traj_space_mfma_ok(int P, int d, int heads, int dtype) {
     static const bool enabled = !(getenv("FOCUS_TRAJ_FUSED") && atoi(getenv("FOCUS_TRAJ_FUSED")) == 0);
-    return enabled && dtype == FOCUS_BF16 && d == HD && P >= 1 && P <= 224 && ((heads * HD) % 8) == 0;
+    return enabled && dtype == FOCUS_BF16 && d == HD && P >= 1 && P <= 32 * FOCUS_TRAJ_MAX_KEY_BLOCKS &&
+           ((heads * HD) % 8) == 0;
 }
 
 // Patch-token rows only (xt, xdiag, lse); the cls row is handled by the caller.
@@ -236,14 +274,14 @@ int focus_traj_space_fwd_mfma(const void* qkv, void* xt, void* xdiag, float* lse
                               hipStream_t s) {
     if (B * heads > 65535) return FOCUS_ERR_SHAPE;
     if (!focus_aligned(qkv, 16) || !focus_aligned(xt, 16) || !focus_aligned(xdiag, 16)) return FOCUS_ERR_ALIGN;
-    switch ((P + 31) / 32) {     // exact block count: the kernels rely on NKB == ceil(P/32)
-        case 1: return launch_fwd<1>(qkv, xt, xdiag, lse, B, F, P, heads, s);
-        case 2: return launch_fwd<2>(qkv, xt, xdiag, lse, B, F, P, heads, s);
-        case 3: return launch_fwd<3>(qkv, xt, xdiag, lse, B, F, P, heads, s);
-        case 4: return launch_fwd<4>(qkv, xt, xdiag, lse, B, F, P, heads, s);
-        case 5: return launch_fwd<5>(qkv, xt, xdiag, lse, B, F, P, heads, s);
-        case 6: return launch_fwd<6>(qkv, xt, xdiag, lse, B, F, P, heads, s);
+    int nkb, nt;
+    focus_traj_space_tiling(P, &nkb, &nt);
+#define FWD(K) case K: return nt == 1 ? launch_fwd<K, false>(qkv, xt, xdiag, lse, B, F, P, heads, 1, s) \
+                                      : launch_fwd<K, true>(qkv, xt, xdiag, lse, B, F, P, heads, nt, s)
+    switch (nkb) {               // exact block count: the kernels rely on NKB * NT == ceil(P/32)
+        FWD(1); FWD(2); FWD(3); FWD(4); FWD(5); FWD(6); FWD(7);
         default: break;
     }
-    return launch_fwd<7>(qkv, xt, xdiag, lse, B, F, P, heads, s);
+#undef FWD
+    return FOCUS_ERR_SHAPE;
 }

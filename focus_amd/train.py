@@ -14,7 +14,14 @@ from .slowfast.utils import misc
 
 def train_step(model, optimizer, loss_fun, inputs, labels, meta, cfg, check_nan=True):
     preds = model(inputs, meta)                                   # train_net.py:86
-    loss = loss_fun(preds, labels)                                # :91-99
+    extra_preds = None
+    if isinstance(preds, tuple):                                  # :87-88 (EK: (verb, {'verb','noun'}))
+        preds, extra_preds = preds
+    if cfg.TRAIN.DATASET == "epickitchens":                       # :95-97
+        loss_dict = loss_fun(extra_preds, labels)
+        loss = loss_dict["verb_loss"] + loss_dict["noun_loss"]
+    else:
+        loss = loss_fun(preds, labels)                            # :99
     if check_nan:
         misc.check_nan_losses(float(loss.detach()))                        # :102 (host sync, as in the reference)
     optimizer.zero_grad(set_to_none=True)                         # :105
@@ -39,5 +46,9 @@ def synthetic_batch(cfg, batch, device, seed=0):
     c = torch.minimum(torch.maximum(c, wh / 2), 1 - wh / 2)
     boxes = torch.cat([c, wh], dim=-1)
     boxes[batch - 1, :, O - 1] = 0                                 # empty-box path
-    labels = torch.randint(0, cfg.MODEL.NUM_CLASSES, (batch,), generator=g)
-    return [x.to(device)], labels.to(device), {"orvit_bboxes": boxes.to(device)}
+    if cfg.TRAIN.DATASET == "epickitchens":                        # verb (97) / noun (300) label dict (train_net.py:95)
+        labels = {"verb": torch.randint(0, 97, (batch,), generator=g).to(device),
+                  "noun": torch.randint(0, 300, (batch,), generator=g).to(device)}
+    else:
+        labels = torch.randint(0, cfg.MODEL.NUM_CLASSES, (batch,), generator=g).to(device)
+    return [x.to(device)], labels, {"orvit_bboxes": boxes.to(device)}

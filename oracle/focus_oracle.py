@@ -345,8 +345,9 @@ def motionformer_embed(p, x, temporal_resolution, kernel, crop_size):
 
 
 def motionformer_forward(p, x, boxes, cfg, training=True):
-    """Motionformer.forward for the single-head (non-EK) case; cfg is a dict with keys
-    depth, heads, orvit_layers, temporal_resolution, patch (t,h,w), crop, head_act."""
+    """Motionformer.forward (video_model_builder.py:1338-1353); cfg is a dict with keys depth, heads, orvit_layers,
+    temporal_resolution, patch (t,h,w), crop.  With EPIC-Kitchens heads in `p` (head0 / head1, :1229-1231) the return
+    value is the reference's (verb, {'verb', 'noun'}) pair (:1341-1348), else the single-head logits."""
     xx, npatch = motionformer_embed(p, x, cfg["temporal_resolution"], cfg["patch"], cfg["crop"])
     side = int(npatch ** 0.5)
     thw = [cfg["temporal_resolution"], side, side]
@@ -358,6 +359,11 @@ def motionformer_forward(p, x, boxes, cfg, training=True):
             xx = trajectory_block(p, name, xx, thw, cfg["heads"])
     feat = layer_norm(p, "norm", xx, 1e-6)[:, 0]
     feat = torch.tanh(linear(p, "pre_logits.fc", feat))                   # HEAD_ACT tanh, USE_MLP
+    if "head0.weight" in p:
+        outs = [linear(p, "head%d" % i, feat) for i in range(2)]
+        if not training:
+            outs = [torch.softmax(o, dim=-1) for o in outs]
+        return outs[0], {"verb": outs[0], "noun": outs[1]}
     logits = linear(p, "head", feat)
     return logits if training else torch.softmax(logits, dim=-1)
 
@@ -367,6 +373,12 @@ def label_smoothing_ce(logits, target, smoothing=0.1):
     lp = torch.log_softmax(logits, dim=-1)
     nll = -lp.gather(-1, target.unsqueeze(1)).squeeze(1)
     return ((1.0 - smoothing) * nll + smoothing * (-lp.mean(-1))).mean()
+
+
+def ek_loss(extra_preds, labels, smoothing=0.1):
+    """EKLoss (losses.py:62-95) with ce_type 'label_smoothing' + the sum the train loop forms (train_net.py:95-97)."""
+    return {"verb_loss": label_smoothing_ce(extra_preds["verb"], labels["verb"], smoothing),
+            "noun_loss": label_smoothing_ce(extra_preds["noun"], labels["noun"], smoothing)}
 
 
 # ----------------------------------------------------------------------------------------------

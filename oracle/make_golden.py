@@ -215,6 +215,70 @@ def main():
     print("wrote", sorted(os.listdir(OUT)))
 
 
+def main_r2():
+    """Round-2 fixtures (own generator, so the round-1 files above regenerate bit-identically)."""
+    torch.set_grad_enabled(True)
+    mods = load_reference(_roi_align_tv)
+    att = mods["attention"]
+    g = torch.Generator().manual_seed(20262)
+
+    # 9. trajectory attention with MORE than 224 keys per frame (the HR regime: key tiles + online softmax in the
+    #    fused kernels), two heads of 64: thw = [2, 230, 1]  (attention.py:479-557)
+    m = att.TrajectoryAttention(128, num_heads=2, qkv_bias=True).double()
+    randomize(m, g, std=0.12)
+    with torch.no_grad():
+        for prm in m.parameters():
+            prm.copy_(prm.float().double())                       # fp32-representable: stored as float32
+    x = torch.randn(1, 1 + 2 * 230, 128, generator=g).double().requires_grad_(True)
+    ct = torch.randn(1, 461, 128, generator=g).double()
+    y, _ = m(x, [2, 230, 1])
+    (y * ct).sum().backward()
+    np.savez(os.path.join(OUT, "traj_attn_p230.npz"), x=x.detach().numpy().astype(np.float32),
+             ct=ct.numpy().astype(np.float32), y=y.detach().numpy(), dx=x.grad.numpy(), thw=np.array([2, 230, 1]),
+             heads=2, **{k: v.astype(np.float32) for k, v in pack("p.", m.state_dict()).items()},
+             **grads_of(m, ["qkv.bias", "proj_q.weight", "proj_kv.weight"]))
+
+    # 10. HR-like Motionformer (EK_ORVIT_MF_HR.yaml reduced): crop 256 != 224 (bicubic pos-embed, 16x16 = 256 > 224
+    #     patches per frame), O=6 objects, EPIC-Kitchens verb/noun heads + EKLoss (losses.py:62-95, the reference's own
+    #     losses.py is executed), one head of 64 channels, depth 2 with ORViT at layer 1
+    load_motionformer(mods)
+    losses = _load_losses()
+    cfg = small_cfg(crop=256, O=6, T=2)
+    cfg.MF.EMBED_DIM, cfg.MF.NUM_HEADS, cfg.MF.DEPTH = 64, 1, 2
+    cfg.TRAIN.DATASET = "epickitchens"
+    cfg.MODEL.NUM_CLASSES = 97
+    cfg.MODEL.LOSS_FUNC = "label_smoothing_cross_entropy"
+    cfg.MIXUP = ns(LABEL_SMOOTH_VALUE=0.1)
+    torch.manual_seed(0)
+    m = mods["video_model_builder"].Motionformer(cfg)
+    randomize(m, g, std=0.1)
+    m.train()
+    x = torch.randn(1, 3, 4, 256, 256, generator=g).half().float()      # stored exactly as fp16
+    boxes = make_boxes(g, 1, 4, 6, zero=((0, None, 5),))
+    labels = {"verb": torch.tensor([41]), "noun": torch.tensor([207])}
+    preds, extra = m([x], {"orvit_bboxes": boxes.clone()})
+    loss_fun = losses.get_loss_func(cfg)(reduction="mean")
+    ld = loss_fun(extra, labels)
+    loss = ld["verb_loss"] + ld["noun_loss"]                              # train_net.py:95-97
+    loss.backward()
+    keys = ["patch_embed_3d.proj.weight", "pos_embed", "temp_embed", "blocks.0.attn.qkv.weight",
+            "blocks.0.attn.proj_kv.weight", "blocks.1.attn.qkv.weight", "blocks.1.patch_to_d.0.weight",
+            "blocks.1.box_categories", "blocks.1.motion_mlp.fc2.weight", "head0.weight", "head1.weight",
+            "head1.bias", "pre_logits.fc.weight"]
+    np.savez(os.path.join(OUT, "motionformer_hr_small.npz"), x=x.numpy().astype(np.float16), boxes=boxes.numpy(),
+             label_verb=labels["verb"].numpy(), label_noun=labels["noun"].numpy(),
+             verb=extra["verb"].detach().numpy(), noun=extra["noun"].detach().numpy(),
+             verb_loss=ld["verb_loss"].detach().numpy(), noun_loss=ld["noun_loss"].detach().numpy(),
+             loss=loss.detach().numpy(), **pack("p.", m.state_dict()), **grads_of(m, keys))
+    print("wrote round-2 fixtures")
+
+
+def _load_losses():
+    """The reference's own slowfast/models/losses.py (plain torch + the stubbed logger)."""
+    from oracle._ref_loader import _load
+    return _load("slowfast.models.losses", "slowfast/models/losses.py")
+
+
 def mods_loss(logits, labels):
     """LabelSmoothingCrossEntropy (losses.py:40-59) is plain torch; restated inline to avoid loading
     losses.py's unrelated imports."""
@@ -224,4 +288,6 @@ def mods_loss(logits, labels):
 
 
 if __name__ == "__main__":
-    main()
+    if "--r2-only" not in sys.argv:
+        main()
+    main_r2()

@@ -1,0 +1,202 @@
+"""Kernel-level parity of the TIMED bf16 kernels (the ones bench.py measures), one kernel per check.
+
+The model-level tests compare a bf16 pipeline with an fp32/fp64 pipeline, so input quantisation dominates and a
+kernel bug that perturbs a few percent of the elements by a few percent could hide inside their 3e-2 tolerance.
+Here every kernel is fed bf16-ROUNDED inputs and compared with an fp64 evaluation of the SAME values, element by
+element:   |got - want| <= rtol * max(|want|, floor * max|want|)   with rtol = 2^-7 (two bf16 ulps) for single-kernel
+outputs; the only slack is the output's own bf16 rounding (2^-9) and the bf16 rounding of MFMA operands the kernel forms
+internally (probabilities, dL).  A wrong tail mask, swizzle or epilogue lands far outside that."""
+import numpy as np
+import pytest
+import torch
+
+from test_gpu_parity import dev
+
+pytestmark = pytest.mark.gpu
+
+RT = 2.0 ** -7
+
+
+def tight(got, want, what, rtol=RT, floor=1e-2):
+    want = want.detach().double()
+    got = got.detach().to(want.device).double()            # compared where the fp64 reference lives (GPU for the GEMMs)
+    assert got.shape == want.shape, (what, got.shape, want.shape)
+    assert torch.isfinite(got).all(), what
+    scale = float(want.abs().max())
+    den = torch.clamp(want.abs(), min=floor * scale)
+    ratio = ((got - want).abs() / den).max()
+    assert float(ratio) <= rtol, "%s: max elementwise rel err %.3e > %.3e (max|want| %.3e)" % (what, float(ratio), rtol, scale)
+    return float(ratio)
+
+
+def bf(t):
+    return t.bfloat16()
+
+
+def gelu64(v):
+    return 0.5 * v * (1.0 + torch.erf(v / 2.0 ** 0.5))
+
+
+def dgelu64(v):
+    return 0.5 * (1.0 + torch.erf(v / 2.0 ** 0.5)) + v * torch.exp(-0.5 * v * v) / (2.0 * np.pi) ** 0.5
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# NT GEMM: every epilogue, on the bench's own shapes and on ragged edges
+# ----------------------------------------------------------------------------------------------------------------
+BENCH_SHAPES = [(12552, 768, 768), (12552, 2304, 768), (12552, 3072, 768), (12552, 768, 3072), (100352, 768, 768)]
+RAGGED_SHAPES = [(1601, 768, 768), (333, 200, 192), (12808, 1536, 768), (129, 97, 64), (6272, 384, 768)]
+
+
+@pytest.mark.parametrize("shape", BENCH_SHAPES + RAGGED_SHAPES)
+def test_nt_gemm_epilogues(shape):
+    from focus_amd import ops
+    M, N, K = shape
+    d = dev()
+    g = torch.Generator(device=d).manual_seed(M + N + K)
+    a = bf(torch.randn(M, K, device=d, generator=g))
+    w = bf(torch.randn(N, K, device=d, generator=g) * K ** -0.5)
+    bias = torch.randn(N, device=d, generator=g)
+    res = bf(torch.randn(M, N, device=d, generator=g))
+    aux_in = bf(torch.randn(M, N, device=d, generator=g))           # saved pre-activation / output of the backward forms
+    v0 = a.double() @ w.double().t()                                 # fp64 product of the same bf16 values
+    big = M * N > 20_000_000
+    # plain, + bias, + bias + residual
+    tight(ops.mm_nt(a, w), v0, "plain %s" % (shape,))
+    tight(ops.mm_nt(a, w, bias=bias, residual=res), v0 + bias.double() + res.double(), "bias+residual %s" % (shape,))
+    # forward activations (bias before the activation, residual after)
+    vb = v0 + bias.double()
+    aux = torch.empty(M, N, device=d, dtype=torch.bfloat16)
+    tight(ops.mm_nt(a, w, bias=bias, aux=aux, epilogue=ops.EPI_GELU), gelu64(vb), "gelu %s" % (shape,))
+    tight(aux, vb, "gelu saved pre-activation %s" % (shape,))
+    tight(ops.mm_nt(a, w, bias=bias, epilogue=ops.EPI_RELU, residual=res), torch.relu(vb) + res.double(),
+          "relu+residual %s" % (shape,))
+    if not big:
+        tight(ops.mm_nt(a, w, bias=bias, epilogue=ops.EPI_TANH), torch.tanh(vb), "tanh %s" % (shape,))
+    # backward forms: C = v * act'(aux)
+    from focus_amd import _lib
+    x = aux_in.double()
+    tight(ops.mm_nt(a, w, aux=aux_in, epilogue=_lib.EPI_DGELU), v0 * dgelu64(x), "dgelu %s" % (shape,))
+    if not big:
+        tight(ops.mm_nt(a, w, aux=aux_in, epilogue=_lib.EPI_DRELU), v0 * (x > 0), "drelu %s" % (shape,))
+        tight(ops.mm_nt(a, w, aux=aux_in, epilogue=_lib.EPI_DTANH), v0 * (1 - x * x), "dtanh %s" % (shape,))
+        # fp32 output of the same kernel family (split-K path): no output rounding at all
+        tight(ops.mm_nt(a, w, out_dtype=torch.float32), v0, "fp32 out %s" % (shape,), rtol=2e-5, floor=1e-2)
+
+
+@pytest.mark.parametrize("shape", [(12552, 768, 768), (12552, 768, 3072), (100352, 768, 768), (12808, 768, 1536)])
+def test_dx_gemm_through_transposed_shadow(shape):
+    """dX = dY . W (the backward of every Linear) through the transposed bf16 weight shadow."""
+    from focus_amd import ops
+    M, N, K = shape                                                  # dy [M,N], w [N,K] -> dx [M,K]
+    d = dev()
+    g = torch.Generator(device=d).manual_seed(7 + M + N)
+    dy = bf(torch.randn(M, N, device=d, generator=g))
+    w = (torch.randn(N, K, device=d, generator=g) * N ** -0.5)
+    got = ops._dx_from(dy, w, torch.bfloat16)
+    tight(got, dy.double() @ bf(w).double(), "dx %s" % (shape,))
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# trajectory attention: space step (fwd, dq, dkv, delta, cls) and time step (fwd, bwd)
+# ----------------------------------------------------------------------------------------------------------------
+def _space_ref(qkv, F_, P, heads, cts):
+    """attention.py:509-535 in fp64 on the given values; returns outputs and d(qkv)."""
+    B, N, C3 = qkv.shape
+    C, S = C3 // 3, F_ * P
+    d = C // heads
+    q64 = qkv.double().requires_grad_()
+
+    def sh(t):
+        return t.reshape(B, N, heads, d).permute(0, 2, 1, 3)
+    q, k, v = (sh(t) for t in q64.split(C, dim=-1))
+    scale = d ** -0.5
+    cls = (torch.softmax((q[:, :, :1] * scale) @ k.transpose(-1, -2), dim=-1) @ v).permute(0, 2, 1, 3).reshape(B, 1, C)
+    A = torch.softmax((q[:, :, 1:] @ k[:, :, 1:].transpose(-1, -2)).reshape(B, heads, S, F_, P) * scale, dim=-1)
+    xt = torch.einsum("bhsfp,bhfpd->bhsfd", A, v[:, :, 1:].reshape(B, heads, F_, P, d))
+    xt = xt.permute(0, 2, 3, 1, 4).reshape(B, S, F_, C)
+    xd = xt[:, torch.arange(S), torch.arange(S) // P]
+    ((xt * cts[0].double().cpu()).sum() + (xd * cts[1].double().cpu()).sum() + (cls * cts[2].double().cpu()).sum()).backward()
+    return xt.detach(), xd.detach(), cls.detach(), q64.grad
+
+
+@pytest.mark.parametrize("P", [196, 200])
+def test_space_attention_kernels_tight(P):
+    """traj_space_fwd / traj_delta / traj_dq / traj_dkv / cls kernels at the bench's frame sizes (F=8, d=64)."""
+    from focus_amd import ops
+    F_, heads, B = 8, 2, 1
+    C, S = heads * 64, F_ * P
+    d = dev()
+    g = torch.Generator().manual_seed(P)
+    qkv = bf(torch.randn(B, 1 + S, 3 * C, generator=g))
+    cts = [bf(torch.randn(B, S, F_, C, generator=g)), bf(torch.randn(B, S, C, generator=g)),
+           bf(torch.randn(B, 1, C, generator=g))]
+    xt_r, xd_r, cls_r, dq_r = _space_ref(qkv, F_, P, heads, cts)
+    qg = qkv.to(d).requires_grad_()
+    xt, xd, cls = ops.traj_space(qg, F_, P, heads)
+    ((xt.float() * cts[0].to(d).float()).sum() + (xd.float() * cts[1].to(d).float()).sum()
+     + (cls.float() * cts[2].to(d).float()).sum()).backward()
+    # forward: probabilities are rounded to bf16 before P.V (<= 2^-9 each, averaged over ~P keys) + output rounding
+    tight(xt, xt_r, "x~ P=%d" % P)
+    tight(xd, xd_r, "x_diag P=%d" % P)
+    tight(cls, cls_r, "cls P=%d" % P)
+    # backward: dL is rounded to bf16 before the dQ / dK products, P before dV; delta uses the bf16 x~
+    gq = qg.grad.double().cpu()
+    tight(gq[:, 1:, :C], dq_r[:, 1:, :C], "dQ (traj_dq) P=%d" % P, rtol=2 * RT)
+    tight(gq[:, 1:, C:2 * C], dq_r[:, 1:, C:2 * C], "dK (traj_dkv + cls) P=%d" % P, rtol=2 * RT)
+    tight(gq[:, 1:, 2 * C:], dq_r[:, 1:, 2 * C:], "dV (traj_dkv + cls) P=%d" % P, rtol=2 * RT)
+    tight(gq[:, :1], dq_r[:, :1], "cls token row of dqkv P=%d" % P, rtol=2 * RT)
+
+
+@pytest.mark.parametrize("F_", [8, 4])
+def test_time_attention_kernels_tight(F_):
+    """time_fwd_vec / time_bwd_vec (attention.py:538-549) at S = F*196, 12 heads of 64."""
+    from focus_amd import ops
+    heads, B, P = 12, 1, 196
+    C, S = heads * 64, F_ * P
+    d = dev()
+    g = torch.Generator().manual_seed(F_)
+    q2 = bf(torch.randn(B, S, C, generator=g))
+    k2 = bf(torch.randn(B, S, F_, C, generator=g))
+    xt = bf(torch.randn(B, S, F_, C, generator=g))
+    ct = bf(torch.randn(B, S, C, generator=g))
+    Q, K2, X = (t.double().requires_grad_() for t in (q2, k2, xt))
+    qh = Q.reshape(B, S, heads, 64) * 64 ** -0.5
+    kh = K2.reshape(B, S, F_, heads, 64)
+    A = torch.softmax(torch.einsum("bshd,bsfhd->bshf", qh, kh), dim=-1)
+    out_r = torch.einsum("bshf,bsfhd->bshd", A, X.reshape(B, S, F_, heads, 64)).reshape(B, S, C)
+    (out_r * ct.double()).sum().backward()
+    qg, kg, xg = (t.to(d).requires_grad_() for t in (q2, k2, xt))
+    out = ops.traj_time(qg, kg, xg, heads)
+    (out.float() * ct.to(d).float()).sum().backward()
+    tight(out, out_r, "time out F=%d" % F_)
+    tight(qg.grad, Q.grad, "time dq2 F=%d" % F_)
+    tight(kg.grad, K2.grad, "time dk2 F=%d" % F_)
+    tight(xg.grad, X.grad, "time dx~ F=%d" % F_)
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# slot attention (steve.py:76-83) at the BASELINE shape of one (frame, iteration) call
+# ----------------------------------------------------------------------------------------------------------------
+def test_slot_attention_kernels_tight():
+    from focus_amd import ops
+    B, N, K, D = 2, 4096, 11, 192
+    d = dev()
+    g = torch.Generator().manual_seed(2)
+    k = bf(torch.randn(B, N, D, generator=g) * D ** -0.5)
+    v = bf(torch.randn(B, N, D, generator=g))
+    q = bf(torch.randn(B, K, D, generator=g))
+    cu, ca = bf(torch.randn(B, K, D, generator=g)), bf(torch.randn(B, N, K, generator=g) * 1e-2)
+    kr, vr, qr = (t.double().requires_grad_() for t in (k, v, q))
+    av = torch.softmax(kr @ qr.transpose(-1, -2), dim=-1)
+    aa = av + 1e-8
+    upd = (aa / aa.sum(dim=-2, keepdim=True)).transpose(-1, -2) @ vr
+    ((upd * cu.double()).sum() + (av * ca.double()).sum()).backward()
+    kg, vg, qg = (t.to(d).requires_grad_() for t in (k, v, q))
+    u2, a2 = ops.slot_attn_step(kg, vg, qg, 1e-8)
+    ((u2.float() * cu.to(d).float()).sum() + (a2.float() * ca.to(d).float()).sum()).backward()
+    tight(a2, av, "slot attn_vis")
+    tight(u2, upd, "slot updates")
+    tight(vg.grad, vr.grad, "slot dv", rtol=2 * RT)
+    tight(kg.grad, kr.grad, "slot dk", rtol=2 * RT)
+    tight(qg.grad, qr.grad, "slot dq", rtol=2 * RT)

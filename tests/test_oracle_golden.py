@@ -116,3 +116,33 @@ def test_motionformer_small(oracle):
     close(loss, a["loss"], 1e-6)
     loss.backward()
     check_grads(a, p, 1e-4)
+
+
+def test_trajectory_attention_more_than_224_keys(oracle):
+    """HR regime (P = 230 > 224 keys per frame, two heads of 64): fixture from the reference module in fp64."""
+    a, p = load_golden("traj_attn_p230", dtype=torch.float64)
+    p = leafify(p)
+    x = T(a["x"], dtype=torch.float64, grad=True)
+    y = oracle.trajectory_attention({("." + k): v for k, v in p.items()}, "", x, list(a["thw"]), int(a["heads"]))
+    close(y, a["y"], 1e-12)
+    (y * T(a["ct"], dtype=torch.float64)).sum().backward()
+    close(x.grad, a["dx"], 1e-11)
+    check_grads(a, p, 1e-11)
+
+
+def test_motionformer_hr_small_ek_heads(oracle):
+    """Reduced EK_ORVIT_MF_HR: crop 256 (bicubic pos-embed, 256 patches + 6 objects per frame), verb/noun heads,
+    EKLoss -- logits, both losses, their sum and selected gradients from the reference model + its own losses.py."""
+    a, p = load_golden("motionformer_hr_small")
+    p = leafify(p)
+    cfg = dict(depth=2, heads=1, orvit_layers=[1], temporal_resolution=2, patch=(2, 16, 16), crop=256)
+    verb, extra = oracle.motionformer_forward(p, T(a["x"], dtype=torch.float32), T(a["boxes"]), cfg, training=True)
+    close(extra["verb"], a["verb"], 2e-5)
+    close(extra["noun"], a["noun"], 2e-5)
+    ld = oracle.ek_loss(extra, {"verb": T(a["label_verb"]), "noun": T(a["label_noun"])})
+    close(ld["verb_loss"], a["verb_loss"], 1e-6)
+    close(ld["noun_loss"], a["noun_loss"], 1e-6)
+    loss = ld["verb_loss"] + ld["noun_loss"]
+    close(loss, a["loss"], 1e-6)
+    loss.backward()
+    check_grads(a, p, 2e-4)
