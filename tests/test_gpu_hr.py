@@ -115,6 +115,11 @@ def test_motionformer_hr_small_golden(mixed):
     loss = ld["verb_loss"] + ld["noun_loss"]
     assert abs(float(loss.detach()) - float(a["loss"])) < tol * max(1.0, abs(float(a["loss"])))
     loss.backward()
+    if mixed:
+        # the max over RoI cells is discontinuous: a bf16 rounding can move the arg-max cell and re-route the whole
+        # patch_to_d gradient of that channel (see test_orvit_block_golden); sanity-bounded only in bf16
+        for k in [k for k in a if k.startswith("grad.") and "patch_to_d" in k]:
+            close(dict(m.named_parameters())[k[5:]].grad, a.pop(k), 0.3, k, floor=1e-2)
     check_param_grads(m, a, tol * (3 if mixed else 2))
     # eval mode returns probabilities of both heads (video_model_builder.py:1344-1345)
     m.eval()
