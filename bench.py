@@ -87,7 +87,7 @@ def cpu_baseline(model, cfg, seconds_budget=25.0):
     from focus_amd.train import synthetic_batch
     from oracle import focus_oracle as fo
     nthreads, phys = host_cores()
-    cores = max(1, min(phys, nthreads, 64))
+    cores = max(1, min(phys, nthreads, 32))          # more threads than this made the oracle SLOWER on the shared host
     torch.set_num_threads(cores)
     base = model.module if hasattr(model, "module") else model
     params = {k: v.detach().float().cpu().clone().requires_grad_(v.is_floating_point())
