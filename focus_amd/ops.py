@@ -103,13 +103,13 @@ def mm_nt(a, b, bias=None, residual=None, aux=None, epilogue=EPI_NONE, out_dtype
     return c
 
 
-def mm_nn(a, b, aux=None, epilogue=EPI_NONE):
+def mm_nn(a, b, aux=None, epilogue=EPI_NONE, alpha=1.0):
     """a [M,K] . b [K,N] -> [M,N] for row-major b (generic kernel unless the caller supplies b^T to mm_nt)."""
     M, K = a.shape
     N = b.shape[1]
     c = torch.empty(M, N, device=a.device, dtype=a.dtype)
     gemm(M, N, K, (a, 0), (a.stride(0), 1, 0, 0), (b, 0), (b.stride(0), 1, 0, 0), (c, 0), (N, 1, 0, 0),
-         aux=(aux, 0) if aux is not None else None, epilogue=epilogue)
+         aux=(aux, 0) if aux is not None else None, epilogue=epilogue, alpha=alpha)
     return c
 
 
@@ -148,35 +148,14 @@ def mm_tn(a, b):
     return c
 
 
-# Weight gradients on a second HIP stream (opt-in, FOCUS_SIDE_STREAM=1): dW (TN GEMM + reduce) and dX (NT GEMM) of a
-# Linear are independent, and both kernels run one persistent workgroup per CU, so each leaves CUs idle in its last
-# round of tiles; on separate streams the other kernel's workgroups can fill them.  Measured on the bench step it
-# LOSES 4-5 % (195 vs 204 clips/s, A/B on one box: the two kernels evict each other's operand panels from L2), so the
-# default keeps everything on the current stream.
 import os as _os
-_SIDE_ON = _os.environ.get("FOCUS_SIDE_STREAM", "0") == "1"
-_side_streams = {}
 
 
 def wgrad_async(dy, x, want_bias):
-    """linear_wgrad on the side stream -> (dw, db, join); call join() before the results are handed to autograd."""
-    if not _SIDE_ON or GEMM_TIMING is not None or not dy.is_cuda:
-        dw, db = linear_wgrad(dy, x, want_bias)
-        return dw, db, (lambda: None)
-    main = torch.cuda.current_stream()
-    side = _side_streams.get(dy.device)
-    if side is None:
-        side = _side_streams[dy.device] = torch.cuda.Stream(device=dy.device)
-    side.wait_stream(main)                       # dy / x were produced on the main stream
-    with torch.cuda.stream(side):
-        dw, db = linear_wgrad(dy, x, want_bias)
-    for t in (dw, db):
-        if t is not None:
-            t.record_stream(main)                # allocated on the side stream, consumed on the main one
-
-    def join():
-        main.wait_stream(side)
-    return dw, db, join
+    """(dw, db, join) of a Linear.  (A side-stream variant that overlapped dW with dX was measured 4-5 % SLOWER on
+    the bench step -- the two persistent kernels evict each other's operand panels from L2 -- and was removed.)"""
+    dw, db = linear_wgrad(dy, x, want_bias)
+    return dw, db, None
 
 
 def linear_wgrad(dy, x, want_bias):
@@ -300,11 +279,95 @@ def shadow(w, dtype, transposed=False):
     return out
 
 
-def _dx_from(dy, w, dtype, aux=None, epilogue=EPI_NONE):
-    """dy [M,N] . w[N,K] -> [M,K]."""
+def _dx_from(dy, w, dtype, aux=None, epilogue=EPI_NONE, alpha=1.0):
+    """alpha * dy [M,N] . w[N,K] -> [M,K]."""
     if dtype == torch.bfloat16 and w.shape[0] % 64 == 0:
-        return mm_nt(dy, shadow(w, dtype, transposed=True), aux=aux, epilogue=epilogue)
-    return mm_nn(dy, shadow(w, dtype), aux=aux, epilogue=epilogue)
+        return mm_nt(dy, shadow(w, dtype, transposed=True), aux=aux, epilogue=epilogue, alpha=alpha)
+    return mm_nn(dy, shadow(w, dtype), aux=aux, epilogue=epilogue, alpha=alpha)
+
+
+# --------------------------------------------------------------------------------------------------
+# Deferred parameter gradients.  A recurrent module (STEVE's slot update: 24 frames x 3 iterations through the same
+# GRU / MLP / LayerNorm parameters) applies every weight dozens of times per step; autograd would run one tiny
+# weight-gradient GEMM, one bias column-sum and one accumulation add per application (~2000 launches of 5-13 us
+# per STEVE step).  Inside `with deferred_wgrads():` the Linear / MLP / LayerNorm nodes recorded by the forward
+# only STASH (dY, X) in their backward; one callback at the end of the backward pass concatenates the stashes and
+# runs ONE weight-gradient GEMM per parameter (the reduction over the applications becomes part of the GEMM's
+# reduction dimension) and adds the result to .grad.  Same sums, different association order.
+# Not used under DistributedDataParallel (its reducer wants every gradient to arrive through autograd).
+# --------------------------------------------------------------------------------------------------
+_DEFER_ON = False
+_DEFER_MAX_ROWS = 8192            # applications larger than this keep the immediate path (their GEMMs are efficient)
+_deferred_lin = {}                # id(w) -> [w, b, alpha, [dy...], [x...]]
+_deferred_vec = {}                # id(p) -> [p, [g...]]
+_flush_queued = False
+
+
+class deferred_wgrads:
+    def __enter__(self):
+        global _DEFER_ON
+        self.prev = _DEFER_ON
+        import torch.distributed as dist
+        multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        _DEFER_ON = not multi and _os.environ.get("FOCUS_DEFER_WGRAD", "1") != "0"
+        return self
+
+    def __exit__(self, *exc):
+        global _DEFER_ON
+        _DEFER_ON = self.prev
+        return False
+
+
+def _queue_flush():
+    global _flush_queued
+    if not _flush_queued:
+        _flush_queued = True
+        torch.autograd.Variable._execution_engine.queue_callback(_flush_deferred)
+
+
+def _defer_linear(w, b, alpha, dy2, x2):
+    e = _deferred_lin.get(id(w))
+    if e is None:
+        e = _deferred_lin[id(w)] = [w, b, alpha, [], []]
+    e[3].append(dy2)
+    e[4].append(x2)
+    _queue_flush()
+
+
+def _defer_vec(p, g):
+    e = _deferred_vec.get(id(p))
+    if e is None:
+        e = _deferred_vec[id(p)] = [p, []]
+    e[1].append(g)
+    _queue_flush()
+
+
+def _acc_grad(p, g):
+    g = g.reshape(p.shape)
+    if p.grad is None:
+        p.grad = g.to(p.dtype) if g.dtype != p.dtype else g
+    else:
+        p.grad.add_(g)
+
+
+def _flush_deferred():
+    global _flush_queued
+    _flush_queued = False
+    lin, vec = list(_deferred_lin.values()), list(_deferred_vec.values())
+    _deferred_lin.clear()
+    _deferred_vec.clear()
+    with torch.no_grad():
+        for w, b, alpha, dys, xs in lin:
+            dy = dys[0] if len(dys) == 1 else torch.cat(dys, 0)
+            x = xs[0] if len(xs) == 1 else torch.cat(xs, 0)
+            dw, db = linear_wgrad(dy, x, b is not None)
+            if alpha != 1.0:
+                dw = dw * alpha
+            _acc_grad(w, dw)
+            if b is not None:
+                _acc_grad(b, db)
+        for p, gs in vec:
+            _acc_grad(p, gs[0] if len(gs) == 1 else torch.stack(gs, 0).sum(0))
 
 
 # --------------------------------------------------------------------------------------------------
@@ -312,16 +375,17 @@ def _dx_from(dy, w, dtype, aux=None, epilogue=EPI_NONE):
 # --------------------------------------------------------------------------------------------------
 class _LinearFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, w, b, residual):
+    def forward(ctx, x, w, b, residual, alpha):
         _need_gpu(x, w)
         shp = x.shape
         x2 = x.reshape(-1, shp[-1])
         if not x2.is_contiguous():
             x2 = x2.contiguous()
         r2 = residual.reshape(-1, w.shape[0]).contiguous() if residual is not None else None
-        y = mm_nt(x2, shadow(w, x.dtype), bias=b, residual=r2)
+        y = mm_nt(x2, shadow(w, x.dtype), bias=b, residual=r2, alpha=alpha)
         ctx.save_for_backward(x2, w)
-        ctx.has_b, ctx.has_r, ctx.shp = b is not None, residual is not None, shp
+        ctx.has_b, ctx.has_r, ctx.shp, ctx.alpha = b is not None, residual is not None, shp, alpha
+        ctx.defer = (w, b) if (_DEFER_ON and x2.shape[0] <= _DEFER_MAX_ROWS and w.is_leaf) else None
         return y.reshape(*shp[:-1], w.shape[0])
 
     @staticmethod
@@ -333,20 +397,28 @@ class _LinearFn(torch.autograd.Function):
         dx = dw = db = None
         join = None
         want_b = ctx.has_b and ctx.needs_input_grad[2]
-        if ctx.needs_input_grad[1]:
+        if ctx.defer is not None and (ctx.needs_input_grad[1] or want_b):
+            pw, pb = ctx.defer
+            _defer_linear(pw, pb if want_b else None, ctx.alpha, dy2, x2)
+        elif ctx.needs_input_grad[1]:
             dw, db, join = wgrad_async(dy2, x2, want_b)
+            if ctx.alpha != 1.0:
+                dw = dw * ctx.alpha
         elif want_b:
             db = colsum(dy2)
         if ctx.needs_input_grad[0]:
-            dx = _dx_from(dy2, w, dy2.dtype).reshape(ctx.shp)
+            if ctx.alpha == 1.0:
+                dx = _dx_from(dy2, w, dy2.dtype).reshape(ctx.shp)
+            else:
+                dx = _dx_from(dy2, w, dy2.dtype, alpha=ctx.alpha).reshape(ctx.shp)
         if join is not None:
             join()
-        return dx, dw, db, (dy if ctx.has_r else None)
+        return dx, dw, db, (dy if ctx.has_r else None), None
 
 
-def linear(x, w, b=None, residual=None):
-    """nn.Linear forward (+ fused residual add): y = x.w^T + b (+ residual)."""
-    return _LinearFn.apply(x, w, b, residual)
+def linear(x, w, b=None, residual=None, alpha=1.0):
+    """nn.Linear forward (+ fused residual add): y = alpha * x.w^T + b (+ residual)."""
+    return _LinearFn.apply(x, w, b, residual, float(alpha))
 
 
 class _MlpFn(torch.autograd.Function):
@@ -366,6 +438,7 @@ class _MlpFn(torch.autograd.Function):
         ctx.save_for_backward(x2, w1, w2, a, z)
         ctx.act, ctx.shp = act, shp
         ctx.has = (b1 is not None, b2 is not None, residual is not None)
+        ctx.defer = (w1, b1, w2, b2) if (_DEFER_ON and M <= _DEFER_MAX_ROWS and w1.is_leaf and w2.is_leaf) else None
         return y.reshape(*shp[:-1], w2.shape[0])
 
     @staticmethod
@@ -375,13 +448,20 @@ class _MlpFn(torch.autograd.Function):
         if not dy2.is_contiguous():
             dy2 = dy2.contiguous()
         join2 = join1 = None
-        if ctx.needs_input_grad[3]:
+        dfr = ctx.defer
+        if dfr is not None:
+            dw2 = db2 = None
+            _defer_linear(dfr[2], dfr[3] if ctx.has[1] else None, 1.0, dy2, a)
+        elif ctx.needs_input_grad[3]:
             dw2, db2, join2 = wgrad_async(dy2, a, ctx.has[1])
         else:
             dw2, db2 = None, (colsum(dy2) if ctx.has[1] else None)
         # dz = (dy . w2) * act'(.) fused in the GEMM epilogue
         dz = _dx_from(dy2, w2, dy2.dtype, aux=(z if ctx.act == EPI_GELU else a), epilogue=_DEPI[ctx.act])
-        if ctx.needs_input_grad[1]:
+        if dfr is not None:
+            dw1 = db1 = None
+            _defer_linear(dfr[0], dfr[1] if ctx.has[0] else None, 1.0, dz, x2)
+        elif ctx.needs_input_grad[1]:
             dw1, db1, join1 = wgrad_async(dz, x2, ctx.has[0])
         else:
             dw1, db1 = None, (colsum(dz) if ctx.has[0] else None)
@@ -448,6 +528,7 @@ def _ln_forward(ctx, x, gamma, beta, eps):
                                               eps, _dt(x2), _stream()), "layernorm_fwd")
     ctx.save_for_backward(x2, gamma, mean, rstd)
     ctx.shp = x.shape
+    ctx.defer = (gamma, beta) if (_DEFER_ON and rows <= _DEFER_MAX_ROWS and gamma.is_leaf and beta.is_leaf) else None
     return y.reshape(x.shape)
 
 
@@ -471,6 +552,10 @@ def _ln_backward(ctx, dy, dres):
     db = torch.empty(D, device=x2.device, dtype=torch.float32)
     _lib.check(L.focus_layernorm_bwd(_p(dy2), _p(x2), _p(gamma), _p(mean), _p(rstd), _p(r2) if r2 is not None else None,
                                      _p(dx), _p(dg), _p(db), _p(partial), rows, D, _dt(x2), _stream()), "layernorm_bwd")
+    if ctx.defer is not None:          # recurrent module: the per-application affine gradients are summed once at the end
+        _defer_vec(ctx.defer[0], dg)
+        _defer_vec(ctx.defer[1], db)
+        return dx.reshape(ctx.shp), None, None
     return dx.reshape(ctx.shp), dg, db
 
 
