@@ -24,16 +24,19 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((address_space(1))) const void gvoid_t;
 typedef __attribute__((address_space(3))) void lvoid_t;
 
-constexpr int BK = 64, NSTAGE = 3;
+constexpr int BK = 64;
 
 __device__ __forceinline__ int swz(int row, int chunk) { return row * 128 + ((chunk ^ (row & 7)) << 4); }
 
 struct Unit { int m0, n0, nk; };
 
-// BM = 128: 4 consumer waves (2x2 of 64x64) + 4 loaders, 96 KiB ring.
-// BM = 256: 8 consumer waves (4x2 of 64x64) + 4 loaders, 144 KiB ring (85 flop per LDS-filled byte instead of 64;
-//           two consumer waves per SIMD overlap each other's ds_read latency).
-template <int BM, int BN, int EPI, int NLOAD>
+// 128x256 / 256x128: 8 consumer waves (64x64 each) + 4 loaders, 3-stage 144 KiB ring (85 flop per LDS-filled byte;
+//           the loaders run two K-steps ahead).
+// 192x256: 12 consumer waves + 4 loaders = 1024 threads, 2-stage 112 KiB ring (110 flop per LDS-filled byte: the
+//           kernel is bound by the L2 -> LDS fill rate of a CU, ~22 B/clk, so bytes per flop is the lever; and
+//           M = 12552 x N = 768 becomes 198 tiles = ONE round of the 256 CUs instead of 297 = two).  With two
+//           stages the loaders run one K-step ahead (s_waitcnt vmcnt(0) per step).
+template <int BM, int BN, int EPI, int NLOAD, int NSTAGE>
 __global__ __launch_bounds__(64 * (BM * BN / 4096 + NLOAD)) void gemm_nt_ws_kernel(const focus_gemm_desc d, int tiles_m, int tiles_n, int GM) {
     constexpr int NCONS = BM * BN / 4096;                        // consumer waves (64x64 each)
     constexpr int WN = BN / 64;                                  // consumer grid is (BM/64) x WN
@@ -102,21 +105,23 @@ __global__ __launch_bounds__(64 * (BM * BN / 4096 + NLOAD)) void gemm_nt_ws_kern
                 __builtin_amdgcn_global_load_lds((gvoid_t*)(b_src[g] + ikt * BK), (lvoid_t*)(sb + (L * GB + g) * 1024), 16, 0, 0);
             if (++ikt == nk) { ikt = 0; if (++iu < my_units) setup(iu); }
         };
+        constexpr int AHEAD = NSTAGE - 1;                  // K-steps the loaders run ahead of the consumers
+        constexpr int INFLIGHT = (AHEAD - 1) * PIECES;     // DMA pieces that may stay outstanding across a barrier
         setup(0);
         issue(0);
-        if (total > 1) {
+        if (AHEAD > 1 && total > 1) {
             issue(1);
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES) : "memory");
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(INFLIGHT) : "memory");
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         __builtin_amdgcn_s_barrier();                      // step 0 is in LDS
-        int st2 = 2, ckt = 0;                              // stage for step t+2 ; position inside the current unit
+        int st2 = AHEAD % NSTAGE, ckt = 0;                 // stage for step t+AHEAD ; position inside the current unit
         for (int t = 0; t < total; ++t) {
-            if (t + 2 < total) {
+            if (t + AHEAD < total) {
                 issue(st2);
-                st2 = st2 == 2 ? 0 : st2 + 1;
-                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES) : "memory");     // step t+1 landed, step t+2 in flight
+                st2 = st2 == NSTAGE - 1 ? 0 : st2 + 1;
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(INFLIGHT) : "memory");   // step t+1 landed, later steps in flight
             } else {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
@@ -242,7 +247,7 @@ __global__ __launch_bounds__(64 * (BM * BN / 4096 + NLOAD)) void gemm_nt_ws_kern
             char* sa = smem + st * STAGE;
             compute(sa);
             last_stage = sa;
-            st = st == 2 ? 0 : st + 1;
+            st = st == NSTAGE - 1 ? 0 : st + 1;
             __builtin_amdgcn_s_barrier();                  // end of this K-step (every consumer is done with `sa`)
         }
         epilogue(last_stage, cur.m0, cur.n0);
@@ -265,10 +270,11 @@ bool focus_gemm_mfma_ws_ok(const focus_gemm_desc& d) {
 
 template <int BM, int BN, int EPI, int NLOAD>
 static int launch_ws_n(const focus_gemm_desc& d, hipStream_t s) {
+    constexpr int NSTAGE = (BM + BN) * 128 * 3 <= 160 * 1024 ? 3 : 2;
     const int tiles_m = (d.M + BM - 1) / BM, tiles_n = (d.N + BN - 1) / BN;
     const int nbatch = d.batch0 * d.batch1;
     const size_t lds = (size_t)NSTAGE * (BM + BN) * 128;
-    auto k = gemm_nt_ws_kernel<BM, BN, EPI, NLOAD>;
+    auto k = gemm_nt_ws_kernel<BM, BN, EPI, NLOAD, NSTAGE>;
     static bool once = (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds) == hipSuccess);
     (void)once;
     const int nunits = tiles_m * tiles_n;
@@ -288,8 +294,6 @@ template <int BM, int BN, int EPI>
 static int launch_ws(const focus_gemm_desc& d, hipStream_t s) {
     // loader waves per workgroup: the LDS-DMA issue rate of the loaders, not the MFMA rate, bounds a K-step
     // (~2.2k clocks per K-step with 4 loaders x 12 pieces against 1k clocks of MFMA); FOCUS_GEMM_NLOAD=4|8 for tuning
-    static const int nload = getenv("FOCUS_GEMM_NLOAD") ? atoi(getenv("FOCUS_GEMM_NLOAD")) : 4;
-    if (nload == 8) return launch_ws_n<BM, BN, EPI, 8>(d, s);
     return launch_ws_n<BM, BN, EPI, 4>(d, s);
 }
 
@@ -307,10 +311,29 @@ static int launch_ws_epi(const focus_gemm_desc& d, hipStream_t s) {
     }
 }
 
+static int g_tile_override = 0;
+extern "C" int focus_gemm_tile_override(int bm) {
+    if (bm != 0 && bm != 128 && bm != 192) return FOCUS_ERR_SHAPE;
+    g_tile_override = bm;
+    return FOCUS_OK;
+}
+
 int focus_gemm_mfma_ws(const focus_gemm_desc& d, hipStream_t s) {
     if (d.batch0 * d.batch1 > 65535) return FOCUS_ERR_SHAPE;
     const int64_t t256 = (int64_t)((d.M + 255) / 256) * ((d.N + 127) / 128);
     const int64_t tw = (int64_t)((d.M + 127) / 128) * ((d.N + 255) / 256);
+    const int64_t t192 = (int64_t)((d.M + 191) / 192) * ((d.N + 255) / 256);
+    // tile choice by modelled time = rounds of the 256 persistent workgroups x time per tile; a 192x256 tile measures
+    // 1.40-1.45x the time of a 128x256 tile for 1.5x its work (tools/gemm_tile_ab.py), so it wins where it saves a
+    // round: 12552 x 768 is 198 tiles = one round instead of 297 = two (1.31-1.38x faster at K = 768 .. 3072).
+    // FOCUS_GEMM_TILE=128|192 or focus_gemm_tile_override() force a shape (tuning).
+    static const int env_force = getenv("FOCUS_GEMM_TILE") ? atoi(getenv("FOCUS_GEMM_TILE")) : 0;
+    const int force = g_tile_override ? g_tile_override : env_force;
+    if (d.N >= 256 && d.batch0 * d.batch1 == 1) {
+        const double c128 = (double)((tw + 255) / 256) * 1.0, c192 = (double)((t192 + 255) / 256) * 1.42;
+        const bool use192 = force ? force == 192 : (t192 >= 128 && c192 < c128);
+        if (use192 && t192 >= 128) return launch_ws_epi<192, 256>(d, s);
+    }
     if (d.N >= 256 && tw >= 192) return launch_ws_epi<128, 256>(d, s);   // 512-byte row segments of C
     if (d.M >= 256 && t256 >= 192) return launch_ws_epi<256, 128>(d, s);
     return FOCUS_ERR_SHAPE;   // too few tiles for one 8-consumer workgroup per CU: the caller uses the uniform kernel

@@ -78,6 +78,10 @@ typedef struct focus_gemm_desc {
 
 int focus_gemm(const focus_gemm_desc* desc, void* stream);
 
+/* Tuning hook: force the row-tile height of the wave-specialised NT kernel (128 or 192; 0 = automatic choice by the
+ * modelled rounds-x-tile-time cost).  Used by tools/gemm_tile_ab.py for A/B timing inside one process. */
+int focus_gemm_tile_override(int bm);
+
 /* Weight-gradient form (A strided along the reduction: rsA == 1, csB == 1, bf16 in, fp32 out): the long reduction is
  * split over workgroups.  With desc->aux == NULL the partial sums are added to a zero-initialised C with fp32
  * atomics (desc->accumulate must be 1); with desc->aux pointing to focus_gemm_tn_workspace_bytes(M, N, K) bytes the
