@@ -70,11 +70,13 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const focus_gemm_desc d
     const int nk = (m_end - m_begin + BKM - 1) / BKM;
     if (nk <= 0) return;
 
-    const bf16_t* Pm = static_cast<const bf16_t*>(d.A);     // P[m][i] : element (i, m) of "A" = Pm[m*ldp + i]
-    const bf16_t* Qm = static_cast<const bf16_t*>(d.B);     // Q[m][j]
+    // batch (blockIdx.y, batch1 only): independent products whose outputs are stacked densely ([batch][M][N])
+    const int bz = blockIdx.y, nbz = gridDim.y;
+    const bf16_t* Pm = static_cast<const bf16_t*>(d.A) + bz * d.bsA1;     // P[m][i] : element (i, m) of "A" = Pm[m*ldp + i]
+    const bf16_t* Qm = static_cast<const bf16_t*>(d.B) + bz * d.bsB1;     // Q[m][j]
     const int64_t ldp = d.csA, ldq = d.rsB;
-    // slab mode: this split's partial tile goes to aux[split][M][N] with plain stores (summed by tn_reduce_kernel)
-    float* C = d.aux ? static_cast<float*>(d.aux) + (int64_t)split * d.M * d.N : static_cast<float*>(d.C);
+    // slab mode: this split's partial tile goes to aux[split][batch][M][N] with plain stores (summed by tn_reduce_kernel)
+    float* C = d.aux ? static_cast<float*>(d.aux) + ((int64_t)split * nbz + bz) * d.M * d.N : static_cast<float*>(d.C);
     const int64_t ldc = d.aux ? d.N : d.rsC;
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -247,11 +249,11 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 }
 
 struct TnPlan { int tiles_i, tiles_j, splits, m_per_split; };
-TnPlan tn_plan(int M, int N, int K) {
+TnPlan tn_plan(int M, int N, int K, int batch = 1) {
     TnPlan p;
     p.tiles_i = (M + BI - 1) / BI;
     p.tiles_j = (N + BJ - 1) / BJ;
-    const int tiles = p.tiles_i * p.tiles_j;
+    const int tiles = p.tiles_i * p.tiles_j * batch;
     p.splits = std::max(1, std::min((2 * 256 + tiles - 1) / tiles, (K + 4 * BKM - 1) / (4 * BKM)));
     if (K <= 1024) p.splits = 1;        // short reductions (slot / object-token layers): one unit per tile, no reduce launch
     p.m_per_split = ((K + p.splits - 1) / p.splits + BKM - 1) / BKM * BKM;
@@ -268,12 +270,24 @@ extern "C" size_t focus_gemm_tn_workspace_bytes(int M, int N, int K) {
     return (size_t)tn_plan(M, N, K).splits * M * N * sizeof(float);
 }
 
+extern "C" size_t focus_gemm_tn_batched_workspace_bytes(int M, int N, int K, int batch) {
+    if (M <= 0 || N <= 0 || K <= 0 || batch <= 0) return 0;
+    if (batch == 1) return focus_gemm_tn_workspace_bytes(M, N, K);
+    return (size_t)tn_plan(M, N, K, batch).splits * batch * M * N * sizeof(float);
+}
+
 // A described as [M, K] with rsA == 1 (P[m][i] row-major: csA = ld of P), B as [K, N] with csB == 1 (Q[m][j]).
 bool focus_gemm_mfma_tn_ok(const focus_gemm_desc& d) {
     static const bool enabled = !(getenv("FOCUS_GEMM_TN") && atoi(getenv("FOCUS_GEMM_TN")) == 0);
     if (!enabled || d.dtype_ab != FOCUS_BF16 || d.dtype_c != FOCUS_F32) return false;
     if (d.rsA != 1 || d.csB != 1 || d.csC != 1) return false;
-    if (d.batch0 * d.batch1 != 1 || d.bias || d.residual || d.epilogue != FOCUS_EPI_NONE) return false;
+    if (d.bias || d.residual || d.epilogue != FOCUS_EPI_NONE) return false;
+    if (d.batch0 * d.batch1 != 1) {
+        // batched form (batch1 only): slab mode, outputs stacked densely [batch][M][N]
+        if (d.batch0 != 1 || !d.aux || d.rsC != d.N || d.bsC1 != (int64_t)d.M * d.N || (d.bsA1 & 7) || (d.bsB1 & 7) ||
+            d.batch1 > 65535)
+            return false;
+    }
     if (!d.aux && !d.accumulate) return false;          // atomic mode needs a zero-initialised accumulate target
     if (d.aux && (d.accumulate || (d.rsC & 3) || !focus_aligned(d.aux, 16) || !focus_aligned(d.C, 16))) return false;
     if ((d.csA & 7) || (d.rsB & 7) || (d.M & 7) || (d.N & 7) || d.M < 8 || d.N < 8 || d.K < 1) return false;
@@ -283,7 +297,9 @@ bool focus_gemm_mfma_tn_ok(const focus_gemm_desc& d) {
 
 int focus_gemm_mfma_tn(const focus_gemm_desc& d, hipStream_t s) {
     if (!focus_gemm_mfma_tn_ok(d)) return FOCUS_ERR_ALIGN;
-    const focus_tn_plan ws = focus_gemm_tn_ws_plan(d.M, d.N, d.K);
+    const int nb = d.batch0 * d.batch1;
+    focus_tn_plan ws = focus_gemm_tn_ws_plan(d.M, d.N, d.K);
+    if (nb > 1) ws.kind = 0;                         // batched products take the uniform kernel
     if (ws.kind) {                                   // large outputs with a long reduction: wave-specialised kernel
         const int rc = focus_gemm_mfma_tn_ws(d, ws, nullptr, s);
         if (rc != FOCUS_OK) return rc;
@@ -295,7 +311,7 @@ int focus_gemm_mfma_tn(const focus_gemm_desc& d, hipStream_t s) {
         }
         return FOCUS_OK;
     }
-    const TnPlan pl = tn_plan(d.M, d.N, d.K);
+    const TnPlan pl = tn_plan(d.M, d.N, d.K, nb);
     const int tiles_i = pl.tiles_i, tiles_j = pl.tiles_j, tiles = tiles_i * tiles_j, splits = pl.splits;
     const int m_per_split = pl.m_per_split;
     const size_t lds = 4 * TILE;
@@ -305,10 +321,10 @@ int focus_gemm_mfma_tn(const focus_gemm_desc& d, hipStream_t s) {
     const bool direct = d.aux && splits == 1 && d.rsC == d.N;
     focus_gemm_desc dd = d;
     if (direct) dd.aux = d.C;
-    hipLaunchKernelGGL(gemm_tn_kernel, dim3(tiles * splits), dim3(256), lds, s, dd, tiles_i, tiles_j, splits, m_per_split);
+    hipLaunchKernelGGL(gemm_tn_kernel, dim3(tiles * splits, nb), dim3(256), lds, s, dd, tiles_i, tiles_j, splits, m_per_split);
     FOCUS_CHECK_LAUNCH();
     if (d.aux && !direct) {
-        const int64_t n4 = (int64_t)d.M * d.N / 4;
+        const int64_t n4 = (int64_t)nb * d.M * d.N / 4;
         hipLaunchKernelGGL(tn_reduce_kernel, dim3((unsigned)cdiv64(n4, 256)), dim3(256), 0, s, (const float*)d.aux,
                            (float*)d.C, n4, splits, d.N, d.rsC);
         FOCUS_CHECK_LAUNCH();

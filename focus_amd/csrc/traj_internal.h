@@ -17,3 +17,5 @@ int focus_traj_cls_fwd(const void* qkv, void* cls_out, float* cls_lse, float* sc
                        hipStream_t s);
 int focus_traj_cls_bwd(const void* qkv, const float* cls_lse, const void* dcls, void* dqkv, float* scratch, int B, int N,
                        int heads, int dtype, hipStream_t s);   // scratch: 2*B*heads*N floats
+// re-associated temporal step (traj_time2.hip)
+bool focus_traj_time2_ok(int F, int heads, int d, int dtype);

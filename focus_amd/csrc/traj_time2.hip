@@ -1,212 +1,443 @@
-// traj_time2.hip -- temporal step of trajectory attention (attention.py:538-549) in re-associated form:
-//   logits[s,f,h] = scale * u[s,h,:] . x~[s,f,:],  u[s,h,:] = Wk[h]^T q2[s,h,:]   (see include/focus_amd.h)
-// One wave per (b,s): the 8 x C slab of x~ is read ONCE into registers (4 channels per lane per 256-channel chunk),
-// each head's 8 frame logits are 8 wave reductions of C-long dot products, softmax over frames, and the output /
-// gradients are finished from the registers.  HBM-bound: x~ (F*C) + u (h*C) read, out (C) written per query.
+// traj_time2.hip -- temporal step of trajectory attention (attention.py:536-549) WITHOUT k2 = proj_kv(x~) in HBM.
+//
+// With use_original_code=True (the only mode the reference runs) the temporal logits are
+//     scale * q2[s,h,:] . (Wk[h] x~[s,f,:] + bk[h])  =  scale * u[s,h,:] . x~[s,f,:]  +  (a term constant in f),
+//     u[s,h,:] = Wk[h]^T q2[s,h,:]  in R^C,
+// and the softmax over the F frames is shift invariant: k2 [B,S,F,C] (the block's largest GEMM, 8x the tokens, and the
+// 154 MB tensor it writes and the time kernels re-read, plus dk2 of the same size backward) never has to exist, and
+// proj_kv.bias gets its exact zero gradient.  u is 12x768 numbers per query -- larger than k2's row -- so it is never
+// written either: it is formed per 64-channel chunk ON CHIP.
+//
+// Decomposition (the same for forward and backward): workgroup = (channel chunk cc of 64 channels, query range).
+// Its slice Wk^T[cc*64 .. +63][all (h,dd)] (96 KB bf16) sits in LDS for the whole launch; per tile of 16 queries:
+//     U^T[c, s]   = sum_dd WkT[c, h*64+dd] q2[s, h*64+dd]          MFMA 16x16x32, M = channels, N = queries, K = 64
+//                   -> bf16 -> LDS image U[s][h][c]
+//   forward  (time2_logits_kernel):
+//     L[f, h]    += sum_c x~[s,f,c] U[s,h,c]   per query s            MFMA 16x16x32, M = frames, N = heads, K = 64;
+//                   the A operand is read from x~ in HBM directly (16 B per lane, 128-B row segments); partial
+//                   logits of the chunk go to slab[cc][b,h,s,f]; time2_softmax_kernel sums the C/64 slabs and takes
+//                   the softmax over f; time2_out_kernel forms out = sum_f a x~ (reads x~ once more).
+//   backward (time2_dl_kernel, then time2_bwd_kernel):
+//     dl[s,f,h]   = scale a (da - sum_f a da),  da[s,f,h] = dout[s,h,:] . x~[s,f,h,:]
+//     dx~[s,f,c]  = a[s,f,h(c)] dout[s,c] + sum_h dl[s,f,h] U[s,h,c]                      (VALU, U from LDS)
+//     g[s,h,c]    = sum_f dl[s,f,h] x~[s,f,c]   ( = du )  -> HBM [B,S,h,C] bf16: the host forms
+//                   dq2 = scale^-1-free GEMM  g[:,h,:] . Wk[h]^T  and  dWk[h] = q2[:,h,:]^T . g[:,h,:]  from it.
+// HBM per block and direction: x~ is read twice forward (logits, out) and twice backward (dl, g), dx~ and g are
+// written once; the k2 path moved k2/dk2 four more times and ran three 100352 x 768 x 768 GEMMs.
 #include "focus_common.h"
+#include <cstdlib>
+#include "traj_internal.h"
 
 namespace {
 
-constexpr int FT = 8;        // frames (compile-time: keeps x~ in registers); other F use the k2 path
-constexpr int NCH = 3;       // 256-channel chunks handled per lane (C <= 768)
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
 
-template <typename T>
-__global__ __launch_bounds__(256) void time2_fwd_kernel(const T* __restrict__ u, const T* __restrict__ xt,
-                                                        T* __restrict__ out, float* __restrict__ attn2, int64_t rows,
-                                                        int S, int heads, int d, float scale) {
-    const int lane = threadIdx.x & 63;
-    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= rows) return;
-    const int C = heads * d, lph = d >> 2;
-    const int64_t b = row / S;
-    const int s = (int)(row % S);
-    f4 x[FT][NCH];
-    bool act[NCH];
-    int hd[NCH];
-#pragma unroll
-    for (int i = 0; i < NCH; ++i) {
-        const int c = i * 256 + lane * 4;
-        act[i] = c < C;
-        hd[i] = act[i] ? c / d : -1;
-#pragma unroll
-        for (int f = 0; f < FT; ++f)
-            x[f][i] = act[i] ? ld4<T>(xt + (row * FT + f) * C + c) : (f4){0.f, 0.f, 0.f, 0.f};
-    }
-    float a[NCH][FT];
-#pragma unroll
-    for (int i = 0; i < NCH; ++i)
-#pragma unroll
-        for (int f = 0; f < FT; ++f) a[i][f] = 0.f;
-    for (int h = 0; h < heads; ++h) {
-        f4 uv[NCH];
-#pragma unroll
-        for (int i = 0; i < NCH; ++i)
-            uv[i] = act[i] ? ld4<T>(u + (row * heads + h) * C + i * 256 + lane * 4) : (f4){0.f, 0.f, 0.f, 0.f};
-        float lg[FT], m = -INFINITY;
-#pragma unroll
-        for (int f = 0; f < FT; ++f) {
-            float p = 0.f;
-#pragma unroll
-            for (int i = 0; i < NCH; ++i)
-                p += uv[i].x * x[f][i].x + uv[i].y * x[f][i].y + uv[i].z * x[f][i].z + uv[i].w * x[f][i].w;
-            lg[f] = scale * wave_sum(p);
-            m = fmaxf(m, lg[f]);
-        }
-        float den = 0.f;
-#pragma unroll
-        for (int f = 0; f < FT; ++f) { lg[f] = __expf(lg[f] - m); den += lg[f]; }
-        const float inv = 1.f / den;
-#pragma unroll
-        for (int i = 0; i < NCH; ++i) {
-            const bool mine = hd[i] == h;
-#pragma unroll
-            for (int f = 0; f < FT; ++f) a[i][f] = mine ? lg[f] * inv : a[i][f];
-        }
-#pragma unroll
-        for (int f = 0; f < FT; ++f)
-            if (lane == f) attn2[((b * heads + h) * S + s) * FT + f] = lg[f] * inv;
-    }
-    (void)lph;
-#pragma unroll
-    for (int i = 0; i < NCH; ++i) {
-        if (!act[i]) continue;
-        f4 o = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int f = 0; f < FT; ++f) {
-            o.x += a[i][f] * x[f][i].x; o.y += a[i][f] * x[f][i].y; o.z += a[i][f] * x[f][i].z; o.w += a[i][f] * x[f][i].w;
-        }
-        st4<T>(out + row * C + i * 256 + lane * 4, o);
+constexpr int CH = 64;                 // channels per chunk (= head dim: chunk cc holds exactly head cc's channels)
+constexpr int TQ = 16;                 // queries per tile (MFMA N)
+constexpr int MAXH = 16;               // heads <= 16 (MFMA N of the logit product)
+constexpr int MAXF = 16;               // frames <= 16 (MFMA M of the logit product)
+
+union Pk8 { uint4 u; bf16_t e[8]; bf16x8 v; };
+union Pk4 { uint2 u; bf16_t e[4]; };
+
+__device__ __forceinline__ void unpack8(const uint4& r, float* v) {
+    v[0] = __uint_as_float(r.x << 16); v[1] = __uint_as_float(r.x & 0xffff0000u);
+    v[2] = __uint_as_float(r.y << 16); v[3] = __uint_as_float(r.y & 0xffff0000u);
+    v[4] = __uint_as_float(r.z << 16); v[5] = __uint_as_float(r.z & 0xffff0000u);
+    v[6] = __uint_as_float(r.w << 16); v[7] = __uint_as_float(r.w & 0xffff0000u);
+}
+__device__ __forceinline__ uint4 pack8(const float* v) {
+    uint4 o;
+    o.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
+    o.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
+    o.z = (uint32_t)f32_to_bf16(v[4]) | ((uint32_t)f32_to_bf16(v[5]) << 16);
+    o.w = (uint32_t)f32_to_bf16(v[6]) | ((uint32_t)f32_to_bf16(v[7]) << 16);
+    return o;
+}
+__device__ __forceinline__ float sum8lanes(float v) {
+    v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64);
+    return v;
+}
+
+// LDS images.  Row pitches are the data bytes + 16: 16 lanes that read the same 16-byte column of 16 consecutive rows
+// (the MFMA row fragments) then fall on 16 different 16-byte slots of the 256-byte bank row.
+__device__ __forceinline__ int wrow_bytes(int C) { return C * 2 + 16; }            // Wk^T slice: [64 c][C (h,dd)]
+__device__ __forceinline__ int urow_bytes(int heads) { return heads * CH * 2 + 16; }   // U: [16 s][heads][64 c]
+
+// Wk^T slice of this chunk -> LDS (once per workgroup; register staged: the padded rows rule out LDS-DMA)
+__device__ __forceinline__ void load_w_slice(char* sW, const bf16_t* wkT, int64_t ldw, int cc, int C) {
+    const int pieces = C / 8, wrow = wrow_bytes(C);              // 16-byte pieces per row
+    for (int e = threadIdx.x; e < CH * pieces; e += blockDim.x) {
+        const int row = e / pieces, pc = e - row * pieces;
+        const uint4 v = *reinterpret_cast<const uint4*>(wkT + (int64_t)(cc * CH + row) * ldw + pc * 8);
+        *reinterpret_cast<uint4*>(sW + row * wrow + pc * 16) = v;
     }
 }
 
-template <typename T>
-__global__ __launch_bounds__(256) void time2_bwd_kernel(const T* __restrict__ u, const T* __restrict__ xt,
-                                                        const float* __restrict__ attn2, const T* __restrict__ dout,
-                                                        T* __restrict__ du, T* __restrict__ dxt, int dxt_accum,
-                                                        int64_t rows, int S, int heads, int d, float scale) {
-    __shared__ float sdl[4][16 * FT];                 // per wave: dlogit[h][f] (scale included)
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int64_t row = (int64_t)blockIdx.x * 4 + w;
-    const bool valid = row < rows;                    // no early return: the wave-level LDS exchange needs every lane
-    const int64_t rw = valid ? row : rows - 1;
-    const int C = heads * d, lph = d >> 2;
-    const int64_t b = rw / S;
-    const int s = (int)(rw % S);
-    f4 x[FT][NCH], g[NCH];
-    bool act[NCH];
-    int hd[NCH];
+// U[s][h][c] of one 16-query tile for the heads of this wave (h = w, w + 4, ...): U^T = WkT_slice . q2^T per head.
+__device__ __forceinline__ void compute_u_tile(const char* sW, char* sU, const bf16_t* __restrict__ q2, int64_t row0,
+                                               int64_t rows_total, int C, int heads, int w, int lane) {
+    const int wrow = wrow_bytes(C), urow = urow_bytes(heads);
+    const int col = lane & 15, kg = lane >> 4;
+    const int64_t qrow = min(row0 + col, rows_total - 1);        // this lane's query (MFMA column), clamped
+    for (int h = w; h < heads; h += 4) {
+        bf16x8 qb[2];
 #pragma unroll
-    for (int i = 0; i < NCH; ++i) {
-        const int c = i * 256 + lane * 4;
-        act[i] = c < C;
-        hd[i] = act[i] ? c / d : 0;
-        g[i] = act[i] ? ld4<T>(dout + rw * C + c) : (f4){0.f, 0.f, 0.f, 0.f};
+        for (int ks = 0; ks < 2; ++ks)
+            qb[ks] = *reinterpret_cast<const bf16x8*>(q2 + qrow * C + h * CH + 32 * ks + 8 * kg);
 #pragma unroll
-        for (int f = 0; f < FT; ++f)
-            x[f][i] = act[i] ? ld4<T>(xt + (rw * FT + f) * C + c) : (f4){0.f, 0.f, 0.f, 0.f};
-    }
-    // d attn[f] for this lane's head (reduce over the head's d/4 lanes), then d logits
-    float a[NCH][FT];
+        for (int mt = 0; mt < 4; ++mt) {
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int i = 0; i < NCH; ++i) {
-        float da[FT], dot = 0.f;
-#pragma unroll
-        for (int f = 0; f < FT; ++f) {
-            a[i][f] = act[i] ? attn2[((b * heads + hd[i]) * S + s) * FT + f] : 0.f;
-            float p = g[i].x * x[f][i].x + g[i].y * x[f][i].y + g[i].z * x[f][i].z + g[i].w * x[f][i].w;
-            for (int o = lph >> 1; o > 0; o >>= 1) p += __shfl_xor(p, o, 64);
-            da[f] = p;
-            dot += a[i][f] * p;
-        }
-        if (act[i] && (lane % lph) == 0) {
-#pragma unroll
-            for (int f = 0; f < FT; ++f) sdl[w][hd[i] * FT + f] = scale * a[i][f] * (da[f] - dot);
-        }
-    }
-    __builtin_amdgcn_wave_barrier();
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    // dxt = attn * dout + sum_h dlogit[f,h] * u[h]  ;  du[h] = sum_f dlogit[f,h] * x[f]
-    f4 dx[FT][NCH];
-#pragma unroll
-    for (int i = 0; i < NCH; ++i)
-#pragma unroll
-        for (int f = 0; f < FT; ++f)
-            dx[f][i] = {a[i][f] * g[i].x, a[i][f] * g[i].y, a[i][f] * g[i].z, a[i][f] * g[i].w};
-    for (int h = 0; h < heads; ++h) {
-        float dl[FT];
-#pragma unroll
-        for (int f = 0; f < FT; ++f) dl[f] = sdl[w][h * FT + f];
-#pragma unroll
-        for (int i = 0; i < NCH; ++i) {
-            if (!act[i]) continue;
-            const int64_t uo = (rw * heads + h) * C + i * 256 + lane * 4;
-            const f4 uv = ld4<T>(u + uo);
-            f4 dv = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int f = 0; f < FT; ++f) {
-                dx[f][i].x += dl[f] * uv.x; dx[f][i].y += dl[f] * uv.y; dx[f][i].z += dl[f] * uv.z; dx[f][i].w += dl[f] * uv.w;
-                dv.x += dl[f] * x[f][i].x; dv.y += dl[f] * x[f][i].y; dv.z += dl[f] * x[f][i].z; dv.w += dl[f] * x[f][i].w;
+            for (int ks = 0; ks < 2; ++ks) {
+                const bf16x8 a = *reinterpret_cast<const bf16x8*>(sW + (16 * mt + col) * wrow + (h * CH + 32 * ks + 8 * kg) * 2);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, qb[ks], acc, 0, 0, 0);
             }
-            if (valid) st4<T>(du + uo, dv);
-        }
-    }
-    if (!valid) return;
+            // acc[r] = U^T[c = 16 mt + 4 kg + r][s = col]
+            Pk4 p;
 #pragma unroll
-    for (int i = 0; i < NCH; ++i) {
-        if (!act[i]) continue;
-#pragma unroll
-        for (int f = 0; f < FT; ++f) {
-            T* p = dxt + (rw * FT + f) * C + i * 256 + lane * 4;
-            f4 o = dx[f][i];
-            if (dxt_accum) { const f4 old = ld4<T>(p); o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w; }
-            st4<T>(p, o);
+            for (int r = 0; r < 4; ++r) p.e[r] = f32_to_bf16(acc[r]);
+            *reinterpret_cast<uint2*>(sU + col * urow + h * (CH * 2) + (16 * mt + 4 * kg) * 2) = p.u;
         }
     }
 }
 
-bool shape_ok(int F, int heads, int d) {
-    const int lph = d >> 2;
-    return F == FT && (d & 3) == 0 && lph >= 1 && lph <= 64 && (lph & (lph - 1)) == 0 && heads >= 1 && heads <= 16 &&
-           heads * d <= NCH * 256;
+// ------------------------------------------------------------------------------------------------
+// forward 1/3: partial logits of one channel chunk
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void time2_logits_kernel(const bf16_t* __restrict__ q2, const bf16_t* __restrict__ xt,
+                                                           const bf16_t* __restrict__ wkT, int64_t ldw,
+                                                           float* __restrict__ slab, int64_t rows, int S, int F, int heads,
+                                                           float scale) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int C = heads * CH, cc = blockIdx.x, nranges = gridDim.y;
+    char* sW = smem;
+    char* sU = smem + CH * wrow_bytes(C);
+    const int urow = urow_bytes(heads);
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int64_t ntiles = (rows + TQ - 1) / TQ;
+    const int64_t t_begin = ntiles * blockIdx.y / nranges, t_end = ntiles * (blockIdx.y + 1) / nranges;
+    load_w_slice(sW, wkT, ldw, cc, C);
+    __syncthreads();
+    const int col = lane & 15, kg = lane >> 4;
+    const int fl = col < F ? col : F - 1;                         // frame of this lane's A row (rows >= F: duplicates)
+    const int hl = col < heads ? col : heads - 1;                 // head of this lane's B column (cols >= heads: dup.)
+    const int64_t slab_chunk = (int64_t)cc * rows * heads * F;    // slab[cc][b][h][s][f] = [cc][(b*heads+h)*S + s][f]
+    for (int64_t t = t_begin; t < t_end; ++t) {
+        const int64_t row0 = t * TQ;
+        // x~ fragments of this wave's 4 queries first: their HBM latency runs under the U product below
+        bf16x8 xa[4][2];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int64_t row = min(row0 + 4 * w + i, rows - 1);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+                xa[i][ks] = *reinterpret_cast<const bf16x8*>(xt + (row * F + fl) * C + cc * CH + 32 * ks + 8 * kg);
+        }
+        compute_u_tile(sW, sU, q2, row0, rows, C, heads, w, lane);
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int sq = 4 * w + i;
+            const int64_t row = row0 + sq;
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const bf16x8 ub = *reinterpret_cast<const bf16x8*>(sU + sq * urow + hl * (CH * 2) + (32 * ks + 8 * kg) * 2);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xa[i][ks], ub, acc, 0, 0, 0);
+            }
+            // acc[r] = L[f = 4 kg + r][h = col]
+            if (row < rows && col < heads) {
+                const int64_t b = row / S;
+                const int s = (int)(row - b * S);
+                float* dst = slab + slab_chunk + (((b * heads + col) * S + s) * F);
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (4 * kg + r < F) dst[4 * kg + r] = acc[r] * scale;
+            }
+        }
+        __syncthreads();                                           // U tile is free for the next tile
+    }
+}
+
+// forward 2/3: sum the chunk slabs, softmax over the frames -> attn2 [B,h,S,F]
+__global__ __launch_bounds__(256) void time2_softmax_kernel(const float* __restrict__ slab, float* __restrict__ attn2,
+                                                            int64_t n, int F, int nchunk) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;       // one (b,h,s) per thread
+    if (i >= n) return;
+    float lg[MAXF];
+#pragma unroll
+    for (int f = 0; f < MAXF; ++f) lg[f] = 0.f;
+    for (int c = 0; c < nchunk; ++c) {
+        const float* p = slab + ((int64_t)c * n + i) * F;
+#pragma unroll
+        for (int f = 0; f < MAXF; ++f)
+            if (f < F) lg[f] += p[f];
+    }
+    float m = -INFINITY;
+#pragma unroll
+    for (int f = 0; f < MAXF; ++f)
+        if (f < F) m = fmaxf(m, lg[f]);
+    float den = 0.f;
+#pragma unroll
+    for (int f = 0; f < MAXF; ++f)
+        if (f < F) { lg[f] = __expf(lg[f] - m); den += lg[f]; }
+    const float inv = 1.f / den;
+#pragma unroll
+    for (int f = 0; f < MAXF; ++f)
+        if (f < F) attn2[i * F + f] = lg[f] * inv;
+}
+
+// forward 3/3: out[s, (h,dd)] = sum_f attn2[s,f,h] x~[s,f,(h,dd)]; thread = (row, 8-channel group), 16-byte accesses
+template <int FT>
+__global__ __launch_bounds__(256) void time2_out_kernel(const bf16_t* __restrict__ xt, const float* __restrict__ attn2,
+                                                        bf16_t* __restrict__ out, int64_t obs, int64_t ngroups, int S,
+                                                        int heads) {
+    const int64_t gi = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const bool act = gi < ngroups;
+    const int64_t g = act ? gi : ngroups - 1;
+    const int gpr = heads * 8;
+    const int64_t row = g / gpr;
+    const int cg = (int)(g - row * gpr);
+    const int C = gpr * 8;
+    uint4 xr[FT];
+#pragma unroll
+    for (int f = 0; f < FT; ++f) xr[f] = *reinterpret_cast<const uint4*>(xt + ((row * FT + f) * C) + cg * 8);
+    const int64_t b = row / S;
+    const int s = (int)(row - b * S);
+    const float* arow = attn2 + (((b * heads + (cg >> 3)) * S + s) * FT);
+    float o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int f = 0; f < FT; ++f) {
+        const float a = arow[f];
+        float xv[8];
+        unpack8(xr[f], xv);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = fmaf(a, xv[e], o[e]);
+    }
+    if (act) *reinterpret_cast<uint4*>(out + b * obs + (int64_t)s * C + cg * 8) = pack8(o);
+}
+
+// backward 1/2: dl[b,h,s,f] = scale * a (da - sum_f a da),  da = dout[s,h,:] . x~[s,f,h,:]
+template <int FT>
+__global__ __launch_bounds__(256) void time2_dl_kernel(const bf16_t* __restrict__ xt, const float* __restrict__ attn2,
+                                                       const bf16_t* __restrict__ dout, int64_t dobs, float* __restrict__ dl,
+                                                       int64_t ngroups, int S, int heads, float scale) {
+    const int64_t gi = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const bool act = gi < ngroups;
+    const int64_t g = act ? gi : ngroups - 1;
+    const int gpr = heads * 8;
+    const int64_t row = g / gpr;
+    const int cg = (int)(g - row * gpr);
+    const int C = gpr * 8;
+    const int64_t b = row / S;
+    const int s = (int)(row - b * S);
+    uint4 xr[FT];
+#pragma unroll
+    for (int f = 0; f < FT; ++f) xr[f] = *reinterpret_cast<const uint4*>(xt + ((row * FT + f) * C) + cg * 8);
+    float gv[8];
+    unpack8(*reinterpret_cast<const uint4*>(dout + b * dobs + (int64_t)s * C + cg * 8), gv);
+    const int64_t o = ((b * heads + (cg >> 3)) * S + s) * FT;
+    float a[FT], da[FT], dot = 0.f;
+#pragma unroll
+    for (int f = 0; f < FT; ++f) {
+        a[f] = attn2[o + f];
+        float xv[8];
+        unpack8(xr[f], xv);
+        float p = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) p = fmaf(gv[e], xv[e], p);
+        da[f] = sum8lanes(p);
+        dot = fmaf(a[f], da[f], dot);
+    }
+    if (act && (cg & 7) == 0) {
+#pragma unroll
+        for (int f = 0; f < FT; ++f) dl[o + f] = scale * a[f] * (da[f] - dot);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward 2/2: dx~ and g = du for one channel chunk (recomputes U on chip like the forward)
+// ------------------------------------------------------------------------------------------------
+template <int FT>
+__global__ __launch_bounds__(256) void time2_bwd_kernel(const bf16_t* __restrict__ q2, const bf16_t* __restrict__ xt,
+                                                        const bf16_t* __restrict__ wkT, int64_t ldw,
+                                                        const float* __restrict__ attn2, const float* __restrict__ dl,
+                                                        const bf16_t* __restrict__ dout, int64_t dobs,
+                                                        bf16_t* __restrict__ dxt, bf16_t* __restrict__ gout, int64_t rows,
+                                                        int S, int heads) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int C = heads * CH, cc = blockIdx.x, nranges = gridDim.y;
+    char* sW = smem;
+    char* sU = sW + CH * wrow_bytes(C);
+    float* sDL = reinterpret_cast<float*>(sU + TQ * urow_bytes(heads));   // [16 s][FT][MAXH] dl; then [16 s][FT] a(h = cc)
+    float* sA = sDL + TQ * FT * MAXH;
+    const int urow = urow_bytes(heads);
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int64_t ntiles = (rows + TQ - 1) / TQ;
+    const int64_t t_begin = ntiles * blockIdx.y / nranges, t_end = ntiles * (blockIdx.y + 1) / nranges;
+    load_w_slice(sW, wkT, ldw, cc, C);
+    __syncthreads();
+    // g task of this thread: query sg = tid >> 4, channel group c8 = (tid >> 1) & 7, head half hh = tid & 1
+    const int sg = tid >> 4, c8g = (tid >> 1) & 7, hh = tid & 1;
+    const int hper = (heads + 1) / 2;
+    for (int64_t t = t_begin; t < t_end; ++t) {
+        const int64_t row0 = t * TQ;
+        // x~ rows of the g task (8 frames x 16 B), issued first
+        const int64_t grow = min(row0 + sg, rows - 1);
+        uint4 xr[FT];
+#pragma unroll
+        for (int f = 0; f < FT; ++f) xr[f] = *reinterpret_cast<const uint4*>(xt + (grow * FT + f) * C + cc * CH + c8g * 8);
+        // dl / a of the tile -> LDS
+        for (int e = tid; e < TQ * FT * heads; e += 256) {
+            const int h = e % heads, sf = e / heads, f = sf % FT, sq = sf / FT;
+            const int64_t row = min(row0 + sq, rows - 1);
+            const int64_t b = row / S;
+            const int s = (int)(row - b * S);
+            sDL[(sq * FT + f) * MAXH + h] = dl[((b * heads + h) * S + s) * FT + f];
+        }
+        for (int e = tid; e < TQ * FT; e += 256) {
+            const int f = e % FT, sq = e / FT;
+            const int64_t row = min(row0 + sq, rows - 1);
+            const int64_t b = row / S;
+            const int s = (int)(row - b * S);
+            sA[e] = attn2[((b * heads + cc) * S + s) * FT + f];
+        }
+        compute_u_tile(sW, sU, q2, row0, rows, C, heads, w, lane);
+        __syncthreads();
+        // ---- dx~[s,f,c] = a[s,f,cc] dout[s,c] + sum_h dl[s,f,h] U[s,h,c] : task = (s, f, 8 channels) ----
+        for (int e = tid; e < TQ * FT * 8; e += 256) {
+            const int c8 = e & 7, f = (e >> 3) % FT, sq = (e >> 3) / FT;
+            const int64_t row = row0 + sq;
+            if (row >= rows) continue;
+            const int64_t b = row / S;
+            const int s = (int)(row - b * S);
+            float dv[8], v[8];
+            unpack8(*reinterpret_cast<const uint4*>(dout + b * dobs + (int64_t)s * C + cc * CH + c8 * 8), dv);
+            const float a = sA[sq * FT + f];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = a * dv[k];
+            const float* dlr = sDL + (sq * FT + f) * MAXH;
+            for (int h = 0; h < heads; ++h) {
+                float uv[8];
+                unpack8(*reinterpret_cast<const uint4*>(sU + sq * urow + h * (CH * 2) + c8 * 16), uv);
+                const float d = dlr[h];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[k] = fmaf(d, uv[k], v[k]);
+            }
+            *reinterpret_cast<uint4*>(dxt + (row * FT + f) * C + cc * CH + c8 * 8) = pack8(v);
+        }
+        // ---- g[s,h,c] = sum_f dl[s,f,h] x~[s,f,c] : this thread's (s, 8 channels) for its half of the heads ----
+        {
+            float xv[FT][8];
+#pragma unroll
+            for (int f = 0; f < FT; ++f) unpack8(xr[f], xv[f]);
+            const int64_t row = row0 + sg;
+            for (int hi = 0; hi < hper; ++hi) {
+                const int h = hh * hper + hi;
+                if (h >= heads) break;
+                float gv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int f = 0; f < FT; ++f) {
+                    const float d = sDL[(sg * FT + f) * MAXH + h];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) gv[k] = fmaf(d, xv[f][k], gv[k]);
+                }
+                if (row < rows)
+                    *reinterpret_cast<uint4*>(gout + (row * heads + h) * C + cc * CH + c8g * 8) = pack8(gv);
+            }
+        }
+        __syncthreads();                                           // U / dl tiles are free for the next tile
+    }
+}
+
+size_t time2_lds_fwd(int heads) { return (size_t)CH * (heads * CH * 2 + 16) + (size_t)TQ * (heads * CH * 2 + 16); }
+size_t time2_lds_bwd(int heads, int F) { return time2_lds_fwd(heads) + (size_t)TQ * F * (MAXH + 1) * sizeof(float); }
+
+int ranges_for(int nchunk, int64_t rows) {
+    int r = 256 / nchunk;                                          // one workgroup per CU
+    const int64_t ntiles = (rows + TQ - 1) / TQ;
+    if (r > ntiles) r = (int)ntiles;
+    return r < 1 ? 1 : r;
 }
 
 }  // namespace
 
-extern "C" int focus_traj_time2_fwd(const void* u, const void* xt, void* out, float* attn2, int B, int S, int F,
+bool focus_traj_time2_ok(int F, int heads, int d, int dtype) {
+    static const bool enabled = !(getenv("FOCUS_TIME2") && atoi(getenv("FOCUS_TIME2")) == 0);
+    return enabled && dtype == FOCUS_BF16 && d == CH && heads >= 1 && heads <= MAXH && (F == 4 || F == 8 || F == 16);
+}
+
+extern "C" size_t focus_traj_time2_workspace_bytes(int B, int S, int F, int heads, int d) {
+    if (B <= 0 || S <= 0 || F <= 0 || heads <= 0 || d != CH) return 0;
+    return (size_t)heads * B * heads * S * F * sizeof(float);       // one partial-logit slab per channel chunk
+}
+
+extern "C" int focus_traj_time2_fwd(const void* q2, const void* xt, const void* wkT, int64_t ldw, void* out,
+                                    int64_t out_bstride, float* attn2, void* ws, size_t ws_bytes, int B, int S, int F,
                                     int heads, int d, int dtype, void* stream) {
-    if (!u || !xt || !out || !attn2) return FOCUS_ERR_NULL;
-    if (!shape_ok(F, heads, d)) return FOCUS_ERR_SHAPE;
+    if (!q2 || !xt || !wkT || !out || !attn2 || !ws) return FOCUS_ERR_NULL;
+    if (B <= 0 || S <= 0 || !focus_traj_time2_ok(F, heads, d, dtype)) return FOCUS_ERR_SHAPE;
+    const int C = heads * CH;
+    if (ldw < C || (ldw & 7) || (out_bstride & 7) || out_bstride < (int64_t)S * C) return FOCUS_ERR_SHAPE;
+    if (!focus_aligned(q2, 16) || !focus_aligned(xt, 16) || !focus_aligned(wkT, 16) || !focus_aligned(out, 16))
+        return FOCUS_ERR_ALIGN;
+    if (ws_bytes < focus_traj_time2_workspace_bytes(B, S, F, heads, d)) return FOCUS_ERR_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
     const int64_t rows = (int64_t)B * S;
-    if (rows <= 0) return FOCUS_OK;
+    const int nchunk = C / CH;
+    const size_t lds = time2_lds_fwd(heads);
+    static bool once = (hipFuncSetAttribute((const void*)time2_logits_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                            160 * 1024) == hipSuccess);
+    (void)once;
+    if (lds > 160 * 1024) return FOCUS_ERR_SHAPE;
     const float scale = 1.f / sqrtf((float)d);
-    dim3 grid((unsigned)cdiv64(rows, 4));
-    if (dtype == FOCUS_BF16)
-        hipLaunchKernelGGL((time2_fwd_kernel<bf16_t>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)u,
-                           (const bf16_t*)xt, (bf16_t*)out, attn2, rows, S, heads, d, scale);
-    else
-        hipLaunchKernelGGL((time2_fwd_kernel<float>), grid, dim3(256), 0, (hipStream_t)stream, (const float*)u,
-                           (const float*)xt, (float*)out, attn2, rows, S, heads, d, scale);
+    hipLaunchKernelGGL(time2_logits_kernel, dim3(nchunk, ranges_for(nchunk, rows)), dim3(256), lds, s, (const bf16_t*)q2,
+                       (const bf16_t*)xt, (const bf16_t*)wkT, ldw, (float*)ws, rows, S, F, heads, scale);
+    FOCUS_CHECK_LAUNCH();
+    const int64_t n = rows * heads;
+    hipLaunchKernelGGL(time2_softmax_kernel, dim3((unsigned)cdiv64(n, 256)), dim3(256), 0, s, (const float*)ws, attn2, n, F,
+                       nchunk);
+    FOCUS_CHECK_LAUNCH();
+    const int64_t ng = rows * heads * 8;
+    dim3 gv((unsigned)cdiv64(ng, 256));
+#define TO(FT) hipLaunchKernelGGL((time2_out_kernel<FT>), gv, dim3(256), 0, s, (const bf16_t*)xt, attn2, (bf16_t*)out, out_bstride, ng, S, heads)
+    if (F == 8) TO(8); else if (F == 4) TO(4); else TO(16);
+#undef TO
     FOCUS_CHECK_LAUNCH();
     return FOCUS_OK;
 }
 
-extern "C" int focus_traj_time2_bwd(const void* u, const void* xt, const float* attn2, const void* dout, void* du,
-                                    void* dxt, int dxt_accum, int B, int S, int F, int heads, int d, int dtype,
-                                    void* stream) {
-    if (!u || !xt || !attn2 || !dout || !du || !dxt) return FOCUS_ERR_NULL;
-    if (!shape_ok(F, heads, d)) return FOCUS_ERR_SHAPE;
+extern "C" int focus_traj_time2_bwd(const void* q2, const void* xt, const void* wkT, int64_t ldw, const float* attn2,
+                                    const void* dout, int64_t dout_bstride, void* dxt, void* g, float* dl, int B, int S,
+                                    int F, int heads, int d, int dtype, void* stream) {
+    if (!q2 || !xt || !wkT || !attn2 || !dout || !dxt || !g || !dl) return FOCUS_ERR_NULL;
+    if (B <= 0 || S <= 0 || !focus_traj_time2_ok(F, heads, d, dtype)) return FOCUS_ERR_SHAPE;
+    const int C = heads * CH;
+    if (ldw < C || (ldw & 7) || (dout_bstride & 7) || dout_bstride < (int64_t)S * C) return FOCUS_ERR_SHAPE;
+    if (!focus_aligned(q2, 16) || !focus_aligned(xt, 16) || !focus_aligned(wkT, 16) || !focus_aligned(dout, 16) ||
+        !focus_aligned(dxt, 16) || !focus_aligned(g, 16))
+        return FOCUS_ERR_ALIGN;
+    hipStream_t s = (hipStream_t)stream;
     const int64_t rows = (int64_t)B * S;
-    if (rows <= 0) return FOCUS_OK;
+    const int nchunk = C / CH;
     const float scale = 1.f / sqrtf((float)d);
-    dim3 grid((unsigned)cdiv64(rows, 4));
-    if (dtype == FOCUS_BF16)
-        hipLaunchKernelGGL((time2_bwd_kernel<bf16_t>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)u,
-                           (const bf16_t*)xt, attn2, (const bf16_t*)dout, (bf16_t*)du, (bf16_t*)dxt, dxt_accum, rows, S,
-                           heads, d, scale);
-    else
-        hipLaunchKernelGGL((time2_bwd_kernel<float>), grid, dim3(256), 0, (hipStream_t)stream, (const float*)u,
-                           (const float*)xt, attn2, (const float*)dout, (float*)du, (float*)dxt, dxt_accum, rows, S, heads,
-                           d, scale);
+    const int64_t ng = rows * heads * 8;
+    dim3 gv((unsigned)cdiv64(ng, 256));
+#define TD(FT) hipLaunchKernelGGL((time2_dl_kernel<FT>), gv, dim3(256), 0, s, (const bf16_t*)xt, attn2, (const bf16_t*)dout, dout_bstride, dl, ng, S, heads, scale)
+    if (F == 8) TD(8); else if (F == 4) TD(4); else TD(16);
+#undef TD
+    FOCUS_CHECK_LAUNCH();
+    const size_t lds = time2_lds_bwd(heads, F);
+    if (lds > 160 * 1024) return FOCUS_ERR_SHAPE;
+    dim3 grid(nchunk, ranges_for(nchunk, rows));
+#define TB(FT) do { \
+        static bool once_##FT = (hipFuncSetAttribute((const void*)time2_bwd_kernel<FT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess); \
+        (void)once_##FT; \
+        hipLaunchKernelGGL((time2_bwd_kernel<FT>), grid, dim3(256), lds, s, (const bf16_t*)q2, (const bf16_t*)xt, (const bf16_t*)wkT, ldw, attn2, (const float*)dl, (const bf16_t*)dout, dout_bstride, (bf16_t*)dxt, (bf16_t*)g, rows, S, heads); } while (0)
+    if (F == 8) TB(8); else if (F == 4) TB(4); else TB(16);
+#undef TB
     FOCUS_CHECK_LAUNCH();
     return FOCUS_OK;
 }

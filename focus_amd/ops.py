@@ -767,77 +767,80 @@ def traj_time_block(q2, xt, w_kv, b_kv, cls_out, heads):
     return _TrajTimeBlockFn.apply(q2, xt, w_kv, b_kv, cls_out, heads)
 
 
-class _TrajTime2Fn(torch.autograd.Function):
-    """Temporal step in re-associated form (include/focus_amd.h: focus_traj_time2_*): the k2 = proj_kv(x~) GEMM over
-    all S*F rows is replaced by u = Wk[h]^T q2 (a per-head GEMM over S rows) + one HBM-bound kernel."""
+class _TrajTime2BlockFn(torch.autograd.Function):
+    """Temporal step of attention.py:536-549 WITHOUT k2 = proj_kv(x~)[..., :C] in HBM (csrc/traj_time2.hip): the logits
+    are scale * (Wk[h]^T q2[s,h,:]) . x~[s,f,:] + const_f, u = Wk[h]^T q2 is formed per 64-channel chunk on chip.
+    Forward = 3 HBM-bound launches over x~; backward = 2 launches + two batched GEMMs over the heads from
+    g = d(loss)/d(u) [B,S,h,C]:  dq2[:, h] = g[:, h, :] . Wk[h]^T ,  dWk[h] = q2[:, h]^T . g[:, h, :].
+    Output: the [B,1+S,C] input of `proj` (row 0 = cls_out), like _TrajTimeBlockFn."""
 
     @staticmethod
-    def forward(ctx, q2, xt, wk, bk, heads):
-        _need_gpu(q2, xt, wk)
+    def forward(ctx, q2, xt, w_kv, b_kv, cls_out, heads):
+        _need_gpu(q2, xt, w_kv)
+        q2, xt = q2.contiguous(), xt.contiguous()
         B, S, F_, C = xt.shape
         d = C // heads
-        q2 = q2.contiguous().view(B * S, C)
-        xt = xt.contiguous()
-        u = torch.empty(B * S, heads, C, device=xt.device, dtype=xt.dtype)
-        if xt.dtype == torch.bfloat16:
-            wkt = shadow(wk, xt.dtype, transposed=True)                  # [C_in, C_out]: K(=dd)-contiguous rows
-            gemm(B * S, C, d, (q2, 0), (C, 1, 0, d), (wkt, 0), (1, C, 0, d), (u, 0), (heads * C, 1, 0, C),
-                 batch=(1, heads))
-        else:
-            w = shadow(wk, xt.dtype)
-            gemm(B * S, C, d, (q2, 0), (C, 1, 0, d), (w, 0), (C, 1, 0, d * C), (u, 0), (heads * C, 1, 0, C),
-                 batch=(1, heads))
-        out = torch.empty(B, S, C, device=xt.device, dtype=xt.dtype)
+        L = _lib.lib()
+        wkT = shadow(w_kv, xt.dtype, transposed=True)                   # [C_in, 2C]: columns :C are Wk^T
+        out = torch.empty(B, S + 1, C, device=xt.device, dtype=xt.dtype)
+        out[:, 0].copy_(cls_out.reshape(B, C))
         attn2 = torch.empty(B, heads, S, F_, device=xt.device, dtype=torch.float32)
-        _lib.check(_lib.lib().focus_traj_time2_fwd(_p(u), _p(xt), _p(out), _p(attn2), B, S, F_, heads, d, _dt(xt),
-                                                   _stream()), "traj_time2_fwd")
-        ctx.save_for_backward(q2, xt, wk, u, attn2)
-        ctx.heads, ctx.has_b = heads, bk is not None
-        ctx.bshape = bk.shape if bk is not None else None
+        nb = L.focus_traj_time2_workspace_bytes(B, S, F_, heads, d)
+        ws = torch.empty(nb // 4, device=xt.device, dtype=torch.float32)
+        _lib.check(L.focus_traj_time2_fwd(_p(q2), _p(xt), _p(wkT), wkT.stride(0), _p(out, C), (S + 1) * C, _p(attn2),
+                                          _p(ws), nb, B, S, F_, heads, d, _dt(xt), _stream()), "traj_time2_fwd")
+        ctx.save_for_backward(q2, xt, attn2, w_kv)
+        ctx.heads, ctx.has_b, ctx.cls_shape = heads, b_kv is not None, cls_out.shape
         return out
 
     @staticmethod
-    def backward(ctx, dout):
-        q2, xt, wk, u, attn2 = ctx.saved_tensors
+    def backward(ctx, dcat):
+        q2, xt, attn2, w_kv = ctx.saved_tensors
         heads = ctx.heads
         B, S, F_, C = xt.shape
         d = C // heads
-        dout = dout.contiguous()
-        du, dxt = torch.empty_like(u), torch.empty_like(xt)
-        _lib.check(_lib.lib().focus_traj_time2_bwd(_p(u), _p(xt), _p(attn2), _p(dout), _p(du), _p(dxt), 0, B, S, F_,
-                                                   heads, d, _dt(xt), _stream()), "traj_time2_bwd")
-        # dq2[:, h*d+dd] = sum_c du[:, h, c] * wk[h*d+dd, c]
-        w = shadow(wk, xt.dtype)
-        dq2 = torch.empty(B * S, C, device=xt.device, dtype=xt.dtype)
-        gemm(B * S, d, C, (du, 0), (heads * C, 1, 0, C), (w, 0), (1, C, 0, d * C), (dq2, 0), (C, 1, 0, d),
-             batch=(1, heads))
-        # dwk[h*d+dd, c] = sum_s q2[s, h*d+dd] * du[s, h, c]   (reduction over the rows of both operands)
-        dwk = torch.zeros(C, C, device=xt.device, dtype=torch.float32)
-        for h in range(heads):
-            gemm(d, C, B * S, (q2, h * d), (1, C, 0, 0), (du, h * C), (heads * C, 1, 0, 0), (dwk, h * d * C),
-                 (C, 1, 0, 0), accumulate=True)
-        dbk = torch.zeros(ctx.bshape, device=xt.device, dtype=torch.float32) if ctx.has_b else None
-        return dq2.view(B, S, C), dxt, dwk, dbk, None
+        dev = xt.device
+        L = _lib.lib()
+        dcat = dcat.contiguous()                 # [B, 1+S, C]: rows 1.. are read in place (batch stride (S+1)*C)
+        wkT = shadow(w_kv, xt.dtype, transposed=True)
+        dxt = torch.empty_like(xt)
+        g = torch.empty(B, S, heads, C, device=dev, dtype=xt.dtype)
+        dl = torch.empty(B, heads, S, F_, device=dev, dtype=torch.float32)
+        _lib.check(L.focus_traj_time2_bwd(_p(q2), _p(xt), _p(wkT), wkT.stride(0), _p(attn2), _p(dcat, C), (S + 1) * C,
+                                          _p(dxt), _p(g), _p(dl), B, S, F_, heads, d, _dt(xt), _stream()), "traj_time2_bwd")
+        R = B * S
+        dq2 = dw = db = None
+        if ctx.needs_input_grad[0]:
+            # dq2[r, h*d+dd] = sum_c g[r,h,c] Wk[h*d+dd, c]   (one launch, batched over the heads)
+            wk = shadow(w_kv, xt.dtype)                                  # [2C, C] row-major: rows :C are Wk
+            dq2 = torch.empty(B, S, C, device=dev, dtype=xt.dtype)
+            gemm(R, d, C, (g, 0), (heads * C, 1, 0, C), (wk, 0), (1, C, 0, d * C), (dq2, 0), (C, 1, 0, d),
+                 batch=(1, heads))
+        if ctx.needs_input_grad[2]:
+            # dWk[h*d+dd, c] = sum_r q2[r, h*d+dd] g[r,h,c]   (batched weight-gradient product; slabs summed once)
+            dw = torch.empty(2 * C, C, device=dev, dtype=torch.float32)
+            nbw = L.focus_gemm_tn_batched_workspace_bytes(d, C, R, heads)
+            wsw = torch.empty(max(nbw, 16) // 4, device=dev, dtype=torch.float32)
+            gemm(d, C, R, (q2, 0), (1, C, 0, d), (g, 0), (heads * C, 1, 0, C), (dw, 0), (C, 1, 0, d * C),
+                 batch=(1, heads), aux=(wsw, 0))
+            dw[C:].zero_()                      # v2 half: no output use, exactly zero gradient
+            if ctx.has_b and ctx.needs_input_grad[3]:
+                db = torch.zeros(2 * C, device=dev, dtype=torch.float32)   # softmax over f is shift invariant: exactly 0
+        dcls = dcat[:, :1].reshape(ctx.cls_shape) if ctx.needs_input_grad[4] else None
+        return dq2, dxt, dw, db, dcls, None
 
 
-import os as _os
-_TIME2 = _os.environ.get("FOCUS_TIME2", "0") == "1"
-
-
-def traj_time2_ok(F_, heads, C):
-    """Opt-in (FOCUS_TIME2=1).  Measured on MI355X at B=8: the re-associated form removes 355 GF of GEMM per block
-    but its per-head GEMMs (K=64 / N=64) and the u/du round trips cost the same ~1.4 ms per block as the k2 path;
-    it pays only once u is formed inside the time kernel (VERDICT follow-up)."""
-    if not _TIME2:
+def traj_time2_ok(xt, heads):
+    """The k2-free temporal step takes bf16, head dim 64, <= 16 heads, F in {4, 8, 16} (FOCUS_TIME2=0 disables it)."""
+    if _os.environ.get("FOCUS_TIME2", "1") == "0" or xt.dtype != torch.bfloat16:
         return False
-    d = C // heads
-    lph = d // 4
-    return F_ == 8 and d % 4 == 0 and lph >= 1 and (lph & (lph - 1)) == 0 and heads <= 16 and C <= 768 and C % 8 == 0
+    B, S, F_, C = xt.shape
+    return C % heads == 0 and C // heads == 64 and heads <= 16 and F_ in (4, 8, 16)
 
 
-def traj_time2(q2, xt, wk, bk, heads):
-    """out [B,S,C] of the temporal step from q2 (un-scaled proj_q output), x~ and the k half of proj_kv."""
-    return _TrajTime2Fn.apply(q2, xt, wk, bk, heads)
+def traj_time2_block(q2, xt, w_kv, b_kv, cls_out, heads):
+    """[B,1+S,C] input of `proj` (row 0 = cls_out) from q2 [B,S,C], x~ [B,S,F,C] and the proj_kv parameters."""
+    return _TrajTime2BlockFn.apply(q2, xt, w_kv, b_kv, cls_out, heads)
 
 
 # --------------------------------------------------------------------------------------------------

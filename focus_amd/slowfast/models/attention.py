@@ -86,19 +86,14 @@ class TrajectoryAttention(nn.Module):
         qkv = ops.linear(x, self.qkv.weight, self.qkv.bias)                       # :506
         xt, xdiag, cls_out = ops.traj_space(qkv, F_, P, h)                         # :509-535
         q2 = ops.linear(xdiag, self.proj_q.weight, self.proj_q.bias)               # :536 (scale applied in-kernel)
-        wk = self.proj_kv.weight[:C]                                               # k2 half only (:537)
-        bk = self.proj_kv.bias[:C] if self.proj_kv.bias is not None else None
-        if ops.traj_time2_ok(F_, h, C):
-            # re-associated: logits = (Wk[h]^T q2) . x~ ; the bias term is constant over frames and cancels in
-            # the softmax -- k2 [B,S,F,C] (the block's largest GEMM) is never formed
-            out = ops.traj_time2(q2, xt, wk, bk, h)
+        # temporal step (:537-549) as one autograd node whose output already is cat(cls_out, out) (the attention rows
+        # are written into tokens 1.. in place).  bf16 / head dim 64: k2 = proj_kv(x~)[:C] is never formed (the logits
+        # are re-associated as (Wk[h]^T q2) . x~, csrc/traj_time2.hip); otherwise k2 GEMM + time kernels.
+        if ops.traj_time2_ok(xt, h):
+            y_in = ops.traj_time2_block(q2, xt, self.proj_kv.weight, self.proj_kv.bias, cls_out, h)
         else:
-            # k2 = proj_kv(x~)[:C] ([B,S,F,C]) + temporal attention as one autograd node (:537-549)
-            # (its output already is cat(cls_out, out): the attention rows are written into tokens 1.. in place)
             y_in = ops.traj_time_block(q2, xt, self.proj_kv.weight, self.proj_kv.bias, cls_out, h)
-            return ops.linear(y_in, self.proj.weight, self.proj.bias, residual=residual), thw_prev
-        y = ops.linear(torch.cat((cls_out, out), dim=1), self.proj.weight, self.proj.bias, residual=residual)
-        return y, thw_prev
+        return ops.linear(y_in, self.proj.weight, self.proj.bias, residual=residual), thw_prev
 
 
 class TrajectoryAttentionBlock(nn.Module):

@@ -88,6 +88,9 @@ int focus_gemm_tile_override(int bm);
  * partials are stored to per-split slabs and summed by a second kernel (no atomics, bitwise reproducible, C is
  * overwritten). */
 size_t focus_gemm_tn_workspace_bytes(int M, int N, int K);
+/* Batched form (desc->batch0 == 1, batch1 = batch independent products whose outputs are stacked densely:
+ * rsC == N, bsC1 == M*N; operands offset by bsA1 / bsB1 per batch): slab mode only, aux of this many bytes. */
+size_t focus_gemm_tn_batched_workspace_bytes(int M, int N, int K, int batch);
 
 /* nn.Linear backward w.r.t. its parameters in one pass over dy (replaces autograd's dy^T @ x and dy.sum(0) of
  * common.py:26-34 / attention.py:506,536-537,555):  dw[N,K] = dy[M,N]^T . x[M,K],  db[N] = sum_m dy[m,:]  (db may be
@@ -158,17 +161,24 @@ int focus_traj_time_bwd(const void* q2, const void* k2, const void* xt, const fl
                         int64_t dout_bstride, void* dq2, void* dk2, void* dxt, int dxt_accumulate, int B, int S, int F,
                         int heads, int d, int dtype, void* stream);
 
-/* Re-associated time step.  With use_original_code=True the temporal logits are
+/* Temporal step WITHOUT k2 = proj_kv(x~)[:, :C] in HBM (attention.py:536-549, use_original_code=True).  The logits are
  *   scale * q2[s,h,:] . (Wk[h] x~[s,f,:] + bk[h])  =  scale * (Wk[h]^T q2[s,h,:]) . x~[s,f,:]  + (a term constant in f),
- * and the softmax over f is shift invariant, so k2 = proj_kv(x~) (the largest GEMM of the block, 8x the tokens) is
- * never formed: u [B,S,h,C] = Wk[h]^T q2[s,h,:] comes from a small per-head GEMM and these kernels read x~ once.
- * Same outputs and gradients as focus_traj_time_* up to rounding order (proj_kv.bias gets its exact zero gradient).
- *   fwd: u, xt -> out [B,S,C], attn2 [B,h,S,F] fp32.
- *   bwd: dxt [B,S,F,C] (written, or accumulated onto when dxt_accum), du [B,S,h,C]. */
-int focus_traj_time2_fwd(const void* u, const void* xt, void* out, float* attn2, int B, int S, int F, int heads,
-                         int d, int dtype, void* stream);
-int focus_traj_time2_bwd(const void* u, const void* xt, const float* attn2, const void* dout, void* du, void* dxt,
-                         int dxt_accum, int B, int S, int F, int heads, int d, int dtype, void* stream);
+ * and the softmax over f is shift invariant, so k2 [B,S,F,C] (the block's largest GEMM: 8x the tokens) and dk2 are
+ * never formed; u[s,h,:] = Wk[h]^T q2[s,h,:] is produced per 64-channel chunk on chip (csrc/traj_time2.hip).
+ * bf16, head dim 64, heads <= 16, F in {4, 8, 16}.  wkT: [C rows (input channel c)][ldw] bf16 whose columns 0..C-1 hold
+ * Wk^T (the transposed shadow of proj_kv.weight).  q2 [B,S,C] is the UN-scaled proj_q output.
+ *   fwd: out rows [B,S,C] at batch stride out_bstride (see focus_traj_time_fwd); attn2 [B,h,S,F] fp32 (saved);
+ *        ws: focus_traj_time2_workspace_bytes() bytes of scratch.
+ *   bwd: dxt [B,S,F,C] (fully written: a*dout + sum_h dl*u); g [B,S,h,C] bf16 = d(loss)/d(u), from which the caller
+ *        forms  dq2[:, h*64+dd] = sum_c g[:,h,c] Wk[h*64+dd, c]  and  dWk[h*64+dd, c] = sum_s q2[s,h*64+dd] g[s,h,c]
+ *        (two batched GEMMs over the heads); dl [B,h,S,F] fp32 scratch.  proj_kv.bias gets its exact zero gradient. */
+size_t focus_traj_time2_workspace_bytes(int B, int S, int F, int heads, int d);
+int focus_traj_time2_fwd(const void* q2, const void* xt, const void* wkT, int64_t ldw, void* out, int64_t out_bstride,
+                         float* attn2, void* ws, size_t ws_bytes, int B, int S, int F, int heads, int d, int dtype,
+                         void* stream);
+int focus_traj_time2_bwd(const void* q2, const void* xt, const void* wkT, int64_t ldw, const float* attn2,
+                         const void* dout, int64_t dout_bstride, void* dxt, void* g, float* dl, int B, int S, int F,
+                         int heads, int d, int dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * RoIAlign over patch-token feature maps (ORViT/utils.py:58-75 -> torchvision.ops.roi_align with

@@ -274,3 +274,48 @@ def test_slot_attention_kernels_tight():
     ck.tight(kg.grad, kr.grad, "slot dk (slot_bwd)", rtol=RT, mag=mag_k)
     ck.tight(qg.grad, qr.grad, "slot dq (slot_bwd)", rtol=RT, mag=mag_q)
     ck.done()
+
+
+@pytest.mark.parametrize("F_,heads,S", [(8, 12, 1568), (4, 2, 100), (16, 3, 50)])
+def test_time2_kernels_tight(F_, heads, S):
+    """The k2-free temporal step (time2_logits / softmax / out, time2_dl / bwd + the two batched GEMMs over g):
+    out, d(q2), d(x~), d(Wk) and the exact zeros of the dead proj_kv parts, against fp64 on the same bf16 values."""
+    from focus_amd import ops
+    B, dh = 2, 64
+    C = heads * dh
+    d = dev()
+    g = torch.Generator().manual_seed(100 * F_ + heads)
+    q2 = bf(torch.randn(B, S, C, generator=g))
+    xt = bf(torch.randn(B, S, F_, C, generator=g))
+    wkv = torch.randn(2 * C, C, generator=g) * C ** -0.5
+    bkv = torch.randn(2 * C, generator=g)
+    cls = bf(torch.randn(B, 1, C, generator=g))
+    ct = bf(torch.randn(B, S + 1, C, generator=g))
+    # fp64 reference of attention.py:537-549 on the bf16-rounded weights (what the kernels read)
+    Q, X, CL = (t.double().requires_grad_() for t in (q2, xt, cls))
+    W = bf(wkv).double().requires_grad_()
+    Bk = bkv.double().requires_grad_()
+    k2 = (X @ W[:C].t() + Bk[:C]).reshape(B, S, F_, heads, dh)
+    qh = Q.reshape(B, S, heads, dh) * dh ** -0.5
+    A = torch.softmax(torch.einsum("bshd,bsfhd->bshf", qh, k2), dim=-1)
+    out_r = torch.cat([CL, torch.einsum("bshf,bsfhd->bshd", A, X.reshape(B, S, F_, heads, dh)).reshape(B, S, C)], 1)
+    (out_r * ct.double()).sum().backward()
+    qg, xg, cg = (t.to(d).requires_grad_() for t in (q2, xt, cls))
+    wg, bg = wkv.to(d).requires_grad_(), bkv.to(d).requires_grad_()
+    assert ops.traj_time2_ok(xg, heads)
+    out = ops.traj_time2_block(qg, xg, wg, bg, cg, heads)
+    (out.float() * ct.to(d).float()).sum().backward()
+    ck = Check()
+    with torch.no_grad():      # scale of the rounding error of u (bf16) inside the logits: sum_c |u||x~| per (s,f,h) -> via A
+        mag_out = torch.cat([CL.abs(), torch.einsum("bshf,bsfhd->bshd", A, X.abs().reshape(B, S, F_, heads, dh)).reshape(B, S, C)], 1)
+    # u = Wk[h]^T q2 is rounded to bf16 before the logit product (as k2 was): the attention weights move by ~u*|logit
+    # terms|, so the limits are a few unit roundoffs of the summed magnitudes
+    ck.tight(out, out_r, "out (time2 logits/softmax/out)", rtol=4 * U, mag=mag_out)
+    ck.tight(cg.grad, CL.grad, "d cls_out", rtol=1.01 * U)
+    gq, gx, gw = Q.grad, X.grad, W.grad
+    ck.tight(qg.grad, gq, "d q2 (g . Wk^T, batched GEMM)", rtol=8 * U, floor=2e-2)
+    ck.tight(xg.grad, gx, "d x~ (time2_bwd)", rtol=8 * U, floor=2e-2)
+    ck.tight(wg.grad[:C], gw[:C], "d Wk (q2^T . g, batched TN GEMM)", rtol=8 * U, floor=2e-2)
+    ck.done()
+    assert float(wg.grad[C:].abs().max()) == 0.0 and float(bg.grad.abs().max()) == 0.0      # dead v2 half, shift-invariant bias
+    assert float(Bk.grad[:C].abs().max()) < 1e-9 * float(gw.abs().max()) + 1e-12           # (the reference agrees: ~0)
