@@ -300,22 +300,37 @@ def test_time2_kernels_tight(F_, heads, S):
     A = torch.softmax(torch.einsum("bshd,bsfhd->bshf", qh, k2), dim=-1)
     out_r = torch.cat([CL, torch.einsum("bshf,bsfhd->bshd", A, X.reshape(B, S, F_, heads, dh)).reshape(B, S, C)], 1)
     (out_r * ct.double()).sum().backward()
-    qg, xg, cg = (t.to(d).requires_grad_() for t in (q2, xt, cls))
-    wg, bg = wkv.to(d).requires_grad_(), bkv.to(d).requires_grad_()
-    assert ops.traj_time2_ok(xg, heads)
-    out = ops.traj_time2_block(qg, xg, wg, bg, cg, heads)
-    (out.float() * ct.to(d).float()).sum().backward()
-    ck = Check()
+    def run(fn):
+        qg, xg, cg = (t.to(d).requires_grad_() for t in (q2, xt, cls))
+        wg, bg = wkv.to(d).requires_grad_(), bkv.to(d).requires_grad_()
+        out = fn(qg, xg, wg, bg, cg, heads)
+        (out.float() * ct.to(d).float()).sum().backward()
+        return out, qg.grad, xg.grad, wg.grad, bg.grad, cg.grad
+
+    def l2(a, b):
+        a, b = a.detach().double().cpu(), b.detach().double().cpu()
+        return float((a - b).norm() / b.norm())
+    assert ops.traj_time2_ok(xt.to(d), heads)
+    out, dq, dx, dw, db, dc = run(ops.traj_time2_block)
+    out0, dq0, dx0, dw0, db0, dc0 = run(ops.traj_time_block)       # the k2 path (k2 and dk2 rounded to bf16 in HBM)
+    gq, gx, gw = Q.grad, X.grad, W.grad
     with torch.no_grad():      # scale of the rounding error of u (bf16) inside the logits: sum_c |u||x~| per (s,f,h) -> via A
         mag_out = torch.cat([CL.abs(), torch.einsum("bshf,bsfhd->bshd", A, X.abs().reshape(B, S, F_, heads, dh)).reshape(B, S, C)], 1)
-    # u = Wk[h]^T q2 is rounded to bf16 before the logit product (as k2 was): the attention weights move by ~u*|logit
-    # terms|, so the limits are a few unit roundoffs of the summed magnitudes
+    ck = Check()
+    # u = Wk[h]^T q2 is rounded to bf16 before the logit product (the k2 path rounds k2 instead): the logits carry
+    # ~u * |their terms| of error either way, which the softmax backward (a (da - sum a da): a cancellation) amplifies.
+    # So the gradients are held (a) to an L2-relative error of 1e-2 and (b) to the k2 path's own error on the same
+    # inputs -- the re-association must not be less accurate than what it replaces.
     ck.tight(out, out_r, "out (time2 logits/softmax/out)", rtol=4 * U, mag=mag_out)
-    ck.tight(cg.grad, CL.grad, "d cls_out", rtol=1.01 * U)
-    gq, gx, gw = Q.grad, X.grad, W.grad
-    ck.tight(qg.grad, gq, "d q2 (g . Wk^T, batched GEMM)", rtol=8 * U, floor=2e-2)
-    ck.tight(xg.grad, gx, "d x~ (time2_bwd)", rtol=8 * U, floor=2e-2)
-    ck.tight(wg.grad[:C], gw[:C], "d Wk (q2^T . g, batched TN GEMM)", rtol=8 * U, floor=2e-2)
+    ck.tight(dc, CL.grad, "d cls_out", rtol=1.01 * U)
+    rows = []
+    for name, new, old, ref in (("d q2", dq, dq0, gq), ("d x~", dx, dx0, gx), ("d Wk", dw[:C], dw0[:C], gw[:C]),
+                                ("out", out, out0, out_r)):
+        e_new, e_old = l2(new, ref), l2(old, ref)
+        rows.append("%-6s L2 rel err: k2-free %.3e   k2 path %.3e" % (name, e_new, e_old))
+        ck.rows.append(rows[-1])
+        if not (e_new < 1e-2 and e_new < 1.5 * e_old + 1e-3):
+            ck.bad.append(rows[-1])
     ck.done()
-    assert float(wg.grad[C:].abs().max()) == 0.0 and float(bg.grad.abs().max()) == 0.0      # dead v2 half, shift-invariant bias
-    assert float(Bk.grad[:C].abs().max()) < 1e-9 * float(gw.abs().max()) + 1e-12           # (the reference agrees: ~0)
+    assert float(dw[C:].abs().max()) == 0.0 and float(db.abs().max()) == 0.0      # dead v2 half, shift-invariant bias
+    assert float(Bk.grad[:C].abs().max()) < 1e-9 * float(gw.abs().max()) + 1e-12   # (the reference agrees: ~0)
