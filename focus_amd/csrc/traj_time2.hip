@@ -75,24 +75,38 @@ __device__ __forceinline__ void load_w_slice(char* sW, const bf16_t* wkT, int64_
     }
 }
 
-// U[s][h][c] of one 16-query tile for the heads of this wave (h = w, w + 4, ...): U^T = WkT_slice . q2^T per head.
-__device__ __forceinline__ void compute_u_tile(const char* sW, char* sU, const bf16_t* __restrict__ q2, int64_t row0,
-                                               int64_t rows_total, int C, int heads, int w, int lane) {
-    const int wrow = wrow_bytes(C), urow = urow_bytes(heads);
+constexpr int HPW = MAXH / 4;           // heads per wave (h = w, w + 4, ...)
+
+// q2 fragments (MFMA B operand: column = query, k = dd) of this wave's heads for the tile starting at row0
+struct QFrag { bf16x8 v[HPW][2]; };
+__device__ __forceinline__ void load_q_frags(QFrag& q, const bf16_t* __restrict__ q2, int64_t row0, int64_t rows_total,
+                                             int C, int heads, int w, int lane) {
     const int col = lane & 15, kg = lane >> 4;
     const int64_t qrow = min(row0 + col, rows_total - 1);        // this lane's query (MFMA column), clamped
-    for (int h = w; h < heads; h += 4) {
-        bf16x8 qb[2];
+#pragma unroll
+    for (int i = 0; i < HPW; ++i) {
+        const int h = min(w + 4 * i, heads - 1);
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
-            qb[ks] = *reinterpret_cast<const bf16x8*>(q2 + qrow * C + h * CH + 32 * ks + 8 * kg);
+            q.v[i][ks] = *reinterpret_cast<const bf16x8*>(q2 + qrow * C + h * CH + 32 * ks + 8 * kg);
+    }
+}
+
+// U[s][h][c] of one 16-query tile for the heads of this wave (h = w, w + 4, ...): U^T = WkT_slice . q2^T per head.
+__device__ __forceinline__ void compute_u_tile(const char* sW, char* sU, const QFrag& q, int C, int heads, int w, int lane) {
+    const int wrow = wrow_bytes(C), urow = urow_bytes(heads);
+    const int col = lane & 15, kg = lane >> 4;
+#pragma unroll
+    for (int i = 0; i < HPW; ++i) {
+        const int h = w + 4 * i;
+        if (h >= heads) break;
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) {
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
                 const bf16x8 a = *reinterpret_cast<const bf16x8*>(sW + (16 * mt + col) * wrow + (h * CH + 32 * ks + 8 * kg) * 2);
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, qb[ks], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, q.v[i][ks], acc, 0, 0, 0);
             }
             // acc[r] = U^T[c = 16 mt + 4 kg + r][s = col]
             Pk4 p;
@@ -124,18 +138,27 @@ __global__ __launch_bounds__(256) void time2_logits_kernel(const bf16_t* __restr
     const int fl = col < F ? col : F - 1;                         // frame of this lane's A row (rows >= F: duplicates)
     const int hl = col < heads ? col : heads - 1;                 // head of this lane's B column (cols >= heads: dup.)
     const int64_t slab_chunk = (int64_t)cc * rows * heads * F;    // slab[cc][b][h][s][f] = [cc][(b*heads+h)*S + s][f]
-    for (int64_t t = t_begin; t < t_end; ++t) {
-        const int64_t row0 = t * TQ;
-        // x~ fragments of this wave's 4 queries first: their HBM latency runs under the U product below
-        bf16x8 xa[4][2];
+    // All global operands of a tile (x~ fragments of this wave's 4 queries, q2 fragments of its heads) are loaded one
+    // tile AHEAD: with one workgroup per CU (the weight slice fills most of the LDS) nothing else hides HBM latency.
+    struct XFrag { bf16x8 v[4][2]; };
+    auto load_x = [&](XFrag& x, int64_t row0) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int64_t row = min(row0 + 4 * w + i, rows - 1);
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks)
-                xa[i][ks] = *reinterpret_cast<const bf16x8*>(xt + (row * F + fl) * C + cc * CH + 32 * ks + 8 * kg);
+                x.v[i][ks] = *reinterpret_cast<const bf16x8*>(xt + (row * F + fl) * C + cc * CH + 32 * ks + 8 * kg);
         }
-        compute_u_tile(sW, sU, q2, row0, rows, C, heads, w, lane);
+    };
+    XFrag xn;
+    QFrag qn;
+    if (t_begin < t_end) { load_x(xn, t_begin * TQ); load_q_frags(qn, q2, t_begin * TQ, rows, C, heads, w, lane); }
+    for (int64_t t = t_begin; t < t_end; ++t) {
+        const int64_t row0 = t * TQ;
+        const XFrag xa = xn;
+        const QFrag qa = qn;
+        if (t + 1 < t_end) { load_x(xn, row0 + TQ); load_q_frags(qn, q2, row0 + TQ, rows, C, heads, w, lane); }
+        compute_u_tile(sW, sU, qa, C, heads, w, lane);
         __syncthreads();
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -145,7 +168,7 @@ __global__ __launch_bounds__(256) void time2_logits_kernel(const bf16_t* __restr
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
                 const bf16x8 ub = *reinterpret_cast<const bf16x8*>(sU + sq * urow + hl * (CH * 2) + (32 * ks + 8 * kg) * 2);
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xa[i][ks], ub, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xa.v[i][ks], ub, acc, 0, 0, 0);
             }
             // acc[r] = L[f = 4 kg + r][h = col]
             if (row < rows && col < heads) {
@@ -169,6 +192,7 @@ __global__ __launch_bounds__(256) void time2_softmax_kernel(const float* __restr
     float lg[MAXF];
 #pragma unroll
     for (int f = 0; f < MAXF; ++f) lg[f] = 0.f;
+#pragma unroll 4
     for (int c = 0; c < nchunk; ++c) {
         const float* p = slab + ((int64_t)c * n + i) * F;
 #pragma unroll
@@ -219,7 +243,7 @@ __global__ __launch_bounds__(256) void time2_out_kernel(const bf16_t* __restrict
     if (act) *reinterpret_cast<uint4*>(out + b * obs + (int64_t)s * C + cg * 8) = pack8(o);
 }
 
-// backward 1/2: dl[b,h,s,f] = scale * a (da - sum_f a da),  da = dout[s,h,:] . x~[s,f,h,:]
+// backward 1/2: dl[b,s,f,h] (h padded to 16) = scale * a (da - sum_f a da),  da = dout[s,h,:] . x~[s,f,h,:]
 template <int FT>
 __global__ __launch_bounds__(256) void time2_dl_kernel(const bf16_t* __restrict__ xt, const float* __restrict__ attn2,
                                                        const bf16_t* __restrict__ dout, int64_t dobs, float* __restrict__ dl,
@@ -252,8 +276,9 @@ __global__ __launch_bounds__(256) void time2_dl_kernel(const bf16_t* __restrict_
         dot = fmaf(a[f], da[f], dot);
     }
     if (act && (cg & 7) == 0) {
+        // [row][f][16]: a (query, frame)'s heads are contiguous -- what the dx~ / g tasks of time2_bwd_kernel read
 #pragma unroll
-        for (int f = 0; f < FT; ++f) dl[o + f] = scale * a[f] * (da[f] - dot);
+        for (int f = 0; f < FT; ++f) dl[(row * FT + f) * MAXH + (cg >> 3)] = scale * a[f] * (da[f] - dot);
     }
 }
 
@@ -267,6 +292,8 @@ __global__ __launch_bounds__(256) void time2_bwd_kernel(const bf16_t* __restrict
                                                         const bf16_t* __restrict__ dout, int64_t dobs,
                                                         bf16_t* __restrict__ dxt, bf16_t* __restrict__ gout, int64_t rows,
                                                         int S, int heads) {
+    constexpr int NTASK = FT / 2;          // dx~ tasks (query, frame, 8 channels) per thread: 16 * FT * 8 / 256
+    constexpr int NDL = FT / 4;            // 16-byte pieces of the tile's dl block per thread: 16 * FT * 16 * 4 / 16 / 256
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int C = heads * CH, cc = blockIdx.x, nranges = gridDim.y;
     char* sW = smem;
@@ -279,42 +306,58 @@ __global__ __launch_bounds__(256) void time2_bwd_kernel(const bf16_t* __restrict
     const int64_t t_begin = ntiles * blockIdx.y / nranges, t_end = ntiles * (blockIdx.y + 1) / nranges;
     load_w_slice(sW, wkT, ldw, cc, C);
     __syncthreads();
-    // g task of this thread: query sg = tid >> 4, channel group c8 = (tid >> 1) & 7, head half hh = tid & 1
+    // g task of this thread: query sg = tid >> 4, channel group c8g = (tid >> 1) & 7, head half hh = tid & 1
     const int sg = tid >> 4, c8g = (tid >> 1) & 7, hh = tid & 1;
     const int hper = (heads + 1) / 2;
+    // dx~ tasks: e = tid + 256 i -> 8-channel group e & 7, (query, frame) = e >> 3
+    const int c8 = tid & 7;
+
+    // every global operand of a tile is loaded one tile ahead (one workgroup per CU: nothing else hides the latency)
+    struct In { uint4 xr[FT]; uint4 dv[NTASK]; uint4 dlp[NDL]; float a; QFrag q; };
+    auto load_in = [&](In& in, int64_t row0) __attribute__((always_inline)) {
+        const int64_t grow = min(row0 + sg, rows - 1);
+#pragma unroll
+        for (int f = 0; f < FT; ++f) in.xr[f] = *reinterpret_cast<const uint4*>(xt + (grow * FT + f) * C + cc * CH + c8g * 8);
+#pragma unroll
+        for (int i = 0; i < NTASK; ++i) {
+            const int sq = ((tid + 256 * i) >> 3) / FT;
+            const int64_t row = min(row0 + sq, rows - 1);
+            const int64_t b = row / S;
+            in.dv[i] = *reinterpret_cast<const uint4*>(dout + b * dobs + (row - b * S) * C + cc * CH + c8 * 8);
+        }
+        const int64_t npieces = (min(row0 + TQ, rows) - row0) * FT * (MAXH / 4);    // valid 16-byte pieces of the block
+#pragma unroll
+        for (int j = 0; j < NDL; ++j) {
+            const int64_t pc = min((int64_t)(tid + 256 * j), npieces - 1);
+            in.dlp[j] = *reinterpret_cast<const uint4*>(dl + row0 * FT * MAXH + pc * 4);
+        }
+        in.a = 0.f;
+        if (tid < TQ * FT) {
+            const int64_t row = min(row0 + tid / FT, rows - 1);
+            const int64_t b = row / S;
+            in.a = attn2[((b * heads + cc) * S + (row - b * S)) * FT + tid % FT];
+        }
+        load_q_frags(in.q, q2, row0, rows, C, heads, w, lane);
+    };
+    In nx;
+    if (t_begin < t_end) load_in(nx, t_begin * TQ);
     for (int64_t t = t_begin; t < t_end; ++t) {
         const int64_t row0 = t * TQ;
-        // x~ rows of the g task (8 frames x 16 B), issued first
-        const int64_t grow = min(row0 + sg, rows - 1);
-        uint4 xr[FT];
-#pragma unroll
-        for (int f = 0; f < FT; ++f) xr[f] = *reinterpret_cast<const uint4*>(xt + (grow * FT + f) * C + cc * CH + c8g * 8);
+        const In in = nx;
+        if (t + 1 < t_end) load_in(nx, row0 + TQ);
         // dl / a of the tile -> LDS
-        for (int e = tid; e < TQ * FT * heads; e += 256) {
-            const int h = e % heads, sf = e / heads, f = sf % FT, sq = sf / FT;
-            const int64_t row = min(row0 + sq, rows - 1);
-            const int64_t b = row / S;
-            const int s = (int)(row - b * S);
-            sDL[(sq * FT + f) * MAXH + h] = dl[((b * heads + h) * S + s) * FT + f];
-        }
-        for (int e = tid; e < TQ * FT; e += 256) {
-            const int f = e % FT, sq = e / FT;
-            const int64_t row = min(row0 + sq, rows - 1);
-            const int64_t b = row / S;
-            const int s = (int)(row - b * S);
-            sA[e] = attn2[((b * heads + cc) * S + s) * FT + f];
-        }
-        compute_u_tile(sW, sU, q2, row0, rows, C, heads, w, lane);
+#pragma unroll
+        for (int j = 0; j < NDL; ++j) reinterpret_cast<uint4*>(sDL)[tid + 256 * j] = in.dlp[j];
+        if (tid < TQ * FT) sA[tid] = in.a;
+        compute_u_tile(sW, sU, in.q, C, heads, w, lane);
         __syncthreads();
         // ---- dx~[s,f,c] = a[s,f,cc] dout[s,c] + sum_h dl[s,f,h] U[s,h,c] : task = (s, f, 8 channels) ----
-        for (int e = tid; e < TQ * FT * 8; e += 256) {
-            const int c8 = e & 7, f = (e >> 3) % FT, sq = (e >> 3) / FT;
+#pragma unroll
+        for (int i = 0; i < NTASK; ++i) {
+            const int sf = (tid + 256 * i) >> 3, f = sf % FT, sq = sf / FT;
             const int64_t row = row0 + sq;
-            if (row >= rows) continue;
-            const int64_t b = row / S;
-            const int s = (int)(row - b * S);
             float dv[8], v[8];
-            unpack8(*reinterpret_cast<const uint4*>(dout + b * dobs + (int64_t)s * C + cc * CH + c8 * 8), dv);
+            unpack8(in.dv[i], dv);
             const float a = sA[sq * FT + f];
 #pragma unroll
             for (int k = 0; k < 8; ++k) v[k] = a * dv[k];
@@ -326,13 +369,13 @@ __global__ __launch_bounds__(256) void time2_bwd_kernel(const bf16_t* __restrict
 #pragma unroll
                 for (int k = 0; k < 8; ++k) v[k] = fmaf(d, uv[k], v[k]);
             }
-            *reinterpret_cast<uint4*>(dxt + (row * FT + f) * C + cc * CH + c8 * 8) = pack8(v);
+            if (row < rows) *reinterpret_cast<uint4*>(dxt + (row * FT + f) * C + cc * CH + c8 * 8) = pack8(v);
         }
         // ---- g[s,h,c] = sum_f dl[s,f,h] x~[s,f,c] : this thread's (s, 8 channels) for its half of the heads ----
         {
             float xv[FT][8];
 #pragma unroll
-            for (int f = 0; f < FT; ++f) unpack8(xr[f], xv[f]);
+            for (int f = 0; f < FT; ++f) unpack8(in.xr[f], xv[f]);
             const int64_t row = row0 + sg;
             for (int hi = 0; hi < hper; ++hi) {
                 const int h = hh * hper + hi;

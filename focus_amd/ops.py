@@ -805,7 +805,7 @@ class _TrajTime2BlockFn(torch.autograd.Function):
         wkT = shadow(w_kv, xt.dtype, transposed=True)
         dxt = torch.empty_like(xt)
         g = torch.empty(B, S, heads, C, device=dev, dtype=xt.dtype)
-        dl = torch.empty(B, heads, S, F_, device=dev, dtype=torch.float32)
+        dl = torch.empty(B, S, F_, 16, device=dev, dtype=torch.float32)      # [.., h padded to 16]
         _lib.check(L.focus_traj_time2_bwd(_p(q2), _p(xt), _p(wkT), wkT.stride(0), _p(attn2), _p(dcat, C), (S + 1) * C,
                                           _p(dxt), _p(g), _p(dl), B, S, F_, heads, d, _dt(xt), _stream()), "traj_time2_bwd")
         R = B * S

@@ -171,7 +171,7 @@ int focus_traj_time_bwd(const void* q2, const void* k2, const void* xt, const fl
  *        ws: focus_traj_time2_workspace_bytes() bytes of scratch.
  *   bwd: dxt [B,S,F,C] (fully written: a*dout + sum_h dl*u); g [B,S,h,C] bf16 = d(loss)/d(u), from which the caller
  *        forms  dq2[:, h*64+dd] = sum_c g[:,h,c] Wk[h*64+dd, c]  and  dWk[h*64+dd, c] = sum_s q2[s,h*64+dd] g[s,h,c]
- *        (two batched GEMMs over the heads); dl [B,h,S,F] fp32 scratch.  proj_kv.bias gets its exact zero gradient. */
+ *        (two batched GEMMs over the heads); dl [B,S,F,16] fp32 scratch.  proj_kv.bias gets its exact zero gradient. */
 size_t focus_traj_time2_workspace_bytes(int B, int S, int F, int heads, int d);
 int focus_traj_time2_fwd(const void* q2, const void* xt, const void* wkT, int64_t ldw, void* out, int64_t out_bstride,
                          float* attn2, void* ws, size_t ws_bytes, int B, int S, int F, int heads, int d, int dtype,
