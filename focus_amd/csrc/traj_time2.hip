@@ -150,14 +150,23 @@ __global__ __launch_bounds__(256) void time2_logits_kernel(const bf16_t* __restr
                 x.v[i][ks] = *reinterpret_cast<const bf16x8*>(xt + (row * F + fl) * C + cc * CH + 32 * ks + 8 * kg);
         }
     };
-    XFrag xn;
-    QFrag qn;
-    if (t_begin < t_end) { load_x(xn, t_begin * TQ); load_q_frags(qn, q2, t_begin * TQ, rows, C, heads, w, lane); }
-    for (int64_t t = t_begin; t < t_end; ++t) {
+    // register ring of DEPTH tiles: ~16 KB of x~ per tile and CU, HBM latency of 2-4 us under load -> several tiles
+    // must be in flight to reach the CU's share of the HBM rate
+    constexpr int DEPTH = 4;
+    XFrag xr[DEPTH];
+    QFrag qr[DEPTH];
+#pragma unroll
+    for (int k = 0; k < DEPTH; ++k)
+        if (t_begin + k < t_end) { load_x(xr[k], (t_begin + k) * TQ); load_q_frags(qr[k], q2, (t_begin + k) * TQ, rows, C, heads, w, lane); }
+    for (int64_t tb = t_begin; tb < t_end; tb += DEPTH) {
+#pragma unroll
+      for (int k = 0; k < DEPTH; ++k) {
+        const int64_t t = tb + k;
+        if (t >= t_end) break;
         const int64_t row0 = t * TQ;
-        const XFrag xa = xn;
-        const QFrag qa = qn;
-        if (t + 1 < t_end) { load_x(xn, row0 + TQ); load_q_frags(qn, q2, row0 + TQ, rows, C, heads, w, lane); }
+        const XFrag xa = xr[k];
+        const QFrag qa = qr[k];
+        if (t + DEPTH < t_end) { load_x(xr[k], row0 + DEPTH * TQ); load_q_frags(qr[k], q2, row0 + DEPTH * TQ, rows, C, heads, w, lane); }
         compute_u_tile(sW, sU, qa, C, heads, w, lane);
         __syncthreads();
 #pragma unroll
@@ -181,6 +190,7 @@ __global__ __launch_bounds__(256) void time2_logits_kernel(const bf16_t* __restr
             }
         }
         __syncthreads();                                           // U tile is free for the next tile
+      }
     }
 }
 
@@ -339,12 +349,19 @@ __global__ __launch_bounds__(256) void time2_bwd_kernel(const bf16_t* __restrict
         }
         load_q_frags(in.q, q2, row0, rows, C, heads, w, lane);
     };
-    In nx;
-    if (t_begin < t_end) load_in(nx, t_begin * TQ);
-    for (int64_t t = t_begin; t < t_end; ++t) {
+    constexpr int DEPTH = FT <= 8 ? 3 : 1;      // register ring of tiles in flight (see time2_logits_kernel)
+    In ring[DEPTH];
+#pragma unroll
+    for (int k = 0; k < DEPTH; ++k)
+        if (t_begin + k < t_end) load_in(ring[k], (t_begin + k) * TQ);
+    for (int64_t tb = t_begin; tb < t_end; tb += DEPTH) {
+#pragma unroll
+      for (int k = 0; k < DEPTH; ++k) {
+        const int64_t t = tb + k;
+        if (t >= t_end) break;
         const int64_t row0 = t * TQ;
-        const In in = nx;
-        if (t + 1 < t_end) load_in(nx, row0 + TQ);
+        const In in = ring[k];
+        if (t + DEPTH < t_end) load_in(ring[k], row0 + DEPTH * TQ);
         // dl / a of the tile -> LDS
 #pragma unroll
         for (int j = 0; j < NDL; ++j) reinterpret_cast<uint4*>(sDL)[tid + 256 * j] = in.dlp[j];
@@ -392,6 +409,7 @@ __global__ __launch_bounds__(256) void time2_bwd_kernel(const bf16_t* __restrict
             }
         }
         __syncthreads();                                           // U / dl tiles are free for the next tile
+      }
     }
 }
 
