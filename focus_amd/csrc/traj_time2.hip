@@ -15,8 +15,8 @@
 //   forward  (time2_logits_kernel):
 //     L[f, h]    += sum_c x~[s,f,c] U[s,h,c]   per query s            MFMA 16x16x32, M = frames, N = heads, K = 64;
 //                   the A operand is read from x~ in HBM directly (16 B per lane, 128-B row segments); partial
-//                   logits of the chunk go to slab[cc][b,h,s,f]; time2_softmax_kernel sums the C/64 slabs and takes
-//                   the softmax over f; time2_out_kernel forms out = sum_f a x~ (reads x~ once more).
+//                   logits of the chunk go to slab[cc][row][h][f]; time2_softmax_kernel sums the C/64 slabs and takes
+//                   the softmax over f (attn2 [B,S,h,F]); time2_out_kernel forms out = sum_f a x~ (reads x~ once more).
 //   backward (time2_dl_kernel, then time2_bwd_kernel):
 //     dl[s,f,h]   = scale a (da - sum_f a da),  da[s,f,h] = dout[s,h,:] . x~[s,f,h,:]
 //     dx~[s,f,c]  = a[s,f,h(c)] dout[s,c] + sum_h dl[s,f,h] U[s,h,c]                      (VALU, U from LDS)
@@ -37,8 +37,9 @@ constexpr int CH = 64;                 // channels per chunk (= head dim: chunk 
 constexpr int TQ = 16;                 // queries per tile (MFMA N)
 constexpr int MAXH = 16;               // heads <= 16 (MFMA N of the logit product)
 constexpr int MAXF = 16;               // frames <= 16 (MFMA M of the logit product)
+constexpr int NGRP = 2;                // wave groups (4 waves each) per workgroup, each streaming its own tiles
+constexpr int HPW = MAXH / 4;          // heads per wave (h = w, w + 4, ...)
 
-union Pk8 { uint4 u; bf16_t e[8]; bf16x8 v; };
 union Pk4 { uint2 u; bf16_t e[4]; };
 
 __device__ __forceinline__ void unpack8(const uint4& r, float* v) {
@@ -62,8 +63,8 @@ __device__ __forceinline__ float sum8lanes(float v) {
 
 // LDS images.  Row pitches are the data bytes + 16: 16 lanes that read the same 16-byte column of 16 consecutive rows
 // (the MFMA row fragments) then fall on 16 different 16-byte slots of the 256-byte bank row.
-__device__ __forceinline__ int wrow_bytes(int C) { return C * 2 + 16; }            // Wk^T slice: [64 c][C (h,dd)]
-__device__ __forceinline__ int urow_bytes(int heads) { return heads * CH * 2 + 16; }   // U: [16 s][heads][64 c]
+__host__ __device__ __forceinline__ int wrow_bytes(int C) { return C * 2 + 16; }              // Wk^T slice: [64 c][C (h,dd)]
+__host__ __device__ __forceinline__ int urow_bytes(int heads) { return heads * CH * 2 + 16; } // U: [16 s][heads][64 c]
 
 // Wk^T slice of this chunk -> LDS (once per workgroup; register staged: the padded rows rule out LDS-DMA)
 __device__ __forceinline__ void load_w_slice(char* sW, const bf16_t* wkT, int64_t ldw, int cc, int C) {
@@ -75,30 +76,28 @@ __device__ __forceinline__ void load_w_slice(char* sW, const bf16_t* wkT, int64_
     }
 }
 
-constexpr int HPW = MAXH / 4;           // heads per wave (h = w, w + 4, ...)
-
 // q2 fragments (MFMA B operand: column = query, k = dd) of this wave's heads for the tile starting at row0
 struct QFrag { bf16x8 v[HPW][2]; };
-__device__ __forceinline__ void load_q_frags(QFrag& q, const bf16_t* __restrict__ q2, int64_t row0, int64_t rows_total,
-                                             int C, int heads, int w, int lane) {
+__device__ __forceinline__ void load_q_frags(QFrag& q, const bf16_t* __restrict__ q2, int row0, int rows, int C, int heads,
+                                             int wg, int lane) {
     const int col = lane & 15, kg = lane >> 4;
-    const int64_t qrow = min(row0 + col, rows_total - 1);        // this lane's query (MFMA column), clamped
+    const int64_t qoff = (int64_t)min(row0 + col, rows - 1) * C;  // this lane's query (MFMA column), clamped
 #pragma unroll
     for (int i = 0; i < HPW; ++i) {
-        const int h = min(w + 4 * i, heads - 1);
+        const int h = min(wg + 4 * i, heads - 1);
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
-            q.v[i][ks] = *reinterpret_cast<const bf16x8*>(q2 + qrow * C + h * CH + 32 * ks + 8 * kg);
+            q.v[i][ks] = *reinterpret_cast<const bf16x8*>(q2 + qoff + h * CH + 32 * ks + 8 * kg);
     }
 }
 
-// U[s][h][c] of one 16-query tile for the heads of this wave (h = w, w + 4, ...): U^T = WkT_slice . q2^T per head.
-__device__ __forceinline__ void compute_u_tile(const char* sW, char* sU, const QFrag& q, int C, int heads, int w, int lane) {
+// U[s][h][c] of one 16-query tile for the heads of this wave (h = wg, wg + 4, ...): U^T = WkT_slice . q2^T per head.
+__device__ __forceinline__ void compute_u_tile(const char* sW, char* sU, const QFrag& q, int C, int heads, int wg, int lane) {
     const int wrow = wrow_bytes(C), urow = urow_bytes(heads);
     const int col = lane & 15, kg = lane >> 4;
 #pragma unroll
     for (int i = 0; i < HPW; ++i) {
-        const int h = w + 4 * i;
+        const int h = wg + 4 * i;
         if (h >= heads) break;
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) {
@@ -118,112 +117,119 @@ __device__ __forceinline__ void compute_u_tile(const char* sW, char* sU, const Q
 }
 
 // ------------------------------------------------------------------------------------------------
-// forward 1/3: partial logits of one channel chunk
+// forward 1/3: partial logits of one channel chunk.  512 threads = 2 groups of 4 waves; group g streams the tiles
+// t_begin + g, t_begin + g + 2, ... of the workgroup's range with its own U buffer (twice the bytes in flight of one
+// group: with the weight slice in LDS only one workgroup fits a CU, and ~16 KB of x~ per tile against 2-4 us of HBM
+// latency is what bounds the kernel).  A wave's x~ fragments pack 16 / F queries into the 16 MFMA rows.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void time2_logits_kernel(const bf16_t* __restrict__ q2, const bf16_t* __restrict__ xt,
-                                                           const bf16_t* __restrict__ wkT, int64_t ldw,
-                                                           float* __restrict__ slab, int64_t rows, int S, int F, int heads,
-                                                           float scale) {
+template <int FT>
+__global__ __launch_bounds__(64 * 4 * NGRP) void time2_logits_kernel(const bf16_t* __restrict__ q2, const bf16_t* __restrict__ xt,
+                                                                     const bf16_t* __restrict__ wkT, int64_t ldw,
+                                                                     float* __restrict__ slab, int rows, int heads,
+                                                                     float scale) {
+    constexpr int QPF = 16 / FT;           // queries per A fragment (rows = (query, frame))
+    constexpr int NFR = 4 / QPF;           // fragments per wave (4 queries per wave); FT = 4: one fragment of 4 queries
+    static_assert(QPF >= 1 && NFR >= 1, "FT in {4, 8, 16}");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int C = heads * CH, cc = blockIdx.x, nranges = gridDim.y;
-    char* sW = smem;
-    char* sU = smem + CH * wrow_bytes(C);
-    const int urow = urow_bytes(heads);
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int64_t ntiles = (rows + TQ - 1) / TQ;
-    const int64_t t_begin = ntiles * blockIdx.y / nranges, t_end = ntiles * (blockIdx.y + 1) / nranges;
+    const int grp = w >> 2, wg = w & 3;
+    char* sW = smem;
+    char* sU = smem + CH * wrow_bytes(C) + grp * TQ * urow_bytes(heads);
+    const int urow = urow_bytes(heads);
+    const int ntiles = (rows + TQ - 1) / TQ;
+    const int t_begin = (int)((int64_t)ntiles * blockIdx.y / nranges), t_end = (int)((int64_t)ntiles * (blockIdx.y + 1) / nranges);
     load_w_slice(sW, wkT, ldw, cc, C);
     __syncthreads();
     const int col = lane & 15, kg = lane >> 4;
-    const int fl = col < F ? col : F - 1;                         // frame of this lane's A row (rows >= F: duplicates)
-    const int hl = col < heads ? col : heads - 1;                 // head of this lane's B column (cols >= heads: dup.)
-    const int64_t slab_chunk = (int64_t)cc * rows * heads * F;    // slab[cc][b][h][s][f] = [cc][(b*heads+h)*S + s][f]
-    // All global operands of a tile (x~ fragments of this wave's 4 queries, q2 fragments of its heads) are loaded one
-    // tile AHEAD: with one workgroup per CU (the weight slice fills most of the LDS) nothing else hides HBM latency.
-    struct XFrag { bf16x8 v[4][2]; };
-    auto load_x = [&](XFrag& x, int64_t row0) __attribute__((always_inline)) {
+    const int qi = col / FT, fl = col % FT;                       // this lane's A row = (query qi of the fragment, frame fl)
+    const int hl = col < heads ? col : heads - 1;                 // head of this lane's B column (cols >= heads: duplicates)
+    struct XFrag { bf16x8 v[NFR][2]; };
+    auto load_x = [&](XFrag& x, int row0) __attribute__((always_inline)) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int64_t row = min(row0 + 4 * w + i, rows - 1);
+        for (int i = 0; i < NFR; ++i) {
+            const int64_t row = min(row0 + 4 * wg + QPF * i + qi, rows - 1);
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks)
-                x.v[i][ks] = *reinterpret_cast<const bf16x8*>(xt + (row * F + fl) * C + cc * CH + 32 * ks + 8 * kg);
+                x.v[i][ks] = *reinterpret_cast<const bf16x8*>(xt + (row * FT + fl) * C + cc * CH + 32 * ks + 8 * kg);
         }
     };
-    // register ring of DEPTH tiles: ~16 KB of x~ per tile and CU, HBM latency of 2-4 us under load -> several tiles
-    // must be in flight to reach the CU's share of the HBM rate
-    constexpr int DEPTH = 4;
-    XFrag xr[DEPTH];
-    QFrag qr[DEPTH];
-#pragma unroll
-    for (int k = 0; k < DEPTH; ++k)
-        if (t_begin + k < t_end) { load_x(xr[k], (t_begin + k) * TQ); load_q_frags(qr[k], q2, (t_begin + k) * TQ, rows, C, heads, w, lane); }
-    for (int64_t tb = t_begin; tb < t_end; tb += DEPTH) {
-#pragma unroll
-      for (int k = 0; k < DEPTH; ++k) {
-        const int64_t t = tb + k;
-        if (t >= t_end) break;
-        const int64_t row0 = t * TQ;
-        const XFrag xa = xr[k];
-        const QFrag qa = qr[k];
-        if (t + DEPTH < t_end) { load_x(xr[k], row0 + DEPTH * TQ); load_q_frags(qr[k], q2, row0 + DEPTH * TQ, rows, C, heads, w, lane); }
-        compute_u_tile(sW, sU, qa, C, heads, w, lane);
+    const int niter = (t_end - t_begin + NGRP - 1) / NGRP;        // both groups run the same number of barriers
+    XFrag xn;
+    QFrag qn;
+    if (t_begin + grp < t_end) { load_x(xn, (t_begin + grp) * TQ); load_q_frags(qn, q2, (t_begin + grp) * TQ, rows, C, heads, wg, lane); }
+    for (int it = 0; it < niter; ++it) {
+        const int t = t_begin + NGRP * it + grp;
+        const bool live = t < t_end;
+        const int row0 = t * TQ;
+        const XFrag xa = xn;
+        const QFrag qa = qn;
+        if (t + NGRP < t_end) { load_x(xn, row0 + NGRP * TQ); load_q_frags(qn, q2, row0 + NGRP * TQ, rows, C, heads, wg, lane); }
+        if (live) compute_u_tile(sW, sU, qa, C, heads, wg, lane);
         __syncthreads();
+        if (live) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int sq = 4 * w + i;
-            const int64_t row = row0 + sq;
-            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            for (int i = 0; i < NFR; ++i) {
+                f32x4 acc[QPF];
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                const bf16x8 ub = *reinterpret_cast<const bf16x8*>(sU + sq * urow + hl * (CH * 2) + (32 * ks + 8 * kg) * 2);
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xa.v[i][ks], ub, acc, 0, 0, 0);
-            }
-            // acc[r] = L[f = 4 kg + r][h = col]
-            if (row < rows && col < heads) {
-                const int64_t b = row / S;
-                const int s = (int)(row - b * S);
-                float* dst = slab + slab_chunk + (((b * heads + col) * S + s) * F);
+                for (int j = 0; j < QPF; ++j) {
+                    const int sq = 4 * wg + QPF * i + j;          // query of the tile whose U is the B operand
+                    acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (4 * kg + r < F) dst[4 * kg + r] = acc[r] * scale;
+                    for (int ks = 0; ks < 2; ++ks) {
+                        const bf16x8 ub = *reinterpret_cast<const bf16x8*>(sU + sq * urow + hl * (CH * 2) + (32 * ks + 8 * kg) * 2);
+                        acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xa.v[i][ks], ub, acc[j], 0, 0, 0);
+                    }
+                }
+                // lane (col = head, kg): output rows 4 kg .. 4 kg + 3 = frames (4 kg) % FT .. of query (4 kg) / FT of the fragment
+                const int jq = (4 * kg) / FT, f0 = (4 * kg) % FT;
+                f32x4 v = acc[0];
+#pragma unroll
+                for (int j = 1; j < QPF; ++j)
+                    if (jq == j) v = acc[j];
+                const int row = row0 + 4 * wg + QPF * i + jq;
+                if (row < rows && col < heads) {
+                    float4 o = make_float4(v[0] * scale, v[1] * scale, v[2] * scale, v[3] * scale);
+                    *reinterpret_cast<float4*>(slab + (((int64_t)cc * rows + row) * heads + col) * FT + f0) = o;
+                }
             }
         }
         __syncthreads();                                           // U tile is free for the next tile
-      }
     }
 }
 
-// forward 2/3: sum the chunk slabs, softmax over the frames -> attn2 [B,h,S,F]
+// forward 2/3: sum the chunk slabs, softmax over the frames -> attn2 [row][h][F]
+template <int FT>
 __global__ __launch_bounds__(256) void time2_softmax_kernel(const float* __restrict__ slab, float* __restrict__ attn2,
-                                                            int64_t n, int F, int nchunk) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;       // one (b,h,s) per thread
+                                                            int64_t n, int nchunk) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;       // one (row, h) per thread
     if (i >= n) return;
-    float lg[MAXF];
+    float lg[FT];
 #pragma unroll
-    for (int f = 0; f < MAXF; ++f) lg[f] = 0.f;
+    for (int f = 0; f < FT; ++f) lg[f] = 0.f;
 #pragma unroll 4
     for (int c = 0; c < nchunk; ++c) {
-        const float* p = slab + ((int64_t)c * n + i) * F;
+        const float4* p = reinterpret_cast<const float4*>(slab + ((int64_t)c * n + i) * FT);
 #pragma unroll
-        for (int f = 0; f < MAXF; ++f)
-            if (f < F) lg[f] += p[f];
+        for (int f4 = 0; f4 < FT / 4; ++f4) {
+            const float4 v = p[f4];
+            lg[4 * f4] += v.x; lg[4 * f4 + 1] += v.y; lg[4 * f4 + 2] += v.z; lg[4 * f4 + 3] += v.w;
+        }
     }
     float m = -INFINITY;
 #pragma unroll
-    for (int f = 0; f < MAXF; ++f)
-        if (f < F) m = fmaxf(m, lg[f]);
+    for (int f = 0; f < FT; ++f) m = fmaxf(m, lg[f]);
     float den = 0.f;
 #pragma unroll
-    for (int f = 0; f < MAXF; ++f)
-        if (f < F) { lg[f] = __expf(lg[f] - m); den += lg[f]; }
+    for (int f = 0; f < FT; ++f) { lg[f] = __expf(lg[f] - m); den += lg[f]; }
     const float inv = 1.f / den;
+    float4* o = reinterpret_cast<float4*>(attn2 + i * FT);
 #pragma unroll
-    for (int f = 0; f < MAXF; ++f)
-        if (f < F) attn2[i * F + f] = lg[f] * inv;
+    for (int f4 = 0; f4 < FT / 4; ++f4)
+        o[f4] = make_float4(lg[4 * f4] * inv, lg[4 * f4 + 1] * inv, lg[4 * f4 + 2] * inv, lg[4 * f4 + 3] * inv);
 }
 
-// forward 3/3: out[s, (h,dd)] = sum_f attn2[s,f,h] x~[s,f,(h,dd)]; thread = (row, 8-channel group), 16-byte accesses
+// forward 3/3: out[s, (h,dd)] = sum_f attn2[s,h,f] x~[s,f,(h,dd)]; thread = (row, 8-channel group), 16-byte accesses
 template <int FT>
 __global__ __launch_bounds__(256) void time2_out_kernel(const bf16_t* __restrict__ xt, const float* __restrict__ attn2,
                                                         bf16_t* __restrict__ out, int64_t obs, int64_t ngroups, int S,
@@ -232,15 +238,13 @@ __global__ __launch_bounds__(256) void time2_out_kernel(const bf16_t* __restrict
     const bool act = gi < ngroups;
     const int64_t g = act ? gi : ngroups - 1;
     const int gpr = heads * 8;
-    const int64_t row = g / gpr;
-    const int cg = (int)(g - row * gpr);
+    const int row = (int)(g / gpr);
+    const int cg = (int)(g - (int64_t)row * gpr);
     const int C = gpr * 8;
     uint4 xr[FT];
 #pragma unroll
-    for (int f = 0; f < FT; ++f) xr[f] = *reinterpret_cast<const uint4*>(xt + ((row * FT + f) * C) + cg * 8);
-    const int64_t b = row / S;
-    const int s = (int)(row - b * S);
-    const float* arow = attn2 + (((b * heads + (cg >> 3)) * S + s) * FT);
+    for (int f = 0; f < FT; ++f) xr[f] = *reinterpret_cast<const uint4*>(xt + (((int64_t)row * FT + f) * C) + cg * 8);
+    const float* arow = attn2 + ((int64_t)row * heads + (cg >> 3)) * FT;
     float o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int f = 0; f < FT; ++f) {
@@ -250,33 +254,33 @@ __global__ __launch_bounds__(256) void time2_out_kernel(const bf16_t* __restrict
 #pragma unroll
         for (int e = 0; e < 8; ++e) o[e] = fmaf(a, xv[e], o[e]);
     }
+    const int b = row / S, s = row - b * S;
     if (act) *reinterpret_cast<uint4*>(out + b * obs + (int64_t)s * C + cg * 8) = pack8(o);
 }
 
-// backward 1/2: dl[b,s,f,h] (h padded to 16) = scale * a (da - sum_f a da),  da = dout[s,h,:] . x~[s,f,h,:]
+// backward 1/2: dl[row][f][h] (bf16, h padded to 16) = scale * a (da - sum_f a da),  da = dout[s,h,:] . x~[s,f,h,:]
 template <int FT>
 __global__ __launch_bounds__(256) void time2_dl_kernel(const bf16_t* __restrict__ xt, const float* __restrict__ attn2,
-                                                       const bf16_t* __restrict__ dout, int64_t dobs, float* __restrict__ dl,
+                                                       const bf16_t* __restrict__ dout, int64_t dobs, bf16_t* __restrict__ dl,
                                                        int64_t ngroups, int S, int heads, float scale) {
     const int64_t gi = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const bool act = gi < ngroups;
     const int64_t g = act ? gi : ngroups - 1;
     const int gpr = heads * 8;
-    const int64_t row = g / gpr;
-    const int cg = (int)(g - row * gpr);
+    const int row = (int)(g / gpr);
+    const int cg = (int)(g - (int64_t)row * gpr);
     const int C = gpr * 8;
-    const int64_t b = row / S;
-    const int s = (int)(row - b * S);
+    const int b = row / S, s = row - b * S;
     uint4 xr[FT];
 #pragma unroll
-    for (int f = 0; f < FT; ++f) xr[f] = *reinterpret_cast<const uint4*>(xt + ((row * FT + f) * C) + cg * 8);
+    for (int f = 0; f < FT; ++f) xr[f] = *reinterpret_cast<const uint4*>(xt + (((int64_t)row * FT + f) * C) + cg * 8);
     float gv[8];
     unpack8(*reinterpret_cast<const uint4*>(dout + b * dobs + (int64_t)s * C + cg * 8), gv);
-    const int64_t o = ((b * heads + (cg >> 3)) * S + s) * FT;
+    const float* arow = attn2 + ((int64_t)row * heads + (cg >> 3)) * FT;
     float a[FT], da[FT], dot = 0.f;
 #pragma unroll
     for (int f = 0; f < FT; ++f) {
-        a[f] = attn2[o + f];
+        a[f] = arow[f];
         float xv[8];
         unpack8(xr[f], xv);
         float p = 0.f;
@@ -288,133 +292,137 @@ __global__ __launch_bounds__(256) void time2_dl_kernel(const bf16_t* __restrict_
     if (act && (cg & 7) == 0) {
         // [row][f][16]: a (query, frame)'s heads are contiguous -- what the dx~ / g tasks of time2_bwd_kernel read
 #pragma unroll
-        for (int f = 0; f < FT; ++f) dl[(row * FT + f) * MAXH + (cg >> 3)] = scale * a[f] * (da[f] - dot);
+        for (int f = 0; f < FT; ++f) dl[((int64_t)row * FT + f) * MAXH + (cg >> 3)] = f32_to_bf16(scale * a[f] * (da[f] - dot));
     }
 }
 
 // ------------------------------------------------------------------------------------------------
-// backward 2/2: dx~ and g = du for one channel chunk (recomputes U on chip like the forward)
+// backward 2/2: dx~ and g = du for one channel chunk (recomputes U on chip like the forward; same two-group stream)
 // ------------------------------------------------------------------------------------------------
 template <int FT>
-__global__ __launch_bounds__(256) void time2_bwd_kernel(const bf16_t* __restrict__ q2, const bf16_t* __restrict__ xt,
-                                                        const bf16_t* __restrict__ wkT, int64_t ldw,
-                                                        const float* __restrict__ attn2, const float* __restrict__ dl,
-                                                        const bf16_t* __restrict__ dout, int64_t dobs,
-                                                        bf16_t* __restrict__ dxt, bf16_t* __restrict__ gout, int64_t rows,
-                                                        int S, int heads) {
+__global__ __launch_bounds__(64 * 4 * NGRP) void time2_bwd_kernel(const bf16_t* __restrict__ q2, const bf16_t* __restrict__ xt,
+                                                                  const bf16_t* __restrict__ wkT, int64_t ldw,
+                                                                  const float* __restrict__ attn2, const bf16_t* __restrict__ dl,
+                                                                  const bf16_t* __restrict__ dout, int64_t dobs,
+                                                                  bf16_t* __restrict__ dxt, bf16_t* __restrict__ gout, int rows,
+                                                                  int S, int heads) {
     constexpr int NTASK = FT / 2;          // dx~ tasks (query, frame, 8 channels) per thread: 16 * FT * 8 / 256
-    constexpr int NDL = FT / 4;            // 16-byte pieces of the tile's dl block per thread: 16 * FT * 16 * 4 / 16 / 256
+    constexpr int DLB = TQ * FT * MAXH * 2;    // bytes of a tile's dl block (bf16): 16 * FT * 16 * 2
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int C = heads * CH, cc = blockIdx.x, nranges = gridDim.y;
-    char* sW = smem;
-    char* sU = sW + CH * wrow_bytes(C);
-    float* sDL = reinterpret_cast<float*>(sU + TQ * urow_bytes(heads));   // [16 s][FT][MAXH] dl; then [16 s][FT] a(h = cc)
-    float* sA = sDL + TQ * FT * MAXH;
-    const int urow = urow_bytes(heads);
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int64_t ntiles = (rows + TQ - 1) / TQ;
-    const int64_t t_begin = ntiles * blockIdx.y / nranges, t_end = ntiles * (blockIdx.y + 1) / nranges;
+    const int grp = w >> 2, wg = w & 3, gt = tid & 255;            // group, wave in group, thread in group
+    char* sW = smem;
+    char* sU = sW + CH * wrow_bytes(C) + grp * (TQ * urow_bytes(heads) + DLB);
+    bf16_t* sDL = reinterpret_cast<bf16_t*>(sU + TQ * urow_bytes(heads));   // [16 s][FT][MAXH] dl (bf16)
+    const int urow = urow_bytes(heads);
+    const int ntiles = (rows + TQ - 1) / TQ;
+    const int t_begin = (int)((int64_t)ntiles * blockIdx.y / nranges), t_end = (int)((int64_t)ntiles * (blockIdx.y + 1) / nranges);
     load_w_slice(sW, wkT, ldw, cc, C);
     __syncthreads();
-    // g task of this thread: query sg = tid >> 4, channel group c8g = (tid >> 1) & 7, head half hh = tid & 1
-    const int sg = tid >> 4, c8g = (tid >> 1) & 7, hh = tid & 1;
+    // g task of this thread: query sg = gt >> 4, channel group c8g = (gt >> 1) & 7, head half hh = gt & 1
+    const int sg = gt >> 4, c8g = (gt >> 1) & 7, hh = gt & 1;
     const int hper = (heads + 1) / 2;
-    // dx~ tasks: e = tid + 256 i -> 8-channel group e & 7, (query, frame) = e >> 3
-    const int c8 = tid & 7;
+    // dx~ tasks: e = gt + 256 i -> 8-channel group e & 7, (query, frame) = e >> 3
+    const int c8 = gt & 7;
 
-    // every global operand of a tile is loaded one tile ahead (one workgroup per CU: nothing else hides the latency)
-    struct In { uint4 xr[FT]; uint4 dv[NTASK]; uint4 dlp[NDL]; float a; QFrag q; };
-    auto load_in = [&](In& in, int64_t row0) __attribute__((always_inline)) {
+    // the HBM streams of a tile (x~ rows of the g task, dout rows of the dx~ tasks) are loaded one tile ahead; dl, a
+    // and q2 are L2-resident and loaded at the top of the tile
+    struct In { uint4 xr[FT]; uint4 dv[NTASK]; };
+    auto load_in = [&](In& in, int row0) __attribute__((always_inline)) {
         const int64_t grow = min(row0 + sg, rows - 1);
 #pragma unroll
         for (int f = 0; f < FT; ++f) in.xr[f] = *reinterpret_cast<const uint4*>(xt + (grow * FT + f) * C + cc * CH + c8g * 8);
 #pragma unroll
         for (int i = 0; i < NTASK; ++i) {
-            const int sq = ((tid + 256 * i) >> 3) / FT;
-            const int64_t row = min(row0 + sq, rows - 1);
-            const int64_t b = row / S;
-            in.dv[i] = *reinterpret_cast<const uint4*>(dout + b * dobs + (row - b * S) * C + cc * CH + c8 * 8);
+            const int row = min(row0 + ((gt + 256 * i) >> 3) / FT, rows - 1);
+            const int b = row / S;
+            in.dv[i] = *reinterpret_cast<const uint4*>(dout + b * dobs + (int64_t)(row - b * S) * C + cc * CH + c8 * 8);
         }
-        const int64_t npieces = (min(row0 + TQ, rows) - row0) * FT * (MAXH / 4);    // valid 16-byte pieces of the block
-#pragma unroll
-        for (int j = 0; j < NDL; ++j) {
-            const int64_t pc = min((int64_t)(tid + 256 * j), npieces - 1);
-            in.dlp[j] = *reinterpret_cast<const uint4*>(dl + row0 * FT * MAXH + pc * 4);
-        }
-        in.a = 0.f;
-        if (tid < TQ * FT) {
-            const int64_t row = min(row0 + tid / FT, rows - 1);
-            const int64_t b = row / S;
-            in.a = attn2[((b * heads + cc) * S + (row - b * S)) * FT + tid % FT];
-        }
-        load_q_frags(in.q, q2, row0, rows, C, heads, w, lane);
     };
-    constexpr int DEPTH = FT <= 8 ? 3 : 1;      // register ring of tiles in flight (see time2_logits_kernel)
-    In ring[DEPTH];
+    const int niter = (t_end - t_begin + NGRP - 1) / NGRP;
+    In nx;
+    if (t_begin + grp < t_end) load_in(nx, (t_begin + grp) * TQ);
+    for (int it = 0; it < niter; ++it) {
+        const int t = t_begin + NGRP * it + grp;
+        const bool live = t < t_end;
+        const int row0 = t * TQ;
+        const In in = nx;
+        if (t + NGRP < t_end) load_in(nx, row0 + NGRP * TQ);
+        float av[NTASK];
+        if (live) {
+            // dl block of the tile (contiguous 16 * FT * 32 bytes) -> LDS ; a of the dx~ tasks ; q2 fragments
+            const int npieces = (min(row0 + TQ, rows) - row0) * FT * 2;       // valid 16-byte pieces
+            for (int pc = gt; pc < DLB / 16; pc += 256)
+                reinterpret_cast<uint4*>(sDL)[pc] = *reinterpret_cast<const uint4*>(dl + (int64_t)row0 * FT * MAXH + min(pc, npieces - 1) * 8);
 #pragma unroll
-    for (int k = 0; k < DEPTH; ++k)
-        if (t_begin + k < t_end) load_in(ring[k], (t_begin + k) * TQ);
-    for (int64_t tb = t_begin; tb < t_end; tb += DEPTH) {
-#pragma unroll
-      for (int k = 0; k < DEPTH; ++k) {
-        const int64_t t = tb + k;
-        if (t >= t_end) break;
-        const int64_t row0 = t * TQ;
-        const In in = ring[k];
-        if (t + DEPTH < t_end) load_in(ring[k], row0 + DEPTH * TQ);
-        // dl / a of the tile -> LDS
-#pragma unroll
-        for (int j = 0; j < NDL; ++j) reinterpret_cast<uint4*>(sDL)[tid + 256 * j] = in.dlp[j];
-        if (tid < TQ * FT) sA[tid] = in.a;
-        compute_u_tile(sW, sU, in.q, C, heads, w, lane);
-        __syncthreads();
-        // ---- dx~[s,f,c] = a[s,f,cc] dout[s,c] + sum_h dl[s,f,h] U[s,h,c] : task = (s, f, 8 channels) ----
-#pragma unroll
-        for (int i = 0; i < NTASK; ++i) {
-            const int sf = (tid + 256 * i) >> 3, f = sf % FT, sq = sf / FT;
-            const int64_t row = row0 + sq;
-            float dv[8], v[8];
-            unpack8(in.dv[i], dv);
-            const float a = sA[sq * FT + f];
-#pragma unroll
-            for (int k = 0; k < 8; ++k) v[k] = a * dv[k];
-            const float* dlr = sDL + (sq * FT + f) * MAXH;
-            for (int h = 0; h < heads; ++h) {
-                float uv[8];
-                unpack8(*reinterpret_cast<const uint4*>(sU + sq * urow + h * (CH * 2) + c8 * 16), uv);
-                const float d = dlr[h];
-#pragma unroll
-                for (int k = 0; k < 8; ++k) v[k] = fmaf(d, uv[k], v[k]);
+            for (int i = 0; i < NTASK; ++i) {
+                const int sf = (gt + 256 * i) >> 3;
+                av[i] = attn2[((int64_t)min(row0 + sf / FT, rows - 1) * heads + cc) * FT + sf % FT];
             }
-            if (row < rows) *reinterpret_cast<uint4*>(dxt + (row * FT + f) * C + cc * CH + c8 * 8) = pack8(v);
+            QFrag q;
+            load_q_frags(q, q2, row0, rows, C, heads, wg, lane);
+            compute_u_tile(sW, sU, q, C, heads, wg, lane);
         }
-        // ---- g[s,h,c] = sum_f dl[s,f,h] x~[s,f,c] : this thread's (s, 8 channels) for its half of the heads ----
-        {
-            float xv[FT][8];
+        __syncthreads();
+        if (live) {
+            // ---- dx~[s,f,c] = a[s,f,cc] dout[s,c] + sum_h dl[s,f,h] U[s,h,c] : task = (s, f, 8 channels) ----
 #pragma unroll
-            for (int f = 0; f < FT; ++f) unpack8(in.xr[f], xv[f]);
-            const int64_t row = row0 + sg;
-            for (int hi = 0; hi < hper; ++hi) {
-                const int h = hh * hper + hi;
-                if (h >= heads) break;
-                float gv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            for (int i = 0; i < NTASK; ++i) {
+                const int sf = (gt + 256 * i) >> 3, f = sf % FT, sq = sf / FT;
+                const int row = row0 + sq;
+                float dv[8], v[8], dlv[16];
+                unpack8(in.dv[i], dv);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[k] = av[i] * dv[k];
+                const uint4* dlr = reinterpret_cast<const uint4*>(sDL + (sq * FT + f) * MAXH);
+                unpack8(dlr[0], dlv);
+                unpack8(dlr[1], dlv + 8);
+#pragma unroll
+                for (int h = 0; h < MAXH; ++h) {
+                    if (h >= heads) break;
+                    float uv[8];
+                    unpack8(*reinterpret_cast<const uint4*>(sU + sq * urow + h * (CH * 2) + c8 * 16), uv);
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) v[k] = fmaf(dlv[h], uv[k], v[k]);
+                }
+                if (row < rows) *reinterpret_cast<uint4*>(dxt + ((int64_t)row * FT + f) * C + cc * CH + c8 * 8) = pack8(v);
+            }
+            // ---- g[s,h,c] = sum_f dl[s,f,h] x~[s,f,c] : this thread's (s, 8 channels) for its half of the heads ----
+            {
+                float gacc[MAXH / 2][8];
+#pragma unroll
+                for (int hi = 0; hi < MAXH / 2; ++hi)
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) gacc[hi][k] = 0.f;
 #pragma unroll
                 for (int f = 0; f < FT; ++f) {
-                    const float d = sDL[(sg * FT + f) * MAXH + h];
+                    float xv[8], dlv[8];
+                    unpack8(in.xr[f], xv);
+                    unpack8(*reinterpret_cast<const uint4*>(sDL + (sg * FT + f) * MAXH + hh * 8), dlv);   // heads 8 hh .. 8 hh + 7
 #pragma unroll
-                    for (int k = 0; k < 8; ++k) gv[k] = fmaf(d, xv[f][k], gv[k]);
+                    for (int hi = 0; hi < MAXH / 2; ++hi)
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) gacc[hi][k] = fmaf(dlv[hi], xv[k], gacc[hi][k]);
                 }
-                if (row < rows)
-                    *reinterpret_cast<uint4*>(gout + (row * heads + h) * C + cc * CH + c8g * 8) = pack8(gv);
+                const int row = row0 + sg;
+#pragma unroll
+                for (int hi = 0; hi < MAXH / 2; ++hi) {
+                    const int h = hh * 8 + hi;
+                    if (h < heads && row < rows)
+                        *reinterpret_cast<uint4*>(gout + ((int64_t)row * heads + h) * C + cc * CH + c8g * 8) = pack8(gacc[hi]);
+                }
             }
         }
         __syncthreads();                                           // U / dl tiles are free for the next tile
-      }
     }
+    (void)hper;
 }
 
-size_t time2_lds_fwd(int heads) { return (size_t)CH * (heads * CH * 2 + 16) + (size_t)TQ * (heads * CH * 2 + 16); }
-size_t time2_lds_bwd(int heads, int F) { return time2_lds_fwd(heads) + (size_t)TQ * F * (MAXH + 1) * sizeof(float); }
+size_t time2_lds_fwd(int heads) { return (size_t)CH * wrow_bytes(heads * CH) + (size_t)NGRP * TQ * urow_bytes(heads); }
+size_t time2_lds_bwd(int heads, int F) {
+    return (size_t)CH * wrow_bytes(heads * CH) + (size_t)NGRP * (TQ * urow_bytes(heads) + TQ * F * MAXH * 2);
+}
 
 int ranges_for(int nchunk, int64_t rows) {
     int r = 256 / nchunk;                                          // one workgroup per CU
@@ -427,7 +435,8 @@ int ranges_for(int nchunk, int64_t rows) {
 
 bool focus_traj_time2_ok(int F, int heads, int d, int dtype) {
     static const bool enabled = !(getenv("FOCUS_TIME2") && atoi(getenv("FOCUS_TIME2")) == 0);
-    return enabled && dtype == FOCUS_BF16 && d == CH && heads >= 1 && heads <= MAXH && (F == 4 || F == 8 || F == 16);
+    return enabled && dtype == FOCUS_BF16 && d == CH && heads >= 1 && heads <= MAXH && (F == 4 || F == 8 || F == 16) &&
+           time2_lds_bwd(heads, F) <= 160 * 1024;
 }
 
 extern "C" size_t focus_traj_time2_workspace_bytes(int B, int S, int F, int heads, int d) {
@@ -441,25 +450,29 @@ extern "C" int focus_traj_time2_fwd(const void* q2, const void* xt, const void* 
     if (!q2 || !xt || !wkT || !out || !attn2 || !ws) return FOCUS_ERR_NULL;
     if (B <= 0 || S <= 0 || !focus_traj_time2_ok(F, heads, d, dtype)) return FOCUS_ERR_SHAPE;
     const int C = heads * CH;
-    if (ldw < C || (ldw & 7) || (out_bstride & 7) || out_bstride < (int64_t)S * C) return FOCUS_ERR_SHAPE;
-    if (!focus_aligned(q2, 16) || !focus_aligned(xt, 16) || !focus_aligned(wkT, 16) || !focus_aligned(out, 16))
+    const int64_t rows = (int64_t)B * S;
+    if (ldw < C || (ldw & 7) || (out_bstride & 7) || out_bstride < (int64_t)S * C || rows * F * C > 0x7fffffffLL * 8)
+        return FOCUS_ERR_SHAPE;
+    if (!focus_aligned(q2, 16) || !focus_aligned(xt, 16) || !focus_aligned(wkT, 16) || !focus_aligned(out, 16) ||
+        !focus_aligned(ws, 16) || !focus_aligned(attn2, 16))
         return FOCUS_ERR_ALIGN;
     if (ws_bytes < focus_traj_time2_workspace_bytes(B, S, F, heads, d)) return FOCUS_ERR_WORKSPACE;
     hipStream_t s = (hipStream_t)stream;
-    const int64_t rows = (int64_t)B * S;
     const int nchunk = C / CH;
     const size_t lds = time2_lds_fwd(heads);
-    static bool once = (hipFuncSetAttribute((const void*)time2_logits_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                            160 * 1024) == hipSuccess);
-    (void)once;
-    if (lds > 160 * 1024) return FOCUS_ERR_SHAPE;
     const float scale = 1.f / sqrtf((float)d);
-    hipLaunchKernelGGL(time2_logits_kernel, dim3(nchunk, ranges_for(nchunk, rows)), dim3(256), lds, s, (const bf16_t*)q2,
-                       (const bf16_t*)xt, (const bf16_t*)wkT, ldw, (float*)ws, rows, S, F, heads, scale);
+    dim3 grid(nchunk, ranges_for(nchunk, rows));
+#define TL(FT) do { \
+        static bool once_##FT = (hipFuncSetAttribute((const void*)time2_logits_kernel<FT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess); \
+        (void)once_##FT; \
+        hipLaunchKernelGGL((time2_logits_kernel<FT>), grid, dim3(64 * 4 * NGRP), lds, s, (const bf16_t*)q2, (const bf16_t*)xt, (const bf16_t*)wkT, ldw, (float*)ws, (int)rows, heads, scale); } while (0)
+    if (F == 8) TL(8); else if (F == 4) TL(4); else TL(16);
+#undef TL
     FOCUS_CHECK_LAUNCH();
     const int64_t n = rows * heads;
-    hipLaunchKernelGGL(time2_softmax_kernel, dim3((unsigned)cdiv64(n, 256)), dim3(256), 0, s, (const float*)ws, attn2, n, F,
-                       nchunk);
+#define TS(FT) hipLaunchKernelGGL((time2_softmax_kernel<FT>), dim3((unsigned)cdiv64(n, 256)), dim3(256), 0, s, (const float*)ws, attn2, n, nchunk)
+    if (F == 8) TS(8); else if (F == 4) TS(4); else TS(16);
+#undef TS
     FOCUS_CHECK_LAUNCH();
     const int64_t ng = rows * heads * 8;
     dim3 gv((unsigned)cdiv64(ng, 256));
@@ -471,32 +484,34 @@ extern "C" int focus_traj_time2_fwd(const void* q2, const void* xt, const void* 
 }
 
 extern "C" int focus_traj_time2_bwd(const void* q2, const void* xt, const void* wkT, int64_t ldw, const float* attn2,
-                                    const void* dout, int64_t dout_bstride, void* dxt, void* g, float* dl, int B, int S,
+                                    const void* dout, int64_t dout_bstride, void* dxt, void* g, void* dl, int B, int S,
                                     int F, int heads, int d, int dtype, void* stream) {
     if (!q2 || !xt || !wkT || !attn2 || !dout || !dxt || !g || !dl) return FOCUS_ERR_NULL;
     if (B <= 0 || S <= 0 || !focus_traj_time2_ok(F, heads, d, dtype)) return FOCUS_ERR_SHAPE;
     const int C = heads * CH;
-    if (ldw < C || (ldw & 7) || (dout_bstride & 7) || dout_bstride < (int64_t)S * C) return FOCUS_ERR_SHAPE;
+    const int64_t rows = (int64_t)B * S;
+    if (ldw < C || (ldw & 7) || (dout_bstride & 7) || dout_bstride < (int64_t)S * C || rows * F * C > 0x7fffffffLL * 8)
+        return FOCUS_ERR_SHAPE;
     if (!focus_aligned(q2, 16) || !focus_aligned(xt, 16) || !focus_aligned(wkT, 16) || !focus_aligned(dout, 16) ||
-        !focus_aligned(dxt, 16) || !focus_aligned(g, 16))
+        !focus_aligned(dxt, 16) || !focus_aligned(g, 16) || !focus_aligned(dl, 16))
         return FOCUS_ERR_ALIGN;
     hipStream_t s = (hipStream_t)stream;
-    const int64_t rows = (int64_t)B * S;
     const int nchunk = C / CH;
     const float scale = 1.f / sqrtf((float)d);
     const int64_t ng = rows * heads * 8;
     dim3 gv((unsigned)cdiv64(ng, 256));
-#define TD(FT) hipLaunchKernelGGL((time2_dl_kernel<FT>), gv, dim3(256), 0, s, (const bf16_t*)xt, attn2, (const bf16_t*)dout, dout_bstride, dl, ng, S, heads, scale)
+    // the padded head columns of dl are read (and multiplied by nothing): keep them finite
+    if (heads < MAXH && hipMemsetAsync(dl, 0, (size_t)rows * F * MAXH * 2, s) != hipSuccess) return FOCUS_ERR_LAUNCH;
+#define TD(FT) hipLaunchKernelGGL((time2_dl_kernel<FT>), gv, dim3(256), 0, s, (const bf16_t*)xt, attn2, (const bf16_t*)dout, dout_bstride, (bf16_t*)dl, ng, S, heads, scale)
     if (F == 8) TD(8); else if (F == 4) TD(4); else TD(16);
 #undef TD
     FOCUS_CHECK_LAUNCH();
     const size_t lds = time2_lds_bwd(heads, F);
-    if (lds > 160 * 1024) return FOCUS_ERR_SHAPE;
     dim3 grid(nchunk, ranges_for(nchunk, rows));
 #define TB(FT) do { \
         static bool once_##FT = (hipFuncSetAttribute((const void*)time2_bwd_kernel<FT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess); \
         (void)once_##FT; \
-        hipLaunchKernelGGL((time2_bwd_kernel<FT>), grid, dim3(256), lds, s, (const bf16_t*)q2, (const bf16_t*)xt, (const bf16_t*)wkT, ldw, attn2, (const float*)dl, (const bf16_t*)dout, dout_bstride, (bf16_t*)dxt, (bf16_t*)g, rows, S, heads); } while (0)
+        hipLaunchKernelGGL((time2_bwd_kernel<FT>), grid, dim3(64 * 4 * NGRP), lds, s, (const bf16_t*)q2, (const bf16_t*)xt, (const bf16_t*)wkT, ldw, attn2, (const bf16_t*)dl, (const bf16_t*)dout, dout_bstride, (bf16_t*)dxt, (bf16_t*)g, (int)rows, S, heads); } while (0)
     if (F == 8) TB(8); else if (F == 4) TB(4); else TB(16);
 #undef TB
     FOCUS_CHECK_LAUNCH();

@@ -784,7 +784,7 @@ class _TrajTime2BlockFn(torch.autograd.Function):
         wkT = shadow(w_kv, xt.dtype, transposed=True)                   # [C_in, 2C]: columns :C are Wk^T
         out = torch.empty(B, S + 1, C, device=xt.device, dtype=xt.dtype)
         out[:, 0].copy_(cls_out.reshape(B, C))
-        attn2 = torch.empty(B, heads, S, F_, device=xt.device, dtype=torch.float32)
+        attn2 = torch.empty(B, S, heads, F_, device=xt.device, dtype=torch.float32)
         nb = L.focus_traj_time2_workspace_bytes(B, S, F_, heads, d)
         ws = torch.empty(nb // 4, device=xt.device, dtype=torch.float32)
         _lib.check(L.focus_traj_time2_fwd(_p(q2), _p(xt), _p(wkT), wkT.stride(0), _p(out, C), (S + 1) * C, _p(attn2),
@@ -805,7 +805,7 @@ class _TrajTime2BlockFn(torch.autograd.Function):
         wkT = shadow(w_kv, xt.dtype, transposed=True)
         dxt = torch.empty_like(xt)
         g = torch.empty(B, S, heads, C, device=dev, dtype=xt.dtype)
-        dl = torch.empty(B, S, F_, 16, device=dev, dtype=torch.float32)      # [.., h padded to 16]
+        dl = torch.empty(B, S, F_, 16, device=dev, dtype=xt.dtype)           # [.., h padded to 16]
         _lib.check(L.focus_traj_time2_bwd(_p(q2), _p(xt), _p(wkT), wkT.stride(0), _p(attn2), _p(dcat, C), (S + 1) * C,
                                           _p(dxt), _p(g), _p(dl), B, S, F_, heads, d, _dt(xt), _stream()), "traj_time2_bwd")
         R = B * S

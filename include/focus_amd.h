@@ -167,17 +167,17 @@ int focus_traj_time_bwd(const void* q2, const void* k2, const void* xt, const fl
  * never formed; u[s,h,:] = Wk[h]^T q2[s,h,:] is produced per 64-channel chunk on chip (csrc/traj_time2.hip).
  * bf16, head dim 64, heads <= 16, F in {4, 8, 16}.  wkT: [C rows (input channel c)][ldw] bf16 whose columns 0..C-1 hold
  * Wk^T (the transposed shadow of proj_kv.weight).  q2 [B,S,C] is the UN-scaled proj_q output.
- *   fwd: out rows [B,S,C] at batch stride out_bstride (see focus_traj_time_fwd); attn2 [B,h,S,F] fp32 (saved);
+ *   fwd: out rows [B,S,C] at batch stride out_bstride (see focus_traj_time_fwd); attn2 [B,S,h,F] fp32 (saved);
  *        ws: focus_traj_time2_workspace_bytes() bytes of scratch.
  *   bwd: dxt [B,S,F,C] (fully written: a*dout + sum_h dl*u); g [B,S,h,C] bf16 = d(loss)/d(u), from which the caller
  *        forms  dq2[:, h*64+dd] = sum_c g[:,h,c] Wk[h*64+dd, c]  and  dWk[h*64+dd, c] = sum_s q2[s,h*64+dd] g[s,h,c]
- *        (two batched GEMMs over the heads); dl [B,S,F,16] fp32 scratch.  proj_kv.bias gets its exact zero gradient. */
+ *        (two batched GEMMs over the heads); dl [B,S,F,16] bf16 scratch.  proj_kv.bias gets its exact zero gradient. */
 size_t focus_traj_time2_workspace_bytes(int B, int S, int F, int heads, int d);
 int focus_traj_time2_fwd(const void* q2, const void* xt, const void* wkT, int64_t ldw, void* out, int64_t out_bstride,
                          float* attn2, void* ws, size_t ws_bytes, int B, int S, int F, int heads, int d, int dtype,
                          void* stream);
 int focus_traj_time2_bwd(const void* q2, const void* xt, const void* wkT, int64_t ldw, const float* attn2,
-                         const void* dout, int64_t dout_bstride, void* dxt, void* g, float* dl, int B, int S, int F,
+                         const void* dout, int64_t dout_bstride, void* dxt, void* g, void* dl, int B, int S, int F,
                          int heads, int d, int dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
