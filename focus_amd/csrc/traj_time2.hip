@@ -348,20 +348,30 @@ __global__ __launch_bounds__(64 * 4 * NGRP) void time2_bwd_kernel(const bf16_t* 
         const bool live = t < t_end;
         const int row0 = t * TQ;
         const In in = nx;
-        if (t + NGRP < t_end) load_in(nx, row0 + NGRP * TQ);
         float av[NTASK];
+        QFrag q;
+        constexpr int NPC = DLB / 16, NDP = (NPC + 255) / 256;    // 16-byte pieces of the dl block; per thread
+        uint4 dlp[NDP];
         if (live) {
-            // dl block of the tile (contiguous 16 * FT * 32 bytes) -> LDS ; a of the dx~ tasks ; q2 fragments
+            // L2-resident operands of THIS tile first (dl block -> LDS, a of the dx~ tasks, q2 fragments): vector-memory
+            // operations retire in order, so the next tile's HBM loads below must be YOUNGER than these -- waiting for
+            // q2 would otherwise wait for the whole prefetch
             const int npieces = (min(row0 + TQ, rows) - row0) * FT * 2;       // valid 16-byte pieces
-            for (int pc = gt; pc < DLB / 16; pc += 256)
-                reinterpret_cast<uint4*>(sDL)[pc] = *reinterpret_cast<const uint4*>(dl + (int64_t)row0 * FT * MAXH + min(pc, npieces - 1) * 8);
+#pragma unroll
+            for (int j = 0; j < NDP; ++j)
+                dlp[j] = *reinterpret_cast<const uint4*>(dl + (int64_t)row0 * FT * MAXH + min(gt + 256 * j, npieces - 1) * 8);
 #pragma unroll
             for (int i = 0; i < NTASK; ++i) {
                 const int sf = (gt + 256 * i) >> 3;
                 av[i] = attn2[((int64_t)min(row0 + sf / FT, rows - 1) * heads + cc) * FT + sf % FT];
             }
-            QFrag q;
             load_q_frags(q, q2, row0, rows, C, heads, wg, lane);
+        }
+        if (t + NGRP < t_end) load_in(nx, row0 + NGRP * TQ);
+        if (live) {
+#pragma unroll
+            for (int j = 0; j < NDP; ++j)
+                if (gt + 256 * j < NPC) reinterpret_cast<uint4*>(sDL)[gt + 256 * j] = dlp[j];
             compute_u_tile(sW, sU, q, C, heads, wg, lane);
         }
         __syncthreads();
