@@ -61,6 +61,15 @@ __device__ __forceinline__ float sum8lanes(float v) {
     return v;
 }
 
+// Workgroup barrier for LDS hand-offs only.  __syncthreads() also releases global memory at workgroup scope, for which
+// hipcc drains s_waitcnt vmcnt(0): that would wait for the NEXT tile's prefetch loads (and this tile's stores) at every
+// barrier and serialise the stream.  The tiles only hand LDS data between waves.
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
 // LDS images.  Row pitches are the data bytes + 16: 16 lanes that read the same 16-byte column of 16 consecutive rows
 // (the MFMA row fragments) then fall on 16 different 16-byte slots of the 256-byte bank row.
 __host__ __device__ __forceinline__ int wrow_bytes(int C) { return C * 2 + 16; }              // Wk^T slice: [64 c][C (h,dd)]
@@ -126,7 +135,7 @@ template <int FT>
 __global__ __launch_bounds__(64 * 4 * NGRP) void time2_logits_kernel(const bf16_t* __restrict__ q2, const bf16_t* __restrict__ xt,
                                                                      const bf16_t* __restrict__ wkT, int64_t ldw,
                                                                      float* __restrict__ slab, int rows, int heads,
-                                                                     float scale) {
+                                                                     float scale, int dbg) {
     constexpr int QPF = 16 / FT;           // queries per A fragment (rows = (query, frame))
     constexpr int NFR = 4 / QPF;           // fragments per wave (4 queries per wave); FT = 4: one fragment of 4 queries
     static_assert(QPF >= 1 && NFR >= 1, "FT in {4, 8, 16}");
@@ -151,7 +160,8 @@ __global__ __launch_bounds__(64 * 4 * NGRP) void time2_logits_kernel(const bf16_
             const int64_t row = min(row0 + 4 * wg + QPF * i + qi, rows - 1);
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks)
-                x.v[i][ks] = *reinterpret_cast<const bf16x8*>(xt + (row * FT + fl) * C + cc * CH + 32 * ks + 8 * kg);
+                x.v[i][ks] = *reinterpret_cast<const bf16x8*>(dbg ? xt + (((int64_t)cc * rows + row) * FT + fl) * CH + 32 * ks + 8 * kg
+                                                                   : xt + (row * FT + fl) * C + cc * CH + 32 * ks + 8 * kg);
         }
     };
     const int niter = (t_end - t_begin + NGRP - 1) / NGRP;        // both groups run the same number of barriers
@@ -166,7 +176,7 @@ __global__ __launch_bounds__(64 * 4 * NGRP) void time2_logits_kernel(const bf16_
         const QFrag qa = qn;
         if (t + NGRP < t_end) { load_x(xn, row0 + NGRP * TQ); load_q_frags(qn, q2, row0 + NGRP * TQ, rows, C, heads, wg, lane); }
         if (live) compute_u_tile(sW, sU, qa, C, heads, wg, lane);
-        __syncthreads();
+        lds_barrier();
         if (live) {
 #pragma unroll
             for (int i = 0; i < NFR; ++i) {
@@ -194,7 +204,7 @@ __global__ __launch_bounds__(64 * 4 * NGRP) void time2_logits_kernel(const bf16_
                 }
             }
         }
-        __syncthreads();                                           // U tile is free for the next tile
+        lds_barrier();                                           // U tile is free for the next tile
     }
 }
 
@@ -305,7 +315,7 @@ __global__ __launch_bounds__(64 * 4 * NGRP) void time2_bwd_kernel(const bf16_t* 
                                                                   const float* __restrict__ attn2, const bf16_t* __restrict__ dl,
                                                                   const bf16_t* __restrict__ dout, int64_t dobs,
                                                                   bf16_t* __restrict__ dxt, bf16_t* __restrict__ gout, int rows,
-                                                                  int S, int heads) {
+                                                                  int S, int heads, int dbg) {
     constexpr int NTASK = FT / 2;          // dx~ tasks (query, frame, 8 channels) per thread: 16 * FT * 8 / 256
     constexpr int DLB = TQ * FT * MAXH * 2;    // bytes of a tile's dl block (bf16): 16 * FT * 16 * 2
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -332,7 +342,9 @@ __global__ __launch_bounds__(64 * 4 * NGRP) void time2_bwd_kernel(const bf16_t* 
     auto load_in = [&](In& in, int row0) __attribute__((always_inline)) {
         const int64_t grow = min(row0 + sg, rows - 1);
 #pragma unroll
-        for (int f = 0; f < FT; ++f) in.xr[f] = *reinterpret_cast<const uint4*>(xt + (grow * FT + f) * C + cc * CH + c8g * 8);
+        for (int f = 0; f < FT; ++f)
+            in.xr[f] = *reinterpret_cast<const uint4*>((dbg & 1) ? xt + (((int64_t)cc * rows + grow) * FT + f) * CH + c8g * 8
+                                                                 : xt + (grow * FT + f) * C + cc * CH + c8g * 8);
 #pragma unroll
         for (int i = 0; i < NTASK; ++i) {
             const int row = min(row0 + ((gt + 256 * i) >> 3) / FT, rows - 1);
@@ -374,7 +386,7 @@ __global__ __launch_bounds__(64 * 4 * NGRP) void time2_bwd_kernel(const bf16_t* 
                 if (gt + 256 * j < NPC) reinterpret_cast<uint4*>(sDL)[gt + 256 * j] = dlp[j];
             compute_u_tile(sW, sU, q, C, heads, wg, lane);
         }
-        __syncthreads();
+        lds_barrier();
         if (live) {
             // ---- dx~[s,f,c] = a[s,f,cc] dout[s,c] + sum_h dl[s,f,h] U[s,h,c] : task = (s, f, 8 channels) ----
 #pragma unroll
@@ -396,7 +408,9 @@ __global__ __launch_bounds__(64 * 4 * NGRP) void time2_bwd_kernel(const bf16_t* 
 #pragma unroll
                     for (int k = 0; k < 8; ++k) v[k] = fmaf(dlv[h], uv[k], v[k]);
                 }
-                if (row < rows) *reinterpret_cast<uint4*>(dxt + ((int64_t)row * FT + f) * C + cc * CH + c8 * 8) = pack8(v);
+                if (row < rows)
+                    *reinterpret_cast<uint4*>((dbg & 1) ? dxt + (((int64_t)cc * rows + row) * FT + f) * CH + c8 * 8
+                                                        : dxt + ((int64_t)row * FT + f) * C + cc * CH + c8 * 8) = pack8(v);
             }
             // ---- g[s,h,c] = sum_f dl[s,f,h] x~[s,f,c] : this thread's (s, 8 channels) for its half of the heads ----
             {
@@ -420,11 +434,12 @@ __global__ __launch_bounds__(64 * 4 * NGRP) void time2_bwd_kernel(const bf16_t* 
                 for (int hi = 0; hi < MAXH / 2; ++hi) {
                     const int h = hh * 8 + hi;
                     if (h < heads && row < rows)
-                        *reinterpret_cast<uint4*>(gout + ((int64_t)row * heads + h) * C + cc * CH + c8g * 8) = pack8(gacc[hi]);
+                        *reinterpret_cast<uint4*>((dbg & 2) ? gout + (((int64_t)cc * rows + row) * heads + h) * CH + c8g * 8
+                                                            : gout + ((int64_t)row * heads + h) * C + cc * CH + c8g * 8) = pack8(gacc[hi]);
                 }
             }
         }
-        __syncthreads();                                           // U / dl tiles are free for the next tile
+        lds_barrier();                                           // U / dl tiles are free for the next tile
     }
     (void)hper;
 }
@@ -471,11 +486,12 @@ extern "C" int focus_traj_time2_fwd(const void* q2, const void* xt, const void* 
     const int nchunk = C / CH;
     const size_t lds = time2_lds_fwd(heads);
     const float scale = 1.f / sqrtf((float)d);
+    static const int dbg = getenv("FOCUS_T2_DEBUG_CONTIG") ? atoi(getenv("FOCUS_T2_DEBUG_CONTIG")) : 0;   // timing experiment only
     dim3 grid(nchunk, ranges_for(nchunk, rows));
 #define TL(FT) do { \
         static bool once_##FT = (hipFuncSetAttribute((const void*)time2_logits_kernel<FT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess); \
         (void)once_##FT; \
-        hipLaunchKernelGGL((time2_logits_kernel<FT>), grid, dim3(64 * 4 * NGRP), lds, s, (const bf16_t*)q2, (const bf16_t*)xt, (const bf16_t*)wkT, ldw, (float*)ws, (int)rows, heads, scale); } while (0)
+        hipLaunchKernelGGL((time2_logits_kernel<FT>), grid, dim3(64 * 4 * NGRP), lds, s, (const bf16_t*)q2, (const bf16_t*)xt, (const bf16_t*)wkT, ldw, (float*)ws, (int)rows, heads, scale, dbg); } while (0)
     if (F == 8) TL(8); else if (F == 4) TL(4); else TL(16);
 #undef TL
     FOCUS_CHECK_LAUNCH();
@@ -517,11 +533,12 @@ extern "C" int focus_traj_time2_bwd(const void* q2, const void* xt, const void* 
 #undef TD
     FOCUS_CHECK_LAUNCH();
     const size_t lds = time2_lds_bwd(heads, F);
+    static const int dbg = getenv("FOCUS_T2_DEBUG_CONTIG") ? atoi(getenv("FOCUS_T2_DEBUG_CONTIG")) : 0;   // timing experiment only
     dim3 grid(nchunk, ranges_for(nchunk, rows));
 #define TB(FT) do { \
         static bool once_##FT = (hipFuncSetAttribute((const void*)time2_bwd_kernel<FT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess); \
         (void)once_##FT; \
-        hipLaunchKernelGGL((time2_bwd_kernel<FT>), grid, dim3(64 * 4 * NGRP), lds, s, (const bf16_t*)q2, (const bf16_t*)xt, (const bf16_t*)wkT, ldw, attn2, (const bf16_t*)dl, (const bf16_t*)dout, dout_bstride, (bf16_t*)dxt, (bf16_t*)g, (int)rows, S, heads); } while (0)
+        hipLaunchKernelGGL((time2_bwd_kernel<FT>), grid, dim3(64 * 4 * NGRP), lds, s, (const bf16_t*)q2, (const bf16_t*)xt, (const bf16_t*)wkT, ldw, attn2, (const bf16_t*)dl, (const bf16_t*)dout, dout_bstride, (bf16_t*)dxt, (bf16_t*)g, (int)rows, S, heads, dbg); } while (0)
     if (F == 8) TB(8); else if (F == 4) TB(4); else TB(16);
 #undef TB
     FOCUS_CHECK_LAUNCH();
