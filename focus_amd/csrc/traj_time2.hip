@@ -17,7 +17,7 @@
 //                   the A operand is read from x~ in HBM directly (16 B per lane, 128-B row segments); partial
 //                   logits of the chunk go to slab[cc][row][h][f]; time2_softmax_kernel sums the C/64 slabs and takes
 //                   the softmax over f (attn2 [B,S,h,F]); time2_out_kernel forms out = sum_f a x~ (reads x~ once more).
-//   backward (time2_dl_kernel, then time2_bwd_kernel):
+//   backward (time2_dl_kernel, then time2_dx_kernel):
 //     dl[s,f,h]   = scale a (da - sum_f a da),  da[s,f,h] = dout[s,h,:] . x~[s,f,h,:]
 //     dx~[s,f,c]  = a[s,f,h(c)] dout[s,c] + sum_h dl[s,f,h] U[s,h,c]                      (VALU, U from LDS)
 //     g[s,h,c]    = sum_f dl[s,f,h] x~[s,f,c]   ( = du )  -> HBM [B,S,h,C] bf16: the host forms
@@ -135,7 +135,7 @@ template <int FT>
 __global__ __launch_bounds__(64 * 4 * NGRP) void time2_logits_kernel(const bf16_t* __restrict__ q2, const bf16_t* __restrict__ xt,
                                                                      const bf16_t* __restrict__ wkT, int64_t ldw,
                                                                      float* __restrict__ slab, int rows, int heads,
-                                                                     float scale, int dbg) {
+                                                                     float scale) {
     constexpr int QPF = 16 / FT;           // queries per A fragment (rows = (query, frame))
     constexpr int NFR = 4 / QPF;           // fragments per wave (4 queries per wave); FT = 4: one fragment of 4 queries
     static_assert(QPF >= 1 && NFR >= 1, "FT in {4, 8, 16}");
@@ -160,8 +160,7 @@ __global__ __launch_bounds__(64 * 4 * NGRP) void time2_logits_kernel(const bf16_
             const int64_t row = min(row0 + 4 * wg + QPF * i + qi, rows - 1);
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks)
-                x.v[i][ks] = *reinterpret_cast<const bf16x8*>(dbg ? xt + (((int64_t)cc * rows + row) * FT + fl) * CH + 32 * ks + 8 * kg
-                                                                   : xt + (row * FT + fl) * C + cc * CH + 32 * ks + 8 * kg);
+                x.v[i][ks] = *reinterpret_cast<const bf16x8*>(xt + (row * FT + fl) * C + cc * CH + 32 * ks + 8 * kg);
         }
     };
     const int niter = (t_end - t_begin + NGRP - 1) / NGRP;        // both groups run the same number of barriers
@@ -268,25 +267,28 @@ __global__ __launch_bounds__(256) void time2_out_kernel(const bf16_t* __restrict
     if (act) *reinterpret_cast<uint4*>(out + b * obs + (int64_t)s * C + cg * 8) = pack8(o);
 }
 
-// backward 1/2: dl[row][f][h] (bf16, h padded to 16) = scale * a (da - sum_f a da),  da = dout[s,h,:] . x~[s,f,h,:]
+// backward 1/2 (streaming, reads x~ once): block = RPB whole query rows, thread = (row, 8-channel group).
+//   da[f]  = dout[s,h,:] . x~[s,f,h,:]  (8-lane reduction inside the head);  dl[f] = scale * a (da - sum_f a da)
+//   dl of the row's heads meet in LDS, then  g[s,h,c8] = sum_f dl[s,f,h] x~[s,f,c8]  for every head h from the x~
+//   registers the thread already holds -> g [row][h][C] bf16 (= d loss / d u), dl [row][f][16] bf16 for time2_dx_kernel.
 template <int FT>
-__global__ __launch_bounds__(256) void time2_dl_kernel(const bf16_t* __restrict__ xt, const float* __restrict__ attn2,
-                                                       const bf16_t* __restrict__ dout, int64_t dobs, bf16_t* __restrict__ dl,
-                                                       int64_t ngroups, int S, int heads, float scale) {
-    const int64_t gi = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    const bool act = gi < ngroups;
-    const int64_t g = act ? gi : ngroups - 1;
-    const int gpr = heads * 8;
-    const int row = (int)(g / gpr);
-    const int cg = (int)(g - (int64_t)row * gpr);
-    const int C = gpr * 8;
+__global__ __launch_bounds__(256) void time2_dlg_kernel(const bf16_t* __restrict__ xt, const float* __restrict__ attn2,
+                                                        const bf16_t* __restrict__ dout, int64_t dobs,
+                                                        bf16_t* __restrict__ dl, bf16_t* __restrict__ gout, int rows,
+                                                        int S, int HEADS, int RPB, float scale) {
+    const int GPR = HEADS * 8, C = HEADS * CH;                     // 8-channel groups per row; RPB = 256 / GPR rows per block
+    __shared__ float sdl[32][FT][MAXH];
+    const int tid = threadIdx.x, rl = min(tid / GPR, RPB - 1), cg = tid - (tid / GPR) * GPR, h = cg >> 3;
+    const int row_raw = blockIdx.x * RPB + rl;
+    const bool act = row_raw < rows && tid < RPB * GPR;             // (threads past the last whole row of the block idle)
+    const int row = act ? row_raw : rows - 1;
     const int b = row / S, s = row - b * S;
     uint4 xr[FT];
 #pragma unroll
     for (int f = 0; f < FT; ++f) xr[f] = *reinterpret_cast<const uint4*>(xt + (((int64_t)row * FT + f) * C) + cg * 8);
     float gv[8];
     unpack8(*reinterpret_cast<const uint4*>(dout + b * dobs + (int64_t)s * C + cg * 8), gv);
-    const float* arow = attn2 + ((int64_t)row * heads + (cg >> 3)) * FT;
+    const float* arow = attn2 + ((int64_t)row * HEADS + h) * FT;
     float a[FT], da[FT], dot = 0.f;
 #pragma unroll
     for (int f = 0; f < FT; ++f) {
@@ -296,26 +298,53 @@ __global__ __launch_bounds__(256) void time2_dl_kernel(const bf16_t* __restrict_
         float p = 0.f;
 #pragma unroll
         for (int e = 0; e < 8; ++e) p = fmaf(gv[e], xv[e], p);
-        da[f] = sum8lanes(p);
+        da[f] = sum8lanes(p);                                    // the head's 8 lanes are adjacent (GPR % 8 == 0)
         dot = fmaf(a[f], da[f], dot);
     }
-    if (act && (cg & 7) == 0) {
-        // [row][f][16]: a (query, frame)'s heads are contiguous -- what the dx~ / g tasks of time2_bwd_kernel read
+    if (tid < RPB * GPR && (cg & 7) == 0) {
 #pragma unroll
-        for (int f = 0; f < FT; ++f) dl[((int64_t)row * FT + f) * MAXH + (cg >> 3)] = f32_to_bf16(scale * a[f] * (da[f] - dot));
+        for (int f = 0; f < FT; ++f) sdl[rl][f][h] = scale * a[f] * (da[f] - dot);
+    }
+    if (tid < RPB * GPR && cg < MAXH - HEADS) {                      // padded head columns: zeros (read by time2_dx_kernel)
+#pragma unroll
+        for (int f = 0; f < FT; ++f) sdl[rl][f][HEADS + cg] = 0.f;
+    }
+    __syncthreads();
+    // dl row -> HBM (bf16 [row][f][16]): FT * 16 values per row, 8 per thread
+    if (act) {
+        for (int pc = cg; pc < FT * 2; pc += GPR) {
+            const int f = pc >> 1, h0 = (pc & 1) * 8;
+            float v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = sdl[rl][f][h0 + k];
+            *reinterpret_cast<uint4*>(dl + ((int64_t)row * FT + f) * MAXH + h0) = pack8(v);
+        }
+    }
+    // g[h][8 channels of this thread] for every head
+    float xv[FT][8];
+#pragma unroll
+    for (int f = 0; f < FT; ++f) unpack8(xr[f], xv[f]);
+    for (int hh = 0; hh < HEADS; ++hh) {
+        float g8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int f = 0; f < FT; ++f) {
+            const float d = sdl[rl][f][hh];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) g8[k] = fmaf(d, xv[f][k], g8[k]);
+        }
+        if (act) *reinterpret_cast<uint4*>(gout + ((int64_t)row * HEADS + hh) * C + cg * 8) = pack8(g8);
     }
 }
 
 // ------------------------------------------------------------------------------------------------
-// backward 2/2: dx~ and g = du for one channel chunk (recomputes U on chip like the forward; same two-group stream)
+// backward 2/2: dx~ for one channel chunk (recomputes U on chip like the forward; same two-group stream)
 // ------------------------------------------------------------------------------------------------
 template <int FT>
-__global__ __launch_bounds__(64 * 4 * NGRP) void time2_bwd_kernel(const bf16_t* __restrict__ q2, const bf16_t* __restrict__ xt,
+__global__ __launch_bounds__(64 * 4 * NGRP) void time2_dx_kernel(const bf16_t* __restrict__ q2, const bf16_t* __restrict__ xt,
                                                                   const bf16_t* __restrict__ wkT, int64_t ldw,
                                                                   const float* __restrict__ attn2, const bf16_t* __restrict__ dl,
                                                                   const bf16_t* __restrict__ dout, int64_t dobs,
-                                                                  bf16_t* __restrict__ dxt, bf16_t* __restrict__ gout, int rows,
-                                                                  int S, int heads, int dbg) {
+                                                                  bf16_t* __restrict__ dxt, int rows, int S, int heads) {
     constexpr int NTASK = FT / 2;          // dx~ tasks (query, frame, 8 channels) per thread: 16 * FT * 8 / 256
     constexpr int DLB = TQ * FT * MAXH * 2;    // bytes of a tile's dl block (bf16): 16 * FT * 16 * 2
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -330,21 +359,12 @@ __global__ __launch_bounds__(64 * 4 * NGRP) void time2_bwd_kernel(const bf16_t* 
     const int t_begin = (int)((int64_t)ntiles * blockIdx.y / nranges), t_end = (int)((int64_t)ntiles * (blockIdx.y + 1) / nranges);
     load_w_slice(sW, wkT, ldw, cc, C);
     __syncthreads();
-    // g task of this thread: query sg = gt >> 4, channel group c8g = (gt >> 1) & 7, head half hh = gt & 1
-    const int sg = gt >> 4, c8g = (gt >> 1) & 7, hh = gt & 1;
-    const int hper = (heads + 1) / 2;
     // dx~ tasks: e = gt + 256 i -> 8-channel group e & 7, (query, frame) = e >> 3
     const int c8 = gt & 7;
 
-    // the HBM streams of a tile (x~ rows of the g task, dout rows of the dx~ tasks) are loaded one tile ahead; dl, a
-    // and q2 are L2-resident and loaded at the top of the tile
-    struct In { uint4 xr[FT]; uint4 dv[NTASK]; };
+    // the dout rows of the dx~ tasks are loaded one tile ahead; dl, a and q2 at the top of the tile
+    struct In { uint4 dv[NTASK]; };
     auto load_in = [&](In& in, int row0) __attribute__((always_inline)) {
-        const int64_t grow = min(row0 + sg, rows - 1);
-#pragma unroll
-        for (int f = 0; f < FT; ++f)
-            in.xr[f] = *reinterpret_cast<const uint4*>((dbg & 1) ? xt + (((int64_t)cc * rows + grow) * FT + f) * CH + c8g * 8
-                                                                 : xt + (grow * FT + f) * C + cc * CH + c8g * 8);
 #pragma unroll
         for (int i = 0; i < NTASK; ++i) {
             const int row = min(row0 + ((gt + 256 * i) >> 3) / FT, rows - 1);
@@ -408,40 +428,11 @@ __global__ __launch_bounds__(64 * 4 * NGRP) void time2_bwd_kernel(const bf16_t* 
 #pragma unroll
                     for (int k = 0; k < 8; ++k) v[k] = fmaf(dlv[h], uv[k], v[k]);
                 }
-                if (row < rows)
-                    *reinterpret_cast<uint4*>((dbg & 1) ? dxt + (((int64_t)cc * rows + row) * FT + f) * CH + c8 * 8
-                                                        : dxt + ((int64_t)row * FT + f) * C + cc * CH + c8 * 8) = pack8(v);
-            }
-            // ---- g[s,h,c] = sum_f dl[s,f,h] x~[s,f,c] : this thread's (s, 8 channels) for its half of the heads ----
-            {
-                float gacc[MAXH / 2][8];
-#pragma unroll
-                for (int hi = 0; hi < MAXH / 2; ++hi)
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) gacc[hi][k] = 0.f;
-#pragma unroll
-                for (int f = 0; f < FT; ++f) {
-                    float xv[8], dlv[8];
-                    unpack8(in.xr[f], xv);
-                    unpack8(*reinterpret_cast<const uint4*>(sDL + (sg * FT + f) * MAXH + hh * 8), dlv);   // heads 8 hh .. 8 hh + 7
-#pragma unroll
-                    for (int hi = 0; hi < MAXH / 2; ++hi)
-#pragma unroll
-                        for (int k = 0; k < 8; ++k) gacc[hi][k] = fmaf(dlv[hi], xv[k], gacc[hi][k]);
-                }
-                const int row = row0 + sg;
-#pragma unroll
-                for (int hi = 0; hi < MAXH / 2; ++hi) {
-                    const int h = hh * 8 + hi;
-                    if (h < heads && row < rows)
-                        *reinterpret_cast<uint4*>((dbg & 2) ? gout + (((int64_t)cc * rows + row) * heads + h) * CH + c8g * 8
-                                                            : gout + ((int64_t)row * heads + h) * C + cc * CH + c8g * 8) = pack8(gacc[hi]);
-                }
+                if (row < rows) *reinterpret_cast<uint4*>(dxt + ((int64_t)row * FT + f) * C + cc * CH + c8 * 8) = pack8(v);
             }
         }
         lds_barrier();                                           // U / dl tiles are free for the next tile
     }
-    (void)hper;
 }
 
 size_t time2_lds_fwd(int heads) { return (size_t)CH * wrow_bytes(heads * CH) + (size_t)NGRP * TQ * urow_bytes(heads); }
@@ -486,12 +477,11 @@ extern "C" int focus_traj_time2_fwd(const void* q2, const void* xt, const void* 
     const int nchunk = C / CH;
     const size_t lds = time2_lds_fwd(heads);
     const float scale = 1.f / sqrtf((float)d);
-    static const int dbg = getenv("FOCUS_T2_DEBUG_CONTIG") ? atoi(getenv("FOCUS_T2_DEBUG_CONTIG")) : 0;   // timing experiment only
     dim3 grid(nchunk, ranges_for(nchunk, rows));
 #define TL(FT) do { \
         static bool once_##FT = (hipFuncSetAttribute((const void*)time2_logits_kernel<FT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess); \
         (void)once_##FT; \
-        hipLaunchKernelGGL((time2_logits_kernel<FT>), grid, dim3(64 * 4 * NGRP), lds, s, (const bf16_t*)q2, (const bf16_t*)xt, (const bf16_t*)wkT, ldw, (float*)ws, (int)rows, heads, scale, dbg); } while (0)
+        hipLaunchKernelGGL((time2_logits_kernel<FT>), grid, dim3(64 * 4 * NGRP), lds, s, (const bf16_t*)q2, (const bf16_t*)xt, (const bf16_t*)wkT, ldw, (float*)ws, (int)rows, heads, scale); } while (0)
     if (F == 8) TL(8); else if (F == 4) TL(4); else TL(16);
 #undef TL
     FOCUS_CHECK_LAUNCH();
@@ -524,21 +514,20 @@ extern "C" int focus_traj_time2_bwd(const void* q2, const void* xt, const void* 
     hipStream_t s = (hipStream_t)stream;
     const int nchunk = C / CH;
     const float scale = 1.f / sqrtf((float)d);
-    const int64_t ng = rows * heads * 8;
-    dim3 gv((unsigned)cdiv64(ng, 256));
-    // the padded head columns of dl are read (and multiplied by nothing): keep them finite
-    if (heads < MAXH && hipMemsetAsync(dl, 0, (size_t)rows * F * MAXH * 2, s) != hipSuccess) return FOCUS_ERR_LAUNCH;
-#define TD(FT) hipLaunchKernelGGL((time2_dl_kernel<FT>), gv, dim3(256), 0, s, (const bf16_t*)xt, attn2, (const bf16_t*)dout, dout_bstride, (bf16_t*)dl, ng, S, heads, scale)
-    if (F == 8) TD(8); else if (F == 4) TD(4); else TD(16);
+    {
+        const int gpr = heads * 8, rpb = 256 / gpr;                // heads <= 16 -> at least 2 whole rows per 256-thread block
+        dim3 gd((unsigned)cdiv64(rows, rpb));
+#define TD(FT) hipLaunchKernelGGL((time2_dlg_kernel<FT>), gd, dim3(256), 0, s, (const bf16_t*)xt, attn2, (const bf16_t*)dout, dout_bstride, (bf16_t*)dl, (bf16_t*)g, (int)rows, S, heads, rpb, scale)
+        if (F == 8) TD(8); else if (F == 4) TD(4); else TD(16);
 #undef TD
-    FOCUS_CHECK_LAUNCH();
+        FOCUS_CHECK_LAUNCH();
+    }
     const size_t lds = time2_lds_bwd(heads, F);
-    static const int dbg = getenv("FOCUS_T2_DEBUG_CONTIG") ? atoi(getenv("FOCUS_T2_DEBUG_CONTIG")) : 0;   // timing experiment only
     dim3 grid(nchunk, ranges_for(nchunk, rows));
 #define TB(FT) do { \
-        static bool once_##FT = (hipFuncSetAttribute((const void*)time2_bwd_kernel<FT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess); \
+        static bool once_##FT = (hipFuncSetAttribute((const void*)time2_dx_kernel<FT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess); \
         (void)once_##FT; \
-        hipLaunchKernelGGL((time2_bwd_kernel<FT>), grid, dim3(64 * 4 * NGRP), lds, s, (const bf16_t*)q2, (const bf16_t*)xt, (const bf16_t*)wkT, ldw, attn2, (const bf16_t*)dl, (const bf16_t*)dout, dout_bstride, (bf16_t*)dxt, (bf16_t*)g, (int)rows, S, heads, dbg); } while (0)
+        hipLaunchKernelGGL((time2_dx_kernel<FT>), grid, dim3(64 * 4 * NGRP), lds, s, (const bf16_t*)q2, (const bf16_t*)xt, (const bf16_t*)wkT, ldw, attn2, (const bf16_t*)dl, (const bf16_t*)dout, dout_bstride, (bf16_t*)dxt, (int)rows, S, heads); } while (0)
     if (F == 8) TB(8); else if (F == 4) TB(4); else TB(16);
 #undef TB
     FOCUS_CHECK_LAUNCH();
