@@ -70,10 +70,14 @@ __device__ __forceinline__ void lds_barrier() {
     asm volatile("" ::: "memory");
 }
 
-// LDS images.  Row pitches are the data bytes + 16: 16 lanes that read the same 16-byte column of 16 consecutive rows
-// (the MFMA row fragments) then fall on 16 different 16-byte slots of the 256-byte bank row.
-__host__ __device__ __forceinline__ int wrow_bytes(int C) { return C * 2 + 16; }              // Wk^T slice: [64 c][C (h,dd)]
-__host__ __device__ __forceinline__ int urow_bytes(int heads) { return heads * CH * 2 + 16; } // U: [16 s][heads][64 c]
+// LDS images, padded against bank conflicts (modelled per instruction with the lane groups of MI355X_MICROARCH.md "LDS";
+// SQ_LDS_BANK_CONFLICT was 57 % of the LDS cycles with +16-byte rows):
+//   W rows + 32 B: a ds_read_b128 lane group mixes 8 rows of k-group a with 8 rows of k-group a + 1; a row pitch of
+//                  2 slots (mod 16) keeps their 16-byte slots apart (pitch of 1 slot: one 2-way conflict per group).
+//   U [16 s][heads][64 c]: query rows + 16 B (the MFMA result is written with the query on the lane); in the forward
+//                  the head rows are read as the B operand with the HEAD on the lane: head pitch 128 + 16 B.
+__host__ __device__ __forceinline__ int wrow_bytes(int C) { return C * 2 + 32; }              // Wk^T slice: [64 c][C (h,dd)]
+template <int HPAD> __host__ __device__ __forceinline__ int urow_bytes(int heads) { return heads * (CH * 2 + HPAD) + 16; }
 
 // Wk^T slice of this chunk -> LDS (once per workgroup; register staged: the padded rows rule out LDS-DMA)
 __device__ __forceinline__ void load_w_slice(char* sW, const bf16_t* wkT, int64_t ldw, int cc, int C) {
@@ -101,8 +105,9 @@ __device__ __forceinline__ void load_q_frags(QFrag& q, const bf16_t* __restrict_
 }
 
 // U[s][h][c] of one 16-query tile for the heads of this wave (h = wg, wg + 4, ...): U^T = WkT_slice . q2^T per head.
+template <int HPAD>
 __device__ __forceinline__ void compute_u_tile(const char* sW, char* sU, const QFrag& q, int C, int heads, int wg, int lane) {
-    const int wrow = wrow_bytes(C), urow = urow_bytes(heads);
+    const int wrow = wrow_bytes(C), urow = urow_bytes<HPAD>(heads);
     const int col = lane & 15, kg = lane >> 4;
 #pragma unroll
     for (int i = 0; i < HPW; ++i) {
@@ -120,7 +125,7 @@ __device__ __forceinline__ void compute_u_tile(const char* sW, char* sU, const Q
             Pk4 p;
 #pragma unroll
             for (int r = 0; r < 4; ++r) p.e[r] = f32_to_bf16(acc[r]);
-            *reinterpret_cast<uint2*>(sU + col * urow + h * (CH * 2) + (16 * mt + 4 * kg) * 2) = p.u;
+            *reinterpret_cast<uint2*>(sU + col * urow + h * (CH * 2 + HPAD) + (16 * mt + 4 * kg) * 2) = p.u;
         }
     }
 }
@@ -144,8 +149,8 @@ __global__ __launch_bounds__(64 * 4 * NGRP) void time2_logits_kernel(const bf16_
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int grp = w >> 2, wg = w & 3;
     char* sW = smem;
-    char* sU = smem + CH * wrow_bytes(C) + grp * TQ * urow_bytes(heads);
-    const int urow = urow_bytes(heads);
+    char* sU = smem + CH * wrow_bytes(C) + grp * TQ * urow_bytes<16>(heads);
+    const int urow = urow_bytes<16>(heads);
     const int ntiles = (rows + TQ - 1) / TQ;
     const int t_begin = (int)((int64_t)ntiles * blockIdx.y / nranges), t_end = (int)((int64_t)ntiles * (blockIdx.y + 1) / nranges);
     load_w_slice(sW, wkT, ldw, cc, C);
@@ -174,7 +179,7 @@ __global__ __launch_bounds__(64 * 4 * NGRP) void time2_logits_kernel(const bf16_
         const XFrag xa = xn;
         const QFrag qa = qn;
         if (t + NGRP < t_end) { load_x(xn, row0 + NGRP * TQ); load_q_frags(qn, q2, row0 + NGRP * TQ, rows, C, heads, wg, lane); }
-        if (live) compute_u_tile(sW, sU, qa, C, heads, wg, lane);
+        if (live) compute_u_tile<16>(sW, sU, qa, C, heads, wg, lane);
         lds_barrier();
         if (live) {
 #pragma unroll
@@ -186,7 +191,7 @@ __global__ __launch_bounds__(64 * 4 * NGRP) void time2_logits_kernel(const bf16_
                     acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                     for (int ks = 0; ks < 2; ++ks) {
-                        const bf16x8 ub = *reinterpret_cast<const bf16x8*>(sU + sq * urow + hl * (CH * 2) + (32 * ks + 8 * kg) * 2);
+                        const bf16x8 ub = *reinterpret_cast<const bf16x8*>(sU + sq * urow + hl * (CH * 2 + 16) + (32 * ks + 8 * kg) * 2);
                         acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xa.v[i][ks], ub, acc[j], 0, 0, 0);
                     }
                 }
@@ -352,9 +357,9 @@ __global__ __launch_bounds__(64 * 4 * NGRP) void time2_dx_kernel(const bf16_t* _
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int grp = w >> 2, wg = w & 3, gt = tid & 255;            // group, wave in group, thread in group
     char* sW = smem;
-    char* sU = sW + CH * wrow_bytes(C) + grp * (TQ * urow_bytes(heads) + DLB);
-    bf16_t* sDL = reinterpret_cast<bf16_t*>(sU + TQ * urow_bytes(heads));   // [16 s][FT][MAXH] dl (bf16)
-    const int urow = urow_bytes(heads);
+    char* sU = sW + CH * wrow_bytes(C) + grp * (TQ * urow_bytes<0>(heads) + DLB);
+    bf16_t* sDL = reinterpret_cast<bf16_t*>(sU + TQ * urow_bytes<0>(heads));   // [16 s][FT][MAXH] dl (bf16)
+    const int urow = urow_bytes<0>(heads);
     const int ntiles = (rows + TQ - 1) / TQ;
     const int t_begin = (int)((int64_t)ntiles * blockIdx.y / nranges), t_end = (int)((int64_t)ntiles * (blockIdx.y + 1) / nranges);
     load_w_slice(sW, wkT, ldw, cc, C);
@@ -404,7 +409,7 @@ __global__ __launch_bounds__(64 * 4 * NGRP) void time2_dx_kernel(const bf16_t* _
 #pragma unroll
             for (int j = 0; j < NDP; ++j)
                 if (gt + 256 * j < NPC) reinterpret_cast<uint4*>(sDL)[gt + 256 * j] = dlp[j];
-            compute_u_tile(sW, sU, q, C, heads, wg, lane);
+            compute_u_tile<0>(sW, sU, q, C, heads, wg, lane);
         }
         lds_barrier();
         if (live) {
@@ -435,9 +440,9 @@ __global__ __launch_bounds__(64 * 4 * NGRP) void time2_dx_kernel(const bf16_t* _
     }
 }
 
-size_t time2_lds_fwd(int heads) { return (size_t)CH * wrow_bytes(heads * CH) + (size_t)NGRP * TQ * urow_bytes(heads); }
+size_t time2_lds_fwd(int heads) { return (size_t)CH * wrow_bytes(heads * CH) + (size_t)NGRP * TQ * urow_bytes<16>(heads); }
 size_t time2_lds_bwd(int heads, int F) {
-    return (size_t)CH * wrow_bytes(heads * CH) + (size_t)NGRP * (TQ * urow_bytes(heads) + TQ * F * MAXH * 2);
+    return (size_t)CH * wrow_bytes(heads * CH) + (size_t)NGRP * (TQ * urow_bytes<0>(heads) + TQ * F * MAXH * 2);
 }
 
 int ranges_for(int nchunk, int64_t rows) {
@@ -452,7 +457,7 @@ int ranges_for(int nchunk, int64_t rows) {
 bool focus_traj_time2_ok(int F, int heads, int d, int dtype) {
     static const bool enabled = !(getenv("FOCUS_TIME2") && atoi(getenv("FOCUS_TIME2")) == 0);
     return enabled && dtype == FOCUS_BF16 && d == CH && heads >= 1 && heads <= MAXH && (F == 4 || F == 8 || F == 16) &&
-           time2_lds_bwd(heads, F) <= 160 * 1024;
+           time2_lds_bwd(heads, F) <= 160 * 1024 && time2_lds_fwd(heads) <= 160 * 1024;
 }
 
 extern "C" size_t focus_traj_time2_workspace_bytes(int B, int S, int F, int heads, int d) {
