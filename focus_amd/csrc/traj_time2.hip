@@ -169,16 +169,28 @@ __global__ __launch_bounds__(64 * 4 * NGRP) void time2_logits_kernel(const bf16_
         }
     };
     const int niter = (t_end - t_begin + NGRP - 1) / NGRP;        // both groups run the same number of barriers
-    XFrag xn;
+    // x~ comes from HBM: XD tiles of this group stay in flight (a CU needs ~50-100 KB in flight for its share of the
+    // HBM rate at 2-4 us latency; a tile is 16 KB); q2 is L2-resident: one tile ahead
+    constexpr int XD = 3;
+    XFrag xring[XD];
     QFrag qn;
-    if (t_begin + grp < t_end) { load_x(xn, (t_begin + grp) * TQ); load_q_frags(qn, q2, (t_begin + grp) * TQ, rows, C, heads, wg, lane); }
-    for (int it = 0; it < niter; ++it) {
+#pragma unroll
+    for (int k = 0; k < XD; ++k)
+        if (t_begin + grp + NGRP * k < t_end) load_x(xring[k], (t_begin + grp + NGRP * k) * TQ);
+    if (t_begin + grp < t_end) load_q_frags(qn, q2, (t_begin + grp) * TQ, rows, C, heads, wg, lane);
+    for (int itb = 0; itb < niter; itb += XD) {
+#pragma unroll
+      for (int k = 0; k < XD; ++k) {
+        const int it = itb + k;
+        if (it >= niter) break;
         const int t = t_begin + NGRP * it + grp;
         const bool live = t < t_end;
         const int row0 = t * TQ;
-        const XFrag xa = xn;
+        const XFrag xa = xring[k];
         const QFrag qa = qn;
-        if (t + NGRP < t_end) { load_x(xn, row0 + NGRP * TQ); load_q_frags(qn, q2, row0 + NGRP * TQ, rows, C, heads, wg, lane); }
+        // (vector-memory operations retire in order: the loads needed soonest are issued first)
+        if (t + NGRP < t_end) load_q_frags(qn, q2, row0 + NGRP * TQ, rows, C, heads, wg, lane);
+        if (t + NGRP * XD < t_end) load_x(xring[k], row0 + NGRP * XD * TQ);
         if (live) compute_u_tile<16>(sW, sU, qa, C, heads, wg, lane);
         lds_barrier();
         if (live) {
@@ -209,6 +221,7 @@ __global__ __launch_bounds__(64 * 4 * NGRP) void time2_logits_kernel(const bf16_
             }
         }
         lds_barrier();                                           // U tile is free for the next tile
+      }
     }
 }
 
@@ -367,13 +380,22 @@ __global__ __launch_bounds__(64 * 4 * NGRP) void time2_dx_kernel(const bf16_t* _
     // dx~ tasks: e = gt + 256 i -> 8-channel group e & 7, (query, frame) = e >> 3
     const int c8 = gt & 7;
 
-    // the dout rows of the dx~ tasks are loaded one tile ahead; dl, a and q2 at the top of the tile
-    struct In { uint4 dv[NTASK]; };
+    // every global operand of a tile (dout rows and a of the dx~ tasks, the dl block, q2 fragments) is loaded one tile
+    // ahead, before the current tile's stores are issued (loads and stores retire in order on one counter)
+    constexpr int NPC = DLB / 16, NDP = (NPC + 255) / 256;        // 16-byte pieces of the dl block; per thread
+    struct In { uint4 dv[NTASK]; float av[NTASK]; uint4 dlp[NDP]; QFrag q; };
     auto load_in = [&](In& in, int row0) __attribute__((always_inline)) {
+        const int npieces = (min(row0 + TQ, rows) - row0) * FT * 2;           // valid 16-byte pieces of the dl block
+#pragma unroll
+        for (int j = 0; j < NDP; ++j)
+            in.dlp[j] = *reinterpret_cast<const uint4*>(dl + (int64_t)row0 * FT * MAXH + min(gt + 256 * j, npieces - 1) * 8);
+        load_q_frags(in.q, q2, row0, rows, C, heads, wg, lane);
 #pragma unroll
         for (int i = 0; i < NTASK; ++i) {
-            const int row = min(row0 + ((gt + 256 * i) >> 3) / FT, rows - 1);
+            const int sf = (gt + 256 * i) >> 3;
+            const int row = min(row0 + sf / FT, rows - 1);
             const int b = row / S;
+            in.av[i] = attn2[((int64_t)row * heads + cc) * FT + sf % FT];
             in.dv[i] = *reinterpret_cast<const uint4*>(dout + b * dobs + (int64_t)(row - b * S) * C + cc * CH + c8 * 8);
         }
     };
@@ -385,31 +407,12 @@ __global__ __launch_bounds__(64 * 4 * NGRP) void time2_dx_kernel(const bf16_t* _
         const bool live = t < t_end;
         const int row0 = t * TQ;
         const In in = nx;
-        float av[NTASK];
-        QFrag q;
-        constexpr int NPC = DLB / 16, NDP = (NPC + 255) / 256;    // 16-byte pieces of the dl block; per thread
-        uint4 dlp[NDP];
-        if (live) {
-            // L2-resident operands of THIS tile first (dl block -> LDS, a of the dx~ tasks, q2 fragments): vector-memory
-            // operations retire in order, so the next tile's HBM loads below must be YOUNGER than these -- waiting for
-            // q2 would otherwise wait for the whole prefetch
-            const int npieces = (min(row0 + TQ, rows) - row0) * FT * 2;       // valid 16-byte pieces
-#pragma unroll
-            for (int j = 0; j < NDP; ++j)
-                dlp[j] = *reinterpret_cast<const uint4*>(dl + (int64_t)row0 * FT * MAXH + min(gt + 256 * j, npieces - 1) * 8);
-#pragma unroll
-            for (int i = 0; i < NTASK; ++i) {
-                const int sf = (gt + 256 * i) >> 3;
-                av[i] = attn2[((int64_t)min(row0 + sf / FT, rows - 1) * heads + cc) * FT + sf % FT];
-            }
-            load_q_frags(q, q2, row0, rows, C, heads, wg, lane);
-        }
         if (t + NGRP < t_end) load_in(nx, row0 + NGRP * TQ);
         if (live) {
 #pragma unroll
             for (int j = 0; j < NDP; ++j)
-                if (gt + 256 * j < NPC) reinterpret_cast<uint4*>(sDL)[gt + 256 * j] = dlp[j];
-            compute_u_tile<0>(sW, sU, q, C, heads, wg, lane);
+                if (gt + 256 * j < NPC) reinterpret_cast<uint4*>(sDL)[gt + 256 * j] = in.dlp[j];
+            compute_u_tile<0>(sW, sU, in.q, C, heads, wg, lane);
         }
         lds_barrier();
         if (live) {
@@ -421,7 +424,7 @@ __global__ __launch_bounds__(64 * 4 * NGRP) void time2_dx_kernel(const bf16_t* _
                 float dv[8], v[8], dlv[16];
                 unpack8(in.dv[i], dv);
 #pragma unroll
-                for (int k = 0; k < 8; ++k) v[k] = av[i] * dv[k];
+                for (int k = 0; k < 8; ++k) v[k] = in.av[i] * dv[k];
                 const uint4* dlr = reinterpret_cast<const uint4*>(sDL + (sq * FT + f) * MAXH);
                 unpack8(dlr[0], dlv);
                 unpack8(dlr[1], dlv + 8);
