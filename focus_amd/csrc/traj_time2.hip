@@ -81,11 +81,24 @@ template <int HPAD> __host__ __device__ __forceinline__ int urow_bytes(int heads
 
 // Wk^T slice of this chunk -> LDS (once per workgroup; register staged: the padded rows rule out LDS-DMA)
 __device__ __forceinline__ void load_w_slice(char* sW, const bf16_t* wkT, int64_t ldw, int cc, int C) {
-    const int pieces = C / 8, wrow = wrow_bytes(C);              // 16-byte pieces per row
-    for (int e = threadIdx.x; e < CH * pieces; e += blockDim.x) {
-        const int row = e / pieces, pc = e - row * pieces;
-        const uint4 v = *reinterpret_cast<const uint4*>(wkT + (int64_t)(cc * CH + row) * ldw + pc * 8);
-        *reinterpret_cast<uint4*>(sW + row * wrow + pc * 16) = v;
+    const int pieces = C / 8, wrow = wrow_bytes(C), total = CH * pieces;      // 16-byte pieces per row / in the slice
+    constexpr int UN = 6;                                        // loads in flight per thread (a serial load -> ds_write
+    for (int e0 = threadIdx.x; e0 < total; e0 += UN * blockDim.x) {   // loop costs one L2/HBM round trip per piece)
+        uint4 v[UN];
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const int e = min(e0 + u * (int)blockDim.x, total - 1);
+            const int row = e / pieces, pc = e - row * pieces;
+            v[u] = *reinterpret_cast<const uint4*>(wkT + (int64_t)(cc * CH + row) * ldw + pc * 8);
+        }
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const int e = e0 + u * (int)blockDim.x;
+            if (e < total) {
+                const int row = e / pieces, pc = e - row * pieces;
+                *reinterpret_cast<uint4*>(sW + row * wrow + pc * 16) = v[u];
+            }
+        }
     }
 }
 
@@ -169,15 +182,19 @@ __global__ __launch_bounds__(64 * 4 * NGRP) void time2_logits_kernel(const bf16_
         }
     };
     const int niter = (t_end - t_begin + NGRP - 1) / NGRP;        // both groups run the same number of barriers
-    // x~ comes from HBM: XD tiles of this group stay in flight (a CU needs ~50-100 KB in flight for its share of the
-    // HBM rate at 2-4 us latency; a tile is 16 KB); q2 is L2-resident: one tile ahead
+    // XD tiles of this group stay in flight (a CU needs ~50-100 KB in flight for its share of the HBM rate at 2-4 us
+    // latency; a tile is 16 KB of x~ + 24 KB of q2)
     constexpr int XD = 3;
     XFrag xring[XD];
-    QFrag qn;
+    QFrag qring[XD];
+    // The ring loads are UNCONDITIONAL (rows past the end are clamped to the last row, tiles past the range re-read it):
+    // with loads under an `if` hipcc cannot count how many are outstanding and drains s_waitcnt vmcnt(0) at every use,
+    // which empties the ring each iteration (seen in the ISA: vmcnt(11) .. vmcnt(0) ladders).
 #pragma unroll
-    for (int k = 0; k < XD; ++k)
-        if (t_begin + grp + NGRP * k < t_end) load_x(xring[k], (t_begin + grp + NGRP * k) * TQ);
-    if (t_begin + grp < t_end) load_q_frags(qn, q2, (t_begin + grp) * TQ, rows, C, heads, wg, lane);
+    for (int k = 0; k < XD; ++k) {
+        load_q_frags(qring[k], q2, (t_begin + grp + NGRP * k) * TQ, rows, C, heads, wg, lane);
+        load_x(xring[k], (t_begin + grp + NGRP * k) * TQ);
+    }
     for (int itb = 0; itb < niter; itb += XD) {
 #pragma unroll
       for (int k = 0; k < XD; ++k) {
@@ -187,10 +204,10 @@ __global__ __launch_bounds__(64 * 4 * NGRP) void time2_logits_kernel(const bf16_
         const bool live = t < t_end;
         const int row0 = t * TQ;
         const XFrag xa = xring[k];
-        const QFrag qa = qn;
-        // (vector-memory operations retire in order: the loads needed soonest are issued first)
-        if (t + NGRP < t_end) load_q_frags(qn, q2, row0 + NGRP * TQ, rows, C, heads, wg, lane);
-        if (t + NGRP * XD < t_end) load_x(xring[k], row0 + NGRP * XD * TQ);
+        const QFrag qa = qring[k];
+        // q2 (19 MB, re-read by the 12 chunk owners: L2 / Infinity Cache, not "free") rides the same ring as x~
+        load_q_frags(qring[k], q2, row0 + NGRP * XD * TQ, rows, C, heads, wg, lane);
+        load_x(xring[k], row0 + NGRP * XD * TQ);
         if (live) compute_u_tile<16>(sW, sU, qa, C, heads, wg, lane);
         lds_barrier();
         if (live) {
@@ -401,13 +418,13 @@ __global__ __launch_bounds__(64 * 4 * NGRP) void time2_dx_kernel(const bf16_t* _
     };
     const int niter = (t_end - t_begin + NGRP - 1) / NGRP;
     In nx;
-    if (t_begin + grp < t_end) load_in(nx, (t_begin + grp) * TQ);
+    load_in(nx, min((t_begin + grp) * TQ, rows - 1));               // unconditional loads: see time2_logits_kernel
     for (int it = 0; it < niter; ++it) {
         const int t = t_begin + NGRP * it + grp;
         const bool live = t < t_end;
         const int row0 = t * TQ;
         const In in = nx;
-        if (t + NGRP < t_end) load_in(nx, row0 + NGRP * TQ);
+        load_in(nx, min(row0 + NGRP * TQ, rows - 1));
         if (live) {
 #pragma unroll
             for (int j = 0; j < NDP; ++j)
