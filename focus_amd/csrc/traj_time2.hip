@@ -36,9 +36,6 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 constexpr int CH = 64;                 // channels per chunk (= head dim: chunk cc holds exactly head cc's channels)
 constexpr int TQ = 16;                 // queries per tile (MFMA N)
 constexpr int MAXH = 16;               // heads <= 16 (MFMA N of the logit product)
-constexpr int MAXF = 16;               // frames <= 16 (MFMA M of the logit product)
-constexpr int NGRP = 2;                // wave groups (4 waves each) per workgroup, each streaming its own tiles
-constexpr int HPW = MAXH / 4;          // heads per wave (h = w, w + 4, ...)
 
 union Pk4 { uint2 u; bf16_t e[4]; };
 
@@ -62,184 +59,256 @@ __device__ __forceinline__ float sum8lanes(float v) {
 }
 
 // Workgroup barrier for LDS hand-offs only.  __syncthreads() also releases global memory at workgroup scope, for which
-// hipcc drains s_waitcnt vmcnt(0): that would wait for the NEXT tile's prefetch loads (and this tile's stores) at every
-// barrier and serialise the stream.  The tiles only hand LDS data between waves.
+// hipcc drains s_waitcnt vmcnt(0): that would wait for the prefetch ring (and this tile's stores) at every barrier and
+// serialise the stream.  The tiles only hand LDS data between waves.
 __device__ __forceinline__ void lds_barrier() {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
 }
 
-// LDS images, padded against bank conflicts (modelled per instruction with the lane groups of MI355X_MICROARCH.md "LDS";
-// SQ_LDS_BANK_CONFLICT was 57 % of the LDS cycles with +16-byte rows):
-//   W rows + 32 B: a ds_read_b128 lane group mixes 8 rows of k-group a with 8 rows of k-group a + 1; a row pitch of
-//                  2 slots (mod 16) keeps their 16-byte slots apart (pitch of 1 slot: one 2-way conflict per group).
-//   U [16 s][heads][64 c]: query rows + 16 B (the MFMA result is written with the query on the lane); in the forward
-//                  the head rows are read as the B operand with the HEAD on the lane: head pitch 128 + 16 B.
-__host__ __device__ __forceinline__ int wrow_bytes(int C) { return C * 2 + 32; }              // Wk^T slice: [64 c][C (h,dd)]
-template <int HPAD> __host__ __device__ __forceinline__ int urow_bytes(int heads) { return heads * (CH * 2 + HPAD) + 16; }
+// Which (channel chunk, query range) a workgroup owns: 256 workgroups of 512 threads, one per CU; id -> (chunk id % nchunk,
+// range id / nchunk), 256 / nchunk ranges, the remainder of the ids idle.  (Placing the nchunk owners of a range on one
+// XCD so that they share its q2 / dl / dout reads in one L2 leaves 8 of an XCD's 32 CUs idle for 12 chunks: measured
+// 35.6 vs 35.2 ms per bench step, so the owners are spread.)
+struct Owner { int cc, range, nranges; };
+__device__ __forceinline__ Owner owner_of_block(int nchunk) {
+    const int id = blockIdx.x;
+    Owner o;
+    o.nranges = gridDim.x / nchunk;
+    o.cc = id % nchunk;
+    o.range = id < o.nranges * nchunk ? id / nchunk : -1;
+    return o;
+}
 
-// Wk^T slice of this chunk -> LDS (once per workgroup; register staged: the padded rows rule out LDS-DMA)
-__device__ __forceinline__ void load_w_slice(char* sW, const bf16_t* wkT, int64_t ldw, int cc, int C) {
-    const int pieces = C / 8, wrow = wrow_bytes(C), total = CH * pieces;      // 16-byte pieces per row / in the slice
-    constexpr int UN = 6;                                        // loads in flight per thread (a serial load -> ds_write
-    for (int e0 = threadIdx.x; e0 < total; e0 += UN * blockDim.x) {   // loop costs one L2/HBM round trip per piece)
-        uint4 v[UN];
+// Global loads the compiler does not track (hand-counted s_waitcnt vmcnt, cdna_hip_programming.md 5.7 form (iii)): used
+// for the prefetch rings -- hipcc's own counting of ring loads in these loops ends in vmcnt(0) ladders.
+__device__ __forceinline__ void gload16_asm(bf16x8& dst, const void* p) {
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(p) : "memory");
+}
+__device__ __forceinline__ void gload4_asm(float& dst, const void* p) {
+    asm volatile("global_load_dword %0, %1, off" : "=v"(dst) : "v"(p) : "memory");
+}
+__device__ __forceinline__ void pin(bf16x8& v) { asm volatile("" : "+v"(v)); }
+__device__ __forceinline__ void pin(float& v) { asm volatile("" : "+v"(v)); }
+
+// ---- U images in LDS (conflict degrees from tools/lds_bank_model.py, lane groups of MI355X_MICROARCH.md "LDS") ----
+// forward : U[16 s][heads][64 c], head pitch 128 + 16 B, query pitch + 16 B: read as the MFMA B operand with the HEAD on
+//           the lane (ds_read_b128, 2-way), written with the query on the lane (ds_write_b64, conflict-free).
+// backward: U[16 s][16 h][64 c], head pitch 128 + 8 B, the 8-byte chunks of a row XOR-ed with (s >> 1) & 7: gathered
+//           h-major by ds_read_b64_tr_b16 (conflict-free), written 2-way.  Head rows >= heads are zero.
+constexpr int FWD_HP = CH * 2 + 16;
+__host__ __device__ __forceinline__ int fwd_urow(int heads) { return heads * FWD_HP + 16; }
+constexpr int BWD_HP = CH * 2 + 8, BWD_UROW = MAXH * BWD_HP;
+__device__ __forceinline__ int bwd_off(int s, int h, int chunk) { return s * BWD_UROW + h * BWD_HP + ((chunk ^ ((s >> 1) & 7)) << 3); }
+
+// ---- the chunk's weights stay in REGISTERS ----
+// Wk^T[cc*64 .. +63][all (h,dd)] is 96 KB: as an LDS image every 16-query tile re-read all of it (the LDS array, not
+// HBM, bounded the kernels: 2070 of 8200 cycles per tile in the U product, the rest barrier waits on it).  Split into
+// units (head h, 32-channel half) it is 2 heads x 8 waves ... : wave w holds units w*UPW .. w*UPW+UPW-1 as MFMA A
+// fragments (16 VGPRs per unit), UPW = ceil(2 heads / 8) <= 4, and LDS carries only the U tiles.
+template <int UPW> struct WFrag { bf16x8 v[UPW][2][2]; };             // [unit][16-channel tile of the half][k step]
+template <int UPW> struct NHeads { static constexpr int value = UPW == 3 ? 2 : (UPW + 1) / 2; };   // distinct heads of a wave
+template <int NHW> struct QFrag { bf16x8 v[NHW][2]; };
+
+template <int UPW>
+__device__ __forceinline__ void load_w_frags(WFrag<UPW>& wf, const bf16_t* __restrict__ wkT, int64_t ldw, int cc, int heads,
+                                             int w, int lane) {
+    const int col = lane & 15, kg = lane >> 4;
 #pragma unroll
-        for (int u = 0; u < UN; ++u) {
-            const int e = min(e0 + u * (int)blockDim.x, total - 1);
-            const int row = e / pieces, pc = e - row * pieces;
-            v[u] = *reinterpret_cast<const uint4*>(wkT + (int64_t)(cc * CH + row) * ldw + pc * 8);
-        }
+    for (int k = 0; k < UPW; ++k) {
+        const int u = min(w * UPW + k, 2 * heads - 1), h = u >> 1, half = u & 1;
 #pragma unroll
-        for (int u = 0; u < UN; ++u) {
-            const int e = e0 + u * (int)blockDim.x;
-            if (e < total) {
-                const int row = e / pieces, pc = e - row * pieces;
-                *reinterpret_cast<uint4*>(sW + row * wrow + pc * 16) = v[u];
-            }
-        }
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+                wf.v[k][m][ks] = *reinterpret_cast<const bf16x8*>(wkT + (int64_t)(cc * CH + 32 * half + 16 * m + col) * ldw +
+                                                                 h * CH + 32 * ks + 8 * kg);
     }
 }
 
-// q2 fragments (MFMA B operand: column = query, k = dd) of this wave's heads for the tile starting at row0
-struct QFrag { bf16x8 v[HPW][2]; };
-__device__ __forceinline__ void load_q_frags(QFrag& q, const bf16_t* __restrict__ q2, int row0, int rows, int C, int heads,
-                                             int wg, int lane) {
-    const int col = lane & 15, kg = lane >> 4;
+// q2 fragments (MFMA B operand: column = query, k = dd) of this wave's heads for the tile starting at row0 (ring load)
+template <int UPW>
+__device__ __forceinline__ void load_q_frags(QFrag<NHeads<UPW>::value>& q, const bf16_t* __restrict__ q2, int row0, int rows,
+                                             int C, int heads, int w, int lane) {
+    const int col = lane & 15, kg = lane >> 4, hfirst = (w * UPW) >> 1;
     const int64_t qoff = (int64_t)min(row0 + col, rows - 1) * C;  // this lane's query (MFMA column), clamped
 #pragma unroll
-    for (int i = 0; i < HPW; ++i) {
-        const int h = min(wg + 4 * i, heads - 1);
+    for (int i = 0; i < NHeads<UPW>::value; ++i) {
+        const int h = min(hfirst + i, heads - 1);
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-            q.v[i][ks] = *reinterpret_cast<const bf16x8*>(q2 + qoff + h * CH + 32 * ks + 8 * kg);
+        for (int ks = 0; ks < 2; ++ks) gload16_asm(q.v[i][ks], q2 + qoff + h * CH + 32 * ks + 8 * kg);
     }
 }
 
-// U[s][h][c] of one 16-query tile for the heads of this wave (h = wg, wg + 4, ...): U^T = WkT_slice . q2^T per head.
-template <int HPAD>
-__device__ __forceinline__ void compute_u_tile(const char* sW, char* sU, const QFrag& q, int C, int heads, int wg, int lane) {
-    const int wrow = wrow_bytes(C), urow = urow_bytes<HPAD>(heads);
-    const int col = lane & 15, kg = lane >> 4;
+// U[s][h][c] of one 16-query tile for the units of this wave: U^T = WkT_unit . q2_h^T  (M = channels, N = queries, K = dd)
+template <int UPW, bool BWD>
+__device__ __forceinline__ void compute_u_tile(const WFrag<UPW>& wf, const QFrag<NHeads<UPW>::value>& q, char* sU, int urow,
+                                               int heads, int w, int lane) {
+    const int col = lane & 15, kg = lane >> 4, hfirst = (w * UPW) >> 1;
 #pragma unroll
-    for (int i = 0; i < HPW; ++i) {
-        const int h = wg + 4 * i;
-        if (h >= heads) break;
+    for (int k = 0; k < UPW; ++k) {
+        const int u = w * UPW + k;
+        if (u >= 2 * heads) break;
+        const int h = u >> 1, half = u & 1;
+        bf16x8 qa[2];
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt) {
+        for (int ks = 0; ks < 2; ++ks) {
+            if (NHeads<UPW>::value == 1) qa[ks] = q.v[0][ks];
+            else qa[ks] = h != hfirst ? q.v[NHeads<UPW>::value - 1][ks] : q.v[0][ks];
+        }
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                const bf16x8 a = *reinterpret_cast<const bf16x8*>(sW + (16 * mt + col) * wrow + (h * CH + 32 * ks + 8 * kg) * 2);
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, q.v[i][ks], acc, 0, 0, 0);
-            }
-            // acc[r] = U^T[c = 16 mt + 4 kg + r][s = col]
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf.v[k][m][0], qa[0], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf.v[k][m][1], qa[1], acc, 0, 0, 0);
+            // acc[r] = U^T[c = 32 half + 16 m + 4 kg + r][s = col]
             Pk4 p;
 #pragma unroll
             for (int r = 0; r < 4; ++r) p.e[r] = f32_to_bf16(acc[r]);
-            *reinterpret_cast<uint2*>(sU + col * urow + h * (CH * 2 + HPAD) + (16 * mt + 4 * kg) * 2) = p.u;
+            const int mt = 2 * half + m;
+            if (BWD) *reinterpret_cast<uint2*>(sU + bwd_off(col, h, 4 * mt + kg)) = p.u;
+            else *reinterpret_cast<uint2*>(sU + col * urow + h * FWD_HP + (16 * mt + 4 * kg) * 2) = p.u;
         }
     }
 }
 
 // ------------------------------------------------------------------------------------------------
-// forward 1/3: partial logits of one channel chunk.  512 threads = 2 groups of 4 waves; group g streams the tiles
-// t_begin + g, t_begin + g + 2, ... of the workgroup's range with its own U buffer (twice the bytes in flight of one
-// group: with the weight slice in LDS only one workgroup fits a CU, and ~16 KB of x~ per tile against 2-4 us of HBM
-// latency is what bounds the kernel).  A wave's x~ fragments pack 16 / F queries into the 16 MFMA rows.
+// forward 1/3: partial logits of one channel chunk.  512 threads = 8 waves, one workgroup per CU, every wave on every
+// tile: U units (above) -> LDS (double buffered: one barrier per tile) -> wave w contracts the x~ fragment(s) of
+// 16 / F queries against their U rows.  x~ is the MFMA A operand straight from HBM (16 B per lane).
 // ------------------------------------------------------------------------------------------------
-template <int FT>
-__global__ __launch_bounds__(64 * 4 * NGRP) void time2_logits_kernel(const bf16_t* __restrict__ q2, const bf16_t* __restrict__ xt,
-                                                                     const bf16_t* __restrict__ wkT, int64_t ldw,
-                                                                     float* __restrict__ slab, int rows, int heads,
-                                                                     float scale) {
+template <int FT, int UPW>
+__global__ __launch_bounds__(512) void time2_logits_kernel(const bf16_t* __restrict__ q2, const bf16_t* __restrict__ xt,
+                                                           const bf16_t* __restrict__ wkT, int64_t ldw,
+                                                           float* __restrict__ slab, int rows, int heads, float scale) {
     constexpr int QPF = 16 / FT;           // queries per A fragment (rows = (query, frame))
-    constexpr int NFR = 4 / QPF;           // fragments per wave (4 queries per wave); FT = 4: one fragment of 4 queries
-    static_assert(QPF >= 1 && NFR >= 1, "FT in {4, 8, 16}");
+    constexpr int NFR = FT > 8 ? FT / 8 : 1;   // fragments per wave: a tile has FT fragments (F = 4: waves 4..7 have none)
+    constexpr int NHW = NHeads<UPW>::value;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int C = heads * CH, cc = blockIdx.x, nranges = gridDim.y;
+    const Owner own = owner_of_block(heads);
+    if (own.range < 0) return;
+    const int C = heads * CH, cc = own.cc;
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int grp = w >> 2, wg = w & 3;
-    char* sW = smem;
-    char* sU = smem + CH * wrow_bytes(C) + grp * TQ * urow_bytes<16>(heads);
-    const int urow = urow_bytes<16>(heads);
+    const int urow = fwd_urow(heads);
     const int ntiles = (rows + TQ - 1) / TQ;
-    const int t_begin = (int)((int64_t)ntiles * blockIdx.y / nranges), t_end = (int)((int64_t)ntiles * (blockIdx.y + 1) / nranges);
-    load_w_slice(sW, wkT, ldw, cc, C);
-    __syncthreads();
+    const int t_begin = (int)((int64_t)ntiles * own.range / own.nranges), t_end = (int)((int64_t)ntiles * (own.range + 1) / own.nranges);
+    const int niter = t_end - t_begin;
+    WFrag<UPW> wf;
+    load_w_frags<UPW>(wf, wkT, ldw, cc, heads, w, lane);
     const int col = lane & 15, kg = lane >> 4;
     const int qi = col / FT, fl = col % FT;                       // this lane's A row = (query qi of the fragment, frame fl)
     const int hl = col < heads ? col : heads - 1;                 // head of this lane's B column (cols >= heads: duplicates)
+    // Software pipeline: between two barriers a wave forms its U units of tile t + 1 (buffer (it+1) & 1) AND contracts its
+    // x~ fragment of tile t against buffer it & 1 -- two independent chains (MFMA + LDS write | LDS read + MFMA + store)
+    // for the scheduler to overlap; done one after the other with every wave in step the tile time was their sum.
+    // Register rings of XD tiles (a CU needs ~50-100 KB in flight for its share of the HBM rate at 2-4 us of latency; a
+    // tile is 16 KB of x~ + 24..32 KB of q2 fragments): q2 of tile t + 1 and x~ of tile t are consumed together, so the q
+    // ring runs one tile ahead of the x ring.  The ring loads are inline-asm loads with a hand-counted wait: the issue
+    // order is  q0 x0 q1 x1 q2 x2 | q0' | (q1' x0') (q2' x1') ...  with exactly NQ + NX = LPT loads per tile and wave
+    // (unconditional: rows past the end are clamped), and the loads a tile consumes are always followed by 2 LPT younger
+    // ones: s_waitcnt vmcnt((XD-1) * LPT); the stores issued in between only make the wait stricter.
+    constexpr int XD = 3, NX = NFR * 2, LPT = NHW * 2 + NX;
     struct XFrag { bf16x8 v[NFR][2]; };
-    auto load_x = [&](XFrag& x, int row0) __attribute__((always_inline)) {
+    auto load_x = [&](XFrag& x, int t) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < NFR; ++i) {
-            const int64_t row = min(row0 + 4 * wg + QPF * i + qi, rows - 1);
+            const int fi = min(w + 8 * i, FT - 1);
+            const int64_t row = min(t * TQ + QPF * fi + qi, rows - 1);
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
-                x.v[i][ks] = *reinterpret_cast<const bf16x8*>(xt + (row * FT + fl) * C + cc * CH + 32 * ks + 8 * kg);
+            for (int ks = 0; ks < 2; ++ks) gload16_asm(x.v[i][ks], xt + (row * FT + fl) * C + cc * CH + 32 * ks + 8 * kg);
         }
     };
-    const int niter = (t_end - t_begin + NGRP - 1) / NGRP;        // both groups run the same number of barriers
-    // XD tiles of this group stay in flight (a CU needs ~50-100 KB in flight for its share of the HBM rate at 2-4 us
-    // latency; a tile is 16 KB of x~ + 24 KB of q2)
-    constexpr int XD = 3;
-    XFrag xring[XD];
-    QFrag qring[XD];
-    // The ring loads are UNCONDITIONAL (rows past the end are clamped to the last row, tiles past the range re-read it):
-    // with loads under an `if` hipcc cannot count how many are outstanding and drains s_waitcnt vmcnt(0) at every use,
-    // which empties the ring each iteration (seen in the ISA: vmcnt(11) .. vmcnt(0) ladders).
+    auto pin_q = [&](QFrag<NHW>& q) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < NHW; ++i) { pin(q.v[i][0]); pin(q.v[i][1]); }
+    };
+    auto pin_x = [&](XFrag& x) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < NFR; ++i) { pin(x.v[i][0]); pin(x.v[i][1]); }
+    };
+    QFrag<NHW> qr[XD];
+    XFrag xr[XD];
 #pragma unroll
     for (int k = 0; k < XD; ++k) {
-        load_q_frags(qring[k], q2, (t_begin + grp + NGRP * k) * TQ, rows, C, heads, wg, lane);
-        load_x(xring[k], (t_begin + grp + NGRP * k) * TQ);
+        load_q_frags<UPW>(qr[k], q2, (t_begin + k) * TQ, rows, C, heads, w, lane);
+        load_x(xr[k], t_begin + k);
+    }
+    if (niter > 0) {                                              // U of the first tile
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((XD - 1) * LPT + NX) : "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        pin_q(qr[0]);
+        compute_u_tile<UPW, false>(wf, qr[0], smem, urow, heads, w, lane);
+        asm volatile("" ::: "memory");
+        pin_q(qr[0]);
+        load_q_frags<UPW>(qr[0], q2, (t_begin + XD) * TQ, rows, C, heads, w, lane);
+        lds_barrier();
     }
     for (int itb = 0; itb < niter; itb += XD) {
 #pragma unroll
       for (int k = 0; k < XD; ++k) {
+        const int k1 = (k + 1) % XD;                              // (static after unrolling)
         const int it = itb + k;
         if (it >= niter) break;
-        const int t = t_begin + NGRP * it + grp;
-        const bool live = t < t_end;
-        const int row0 = t * TQ;
-        const XFrag xa = xring[k];
-        const QFrag qa = qring[k];
-        // q2 (19 MB, re-read by the 12 chunk owners: L2 / Infinity Cache, not "free") rides the same ring as x~
-        load_q_frags(qring[k], q2, row0 + NGRP * XD * TQ, rows, C, heads, wg, lane);
-        load_x(xring[k], row0 + NGRP * XD * TQ);
-        if (live) compute_u_tile<16>(sW, sU, qa, C, heads, wg, lane);
-        lds_barrier();
-        if (live) {
+        const int t = t_begin + it, row0 = t * TQ;
+        const char* sU = smem + (it & 1) * (TQ * urow);
+        char* sUn = smem + ((it + 1) & 1) * (TQ * urow);
+        // the contraction's B operands first: their LDS latency passes under the U product
+        bf16x8 ub[NFR][QPF][2];
 #pragma unroll
-            for (int i = 0; i < NFR; ++i) {
-                f32x4 acc[QPF];
+        for (int i = 0; i < NFR; ++i) {
+            const int fi = min(w + 8 * i, FT - 1);
 #pragma unroll
-                for (int j = 0; j < QPF; ++j) {
-                    const int sq = 4 * wg + QPF * i + j;          // query of the tile whose U is the B operand
-                    acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            for (int j = 0; j < QPF; ++j)
 #pragma unroll
-                    for (int ks = 0; ks < 2; ++ks) {
-                        const bf16x8 ub = *reinterpret_cast<const bf16x8*>(sU + sq * urow + hl * (CH * 2 + 16) + (32 * ks + 8 * kg) * 2);
-                        acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xa.v[i][ks], ub, acc[j], 0, 0, 0);
-                    }
-                }
-                // lane (col = head, kg): output rows 4 kg .. 4 kg + 3 = frames (4 kg) % FT .. of query (4 kg) / FT of the fragment
-                const int jq = (4 * kg) / FT, f0 = (4 * kg) % FT;
-                f32x4 v = acc[0];
+                for (int ks = 0; ks < 2; ++ks)
+                    ub[i][j][ks] = *reinterpret_cast<const bf16x8*>(sU + (QPF * fi + j) * urow + hl * FWD_HP + (32 * ks + 8 * kg) * 2);
+        }
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((XD - 1) * LPT) : "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        pin_q(qr[k1]);
+        pin_x(xr[k]);
+        if (it + 1 < niter) compute_u_tile<UPW, false>(wf, qr[k1], sUn, urow, heads, w, lane);
+        f32x4 res[NFR];
 #pragma unroll
-                for (int j = 1; j < QPF; ++j)
-                    if (jq == j) v = acc[j];
-                const int row = row0 + 4 * wg + QPF * i + jq;
-                if (row < rows && col < heads) {
-                    float4 o = make_float4(v[0] * scale, v[1] * scale, v[2] * scale, v[3] * scale);
-                    *reinterpret_cast<float4*>(slab + (((int64_t)cc * rows + row) * heads + col) * FT + f0) = o;
-                }
+        for (int i = 0; i < NFR; ++i) {
+            f32x4 acc[QPF];
+#pragma unroll
+            for (int j = 0; j < QPF; ++j) {                       // query QPF fi + j of the tile: its U is the B operand
+                acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks)
+                    acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xr[k].v[i][ks], ub[i][j][ks], acc[j], 0, 0, 0);
+            }
+            // lane (col = head, kg): output rows 4 kg .. 4 kg + 3 = frames (4 kg) % FT .. of query (4 kg) / FT of the fragment
+            res[i] = acc[0];
+#pragma unroll
+            for (int j = 1; j < QPF; ++j)
+                if ((4 * kg) / FT == j) res[i] = acc[j];
+        }
+        // q slot k1 and x slot k are consumed (their MFMAs have been issued): refill them, then store
+        asm volatile("" ::: "memory");
+        pin_q(qr[k1]);
+        pin_x(xr[k]);
+        load_q_frags<UPW>(qr[k1], q2, (t + 1 + XD) * TQ, rows, C, heads, w, lane);
+        load_x(xr[k], t + XD);
+#pragma unroll
+        for (int i = 0; i < NFR; ++i) {
+            const int fi = w + 8 * i;
+            const int jq = (4 * kg) / FT, f0 = (4 * kg) % FT;
+            const int row = row0 + QPF * fi + jq;
+            if (fi < FT && row < rows && col < heads) {
+                const f32x4 v = res[i];
+                float4 o = make_float4(v[0] * scale, v[1] * scale, v[2] * scale, v[3] * scale);
+                *reinterpret_cast<float4*>(slab + (((int64_t)cc * rows + row) * heads + col) * FT + f0) = o;
             }
         }
-        lds_barrier();                                           // U tile is free for the next tile
+        lds_barrier();                                           // one barrier per tile: U(t+1) complete, U(t) free
       }
     }
+    // the ring loads of the tiles past the end are still in flight and hipcc does not know: drain them before anything
+    // below may reuse their destination registers (an address register overwritten by a late load faults)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
 // forward 2/3: sum the chunk slabs, softmax over the frames -> attn2 [row][h][F]
@@ -372,112 +441,175 @@ __global__ __launch_bounds__(256) void time2_dlg_kernel(const bf16_t* __restrict
 }
 
 // ------------------------------------------------------------------------------------------------
-// backward 2/2: dx~ for one channel chunk (recomputes U on chip like the forward; same two-group stream)
+// backward 2/2: dx~ for one channel chunk.  U is recomputed on chip like the forward; the contraction over the heads
+//     dx~[s,f,c] = a[s,f,h(c)] dout[s,c] + sum_h dl[s,f,h] U[s,h,c]
+// is an MFMA with M = channels, N = (query, frame) columns, K = (query j' of the column tile, head): the B operand is
+// dl masked to its own query (block diagonal, read from HBM in operand layout), the A operand is U^T gathered h-major
+// from the [s][h][c] image by ds_read_b64_tr_b16.  M row 4 p + e of tile mt is channel 16 p + 4 mt + e, so a lane ends
+// with 16 consecutive channels of one (query, frame) row: two 16-byte stores, two 16-byte dout loads.
 // ------------------------------------------------------------------------------------------------
-template <int FT>
-__global__ __launch_bounds__(64 * 4 * NGRP) void time2_dx_kernel(const bf16_t* __restrict__ q2, const bf16_t* __restrict__ xt,
-                                                                  const bf16_t* __restrict__ wkT, int64_t ldw,
-                                                                  const float* __restrict__ attn2, const bf16_t* __restrict__ dl,
-                                                                  const bf16_t* __restrict__ dout, int64_t dobs,
-                                                                  bf16_t* __restrict__ dxt, int rows, int S, int heads) {
-    constexpr int NTASK = FT / 2;          // dx~ tasks (query, frame, 8 channels) per thread: 16 * FT * 8 / 256
-    constexpr int DLB = TQ * FT * MAXH * 2;    // bytes of a tile's dl block (bf16): 16 * FT * 16 * 2
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int C = heads * CH, cc = blockIdx.x, nranges = gridDim.y;
-    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int grp = w >> 2, wg = w & 3, gt = tid & 255;            // group, wave in group, thread in group
-    char* sW = smem;
-    char* sU = sW + CH * wrow_bytes(C) + grp * (TQ * urow_bytes<0>(heads) + DLB);
-    bf16_t* sDL = reinterpret_cast<bf16_t*>(sU + TQ * urow_bytes<0>(heads));   // [16 s][FT][MAXH] dl (bf16)
-    const int urow = urow_bytes<0>(heads);
-    const int ntiles = (rows + TQ - 1) / TQ;
-    const int t_begin = (int)((int64_t)ntiles * blockIdx.y / nranges), t_end = (int)((int64_t)ntiles * (blockIdx.y + 1) / nranges);
-    load_w_slice(sW, wkT, ldw, cc, C);
-    __syncthreads();
-    // dx~ tasks: e = gt + 256 i -> 8-channel group e & 7, (query, frame) = e >> 3
-    const int c8 = gt & 7;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+union TrFrag { bf16x8 v; s16x4 t[2]; };
 
-    // every global operand of a tile (dout rows and a of the dx~ tasks, the dl block, q2 fragments) is loaded one tile
-    // ahead, before the current tile's stores are issued (loads and stores retire in order on one counter)
-    constexpr int NPC = DLB / 16, NDP = (NPC + 255) / 256;        // 16-byte pieces of the dl block; per thread
-    struct In { uint4 dv[NTASK]; float av[NTASK]; uint4 dlp[NDP]; QFrag q; };
-    auto load_in = [&](In& in, int row0) __attribute__((always_inline)) {
-        const int npieces = (min(row0 + TQ, rows) - row0) * FT * 2;           // valid 16-byte pieces of the dl block
+template <int FT, int UPW>
+__global__ __launch_bounds__(512) void time2_dx_kernel(const bf16_t* __restrict__ q2, const bf16_t* __restrict__ wkT, int64_t ldw,
+                                                       const float* __restrict__ attn2, const bf16_t* __restrict__ dl,
+                                                       const bf16_t* __restrict__ dout, int64_t dobs,
+                                                       bf16_t* __restrict__ dxt, int rows, int S, int heads) {
+    constexpr int QPF = 16 / FT;           // queries per column tile (columns = (query, frame))
+    constexpr int NNT = FT > 8 ? FT / 8 : 1;   // column tiles per wave: a tile of 16 queries has FT of them
+    constexpr int KS = QPF > 2 ? QPF / 2 : 1;  // k steps: K = QPF queries x 16 heads (F = 16: the upper 16 slots are zero)
+    constexpr int NHW = NHeads<UPW>::value;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const Owner own = owner_of_block(heads);
+    if (own.range < 0) return;
+    const int C = heads * CH, cc = own.cc;
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ntiles = (rows + TQ - 1) / TQ;
+    const int t_begin = (int)((int64_t)ntiles * own.range / own.nranges), t_end = (int)((int64_t)ntiles * (own.range + 1) / own.nranges);
+    const int niter = t_end - t_begin;
+    WFrag<UPW> wf;
+    load_w_frags<UPW>(wf, wkT, ldw, cc, heads, w, lane);
+    for (int e = tid; e < 2 * TQ * BWD_UROW / 16; e += 512)         // head rows >= heads stay zero (their dl is zero, but
+        reinterpret_cast<uint4*>(smem)[e] = make_uint4(0, 0, 0, 0);   // 0 x garbage must not be NaN)
+    __syncthreads();
+    const int col = lane & 15, kg = lane >> 4;
+    const int j = col / FT, f = col % FT;                          // this lane's output column = (query j of the tile, frame f)
+    const int hb = QPF >= 2 ? 8 * (kg >> 1) : 8 * (kg & 1);        // heads hb .. hb + 7 in this lane group's k slots
+    const int tq = (lane & 15) >> 2, tp = lane & 3;                // transposed read: this lane supplies head row tq, channels 16 tp ..
+
+    // pipeline and rings as in time2_logits_kernel: U of tile t + 1 and the dx~ product of tile t share a barrier interval
+    struct DFrag { bf16x8 dl[NNT]; float a[NNT]; bf16x8 dout[NNT][2]; };
+    constexpr int XD = FT > 8 ? 2 : 3, NX = NNT * 4, LPT = NHW * 2 + NX;   // (F = 16: a third slot would spill, and a
+                                                                         // spilled ring register is stored before its load lands)
+    auto load_d = [&](DFrag& x, int t) __attribute__((always_inline)) {
 #pragma unroll
-        for (int j = 0; j < NDP; ++j)
-            in.dlp[j] = *reinterpret_cast<const uint4*>(dl + (int64_t)row0 * FT * MAXH + min(gt + 256 * j, npieces - 1) * 8);
-        load_q_frags(in.q, q2, row0, rows, C, heads, wg, lane);
-#pragma unroll
-        for (int i = 0; i < NTASK; ++i) {
-            const int sf = (gt + 256 * i) >> 3;
-            const int row = min(row0 + sf / FT, rows - 1);
+        for (int i = 0; i < NNT; ++i) {
+            const int nt = min(w + 8 * i, FT - 1);
+            const int row = min(t * TQ + QPF * nt + j, rows - 1);
             const int b = row / S;
-            in.av[i] = attn2[((int64_t)row * heads + cc) * FT + sf % FT];
-            in.dv[i] = *reinterpret_cast<const uint4*>(dout + b * dobs + (int64_t)(row - b * S) * C + cc * CH + c8 * 8);
+            gload16_asm(x.dl[i], dl + ((int64_t)row * FT + f) * MAXH + hb);
+            gload4_asm(x.a[i], attn2 + ((int64_t)row * heads + cc) * FT + f);
+            const bf16_t* dp = dout + b * dobs + (int64_t)(row - b * S) * C + cc * CH + 16 * kg;
+            gload16_asm(x.dout[i][0], dp);
+            gload16_asm(x.dout[i][1], dp + 8);
         }
     };
-    const int niter = (t_end - t_begin + NGRP - 1) / NGRP;
-    In nx;
-    load_in(nx, min((t_begin + grp) * TQ, rows - 1));               // unconditional loads: see time2_logits_kernel
-    for (int it = 0; it < niter; ++it) {
-        const int t = t_begin + NGRP * it + grp;
-        const bool live = t < t_end;
-        const int row0 = t * TQ;
-        const In in = nx;
-        load_in(nx, min(row0 + NGRP * TQ, rows - 1));
-        if (live) {
+    auto pin_q = [&](QFrag<NHW>& q) __attribute__((always_inline)) {
 #pragma unroll
-            for (int j = 0; j < NDP; ++j)
-                if (gt + 256 * j < NPC) reinterpret_cast<uint4*>(sDL)[gt + 256 * j] = in.dlp[j];
-            compute_u_tile<0>(sW, sU, in.q, C, heads, wg, lane);
-        }
+        for (int i = 0; i < NHW; ++i) { pin(q.v[i][0]); pin(q.v[i][1]); }
+    };
+    auto pin_d = [&](DFrag& x) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < NNT; ++i) { pin(x.dl[i]); pin(x.a[i]); pin(x.dout[i][0]); pin(x.dout[i][1]); }
+    };
+    QFrag<NHW> qr[XD];
+    DFrag dr[XD];
+#pragma unroll
+    for (int k = 0; k < XD; ++k) {
+        load_q_frags<UPW>(qr[k], q2, (t_begin + k) * TQ, rows, C, heads, w, lane);
+        load_d(dr[k], t_begin + k);
+    }
+    if (niter > 0) {                                              // U of the first tile
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((XD - 1) * LPT + NX) : "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        pin_q(qr[0]);
+        compute_u_tile<UPW, true>(wf, qr[0], smem, 0, heads, w, lane);
+        asm volatile("" ::: "memory");
+        pin_q(qr[0]);
+        load_q_frags<UPW>(qr[0], q2, (t_begin + XD) * TQ, rows, C, heads, w, lane);
         lds_barrier();
-        if (live) {
-            // ---- dx~[s,f,c] = a[s,f,cc] dout[s,c] + sum_h dl[s,f,h] U[s,h,c] : task = (s, f, 8 channels) ----
+    }
+    for (int itb = 0; itb < niter; itb += XD) {
 #pragma unroll
-            for (int i = 0; i < NTASK; ++i) {
-                const int sf = (gt + 256 * i) >> 3, f = sf % FT, sq = sf / FT;
-                const int row = row0 + sq;
-                float dv[8], v[8], dlv[16];
-                unpack8(in.dv[i], dv);
+      for (int k = 0; k < XD; ++k) {
+        const int k1 = (k + 1) % XD;                              // (static after unrolling)
+        const int it = itb + k;
+        if (it >= niter) break;
+        const int t = t_begin + it, row0 = t * TQ;
+        const char* sU = smem + (it & 1) * (TQ * BWD_UROW);
+        char* sUn = smem + ((it + 1) & 1) * (TQ * BWD_UROW);
+        // the A operands (U^T of this tile, gathered h-major) first: their LDS latency passes under the U product
+        TrFrag af[NNT][KS][4];
 #pragma unroll
-                for (int k = 0; k < 8; ++k) v[k] = in.av[i] * dv[k];
-                const uint4* dlr = reinterpret_cast<const uint4*>(sDL + (sq * FT + f) * MAXH);
-                unpack8(dlr[0], dlv);
-                unpack8(dlr[1], dlv + 8);
+        for (int i = 0; i < NNT; ++i) {
+            const int nt = min(w + 8 * i, FT - 1);
 #pragma unroll
-                for (int h = 0; h < MAXH; ++h) {
-                    if (h >= heads) break;
-                    float uv[8];
-                    unpack8(*reinterpret_cast<const uint4*>(sU + sq * urow + h * (CH * 2) + c8 * 16), uv);
+            for (int ks = 0; ks < KS; ++ks) {
+                const int jp = QPF >= 2 ? (kg & 1) + 2 * ks : 0;  // query of this lane group's k slots
+                const int sa = QPF * nt + jp;
 #pragma unroll
-                    for (int k = 0; k < 8; ++k) v[k] = fmaf(dlv[h], uv[k], v[k]);
+                for (int mt = 0; mt < 4; ++mt) {
+                    af[i][ks][mt].t[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(sU + bwd_off(sa, hb + tq, 4 * tp + mt)));
+                    af[i][ks][mt].t[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(sU + bwd_off(sa, hb + 4 + tq, 4 * tp + mt)));
                 }
-                if (row < rows) *reinterpret_cast<uint4*>(dxt + ((int64_t)row * FT + f) * C + cc * CH + c8 * 8) = pack8(v);
             }
         }
-        lds_barrier();                                           // U / dl tiles are free for the next tile
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((XD - 1) * LPT) : "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        pin_q(qr[k1]);
+        pin_d(dr[k]);
+        if (it + 1 < niter) compute_u_tile<UPW, true>(wf, qr[k1], sUn, 0, heads, w, lane);
+        uint4 o[NNT][2];
+#pragma unroll
+        for (int i = 0; i < NNT; ++i) {
+            f32x4 acc[4];
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) acc[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const int jp = QPF >= 2 ? (kg & 1) + 2 * ks : 0;
+                const bool keep = QPF >= 2 ? jp == j : kg < 2;
+                bf16x8 bfr = dr[k].dl[i];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) bfr[e] = keep ? bfr[e] : (__bf16)0.f;
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt)
+                    acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i][ks][mt].v, bfr, acc[mt], 0, 0, 0);
+            }
+            // lane (col = (j, f), kg): acc[mt][r] = channel 16 kg + 4 mt + r of row (j, f)
+            float dv[16], v[16];
+            unpack8(*reinterpret_cast<const uint4*>(&dr[k].dout[i][0]), dv);
+            unpack8(*reinterpret_cast<const uint4*>(&dr[k].dout[i][1]), dv + 8);
+            const float av = dr[k].a[i];
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[4 * mt + r] = fmaf(av, dv[4 * mt + r], acc[mt][r]);
+            o[i][0] = pack8(v);
+            o[i][1] = pack8(v + 8);
+        }
+        asm volatile("" ::: "memory");
+        pin_q(qr[k1]);
+        pin_d(dr[k]);
+        load_q_frags<UPW>(qr[k1], q2, (t + 1 + XD) * TQ, rows, C, heads, w, lane);
+        load_d(dr[k], t + XD);
+#pragma unroll
+        for (int i = 0; i < NNT; ++i) {
+            const int nt = w + 8 * i;
+            const int row = row0 + QPF * nt + j;
+            if (nt < FT && row < rows) {
+                uint4* dp = reinterpret_cast<uint4*>(dxt + ((int64_t)row * FT + f) * C + cc * CH + 16 * kg);
+                dp[0] = o[i][0];
+                dp[1] = o[i][1];
+            }
+        }
+        lds_barrier();                                           // one barrier per tile: U(t+1) complete, U(t) free
+      }
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // late ring loads: see time2_logits_kernel
 }
 
-size_t time2_lds_fwd(int heads) { return (size_t)CH * wrow_bytes(heads * CH) + (size_t)NGRP * TQ * urow_bytes<16>(heads); }
-size_t time2_lds_bwd(int heads, int F) {
-    return (size_t)CH * wrow_bytes(heads * CH) + (size_t)NGRP * (TQ * urow_bytes<0>(heads) + TQ * F * MAXH * 2);
-}
-
-int ranges_for(int nchunk, int64_t rows) {
-    int r = 256 / nchunk;                                          // one workgroup per CU
-    const int64_t ntiles = (rows + TQ - 1) / TQ;
-    if (r > ntiles) r = (int)ntiles;
-    return r < 1 ? 1 : r;
-}
+size_t time2_lds_fwd(int heads) { return (size_t)2 * TQ * fwd_urow(heads); }
+size_t time2_lds_bwd() { return (size_t)2 * TQ * BWD_UROW; }
 
 }  // namespace
 
 bool focus_traj_time2_ok(int F, int heads, int d, int dtype) {
     static const bool enabled = !(getenv("FOCUS_TIME2") && atoi(getenv("FOCUS_TIME2")) == 0);
     return enabled && dtype == FOCUS_BF16 && d == CH && heads >= 1 && heads <= MAXH && (F == 4 || F == 8 || F == 16) &&
-           time2_lds_bwd(heads, F) <= 160 * 1024 && time2_lds_fwd(heads) <= 160 * 1024;
+           time2_lds_fwd(heads) <= 160 * 1024;
 }
 
 extern "C" size_t focus_traj_time2_workspace_bytes(int B, int S, int F, int heads, int d) {
@@ -502,12 +634,14 @@ extern "C" int focus_traj_time2_fwd(const void* q2, const void* xt, const void* 
     const int nchunk = C / CH;
     const size_t lds = time2_lds_fwd(heads);
     const float scale = 1.f / sqrtf((float)d);
-    dim3 grid(nchunk, ranges_for(nchunk, rows));
-#define TL(FT) do { \
-        static bool once_##FT = (hipFuncSetAttribute((const void*)time2_logits_kernel<FT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess); \
-        (void)once_##FT; \
-        hipLaunchKernelGGL((time2_logits_kernel<FT>), grid, dim3(64 * 4 * NGRP), lds, s, (const bf16_t*)q2, (const bf16_t*)xt, (const bf16_t*)wkT, ldw, (float*)ws, (int)rows, heads, scale); } while (0)
-    if (F == 8) TL(8); else if (F == 4) TL(4); else TL(16);
+    const int upw = (2 * heads + 7) / 8;                          // weight units per wave (see WFrag)
+#define TL(FT, UPW) do { \
+        static bool once = (hipFuncSetAttribute((const void*)time2_logits_kernel<FT, UPW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess); \
+        (void)once; \
+        hipLaunchKernelGGL((time2_logits_kernel<FT, UPW>), dim3(256), dim3(512), lds, s, (const bf16_t*)q2, (const bf16_t*)xt, (const bf16_t*)wkT, ldw, (float*)ws, (int)rows, heads, scale); } while (0)
+#define TLU(FT) do { if (upw == 1) TL(FT, 1); else if (upw == 2) TL(FT, 2); else if (upw == 3) TL(FT, 3); else TL(FT, 4); } while (0)
+    if (F == 8) TLU(8); else if (F == 4) TLU(4); else TLU(16);
+#undef TLU
 #undef TL
     FOCUS_CHECK_LAUNCH();
     const int64_t n = rows * heads;
@@ -547,13 +681,15 @@ extern "C" int focus_traj_time2_bwd(const void* q2, const void* xt, const void* 
 #undef TD
         FOCUS_CHECK_LAUNCH();
     }
-    const size_t lds = time2_lds_bwd(heads, F);
-    dim3 grid(nchunk, ranges_for(nchunk, rows));
-#define TB(FT) do { \
-        static bool once_##FT = (hipFuncSetAttribute((const void*)time2_dx_kernel<FT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess); \
-        (void)once_##FT; \
-        hipLaunchKernelGGL((time2_dx_kernel<FT>), grid, dim3(64 * 4 * NGRP), lds, s, (const bf16_t*)q2, (const bf16_t*)xt, (const bf16_t*)wkT, ldw, attn2, (const bf16_t*)dl, (const bf16_t*)dout, dout_bstride, (bf16_t*)dxt, (int)rows, S, heads); } while (0)
-    if (F == 8) TB(8); else if (F == 4) TB(4); else TB(16);
+    const size_t lds = time2_lds_bwd();
+    const int upw = (2 * heads + 7) / 8;
+#define TB(FT, UPW) do { \
+        static bool once = (hipFuncSetAttribute((const void*)time2_dx_kernel<FT, UPW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess); \
+        (void)once; \
+        hipLaunchKernelGGL((time2_dx_kernel<FT, UPW>), dim3(256), dim3(512), lds, s, (const bf16_t*)q2, (const bf16_t*)wkT, ldw, attn2, (const bf16_t*)dl, (const bf16_t*)dout, dout_bstride, (bf16_t*)dxt, (int)rows, S, heads); } while (0)
+#define TBU(FT) do { if (upw == 1) TB(FT, 1); else if (upw == 2) TB(FT, 2); else if (upw == 3) TB(FT, 3); else TB(FT, 4); } while (0)
+    if (F == 8) TBU(8); else if (F == 4) TBU(4); else TBU(16);
+#undef TBU
 #undef TB
     FOCUS_CHECK_LAUNCH();
     return FOCUS_OK;

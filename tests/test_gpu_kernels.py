@@ -276,7 +276,8 @@ def test_slot_attention_kernels_tight():
     ck.done()
 
 
-@pytest.mark.parametrize("F_,heads,S", [(8, 12, 1568), (4, 2, 100), (16, 3, 50)])
+@pytest.mark.parametrize("F_,heads,S", [(8, 12, 1568), (4, 2, 100), (16, 3, 50), (8, 16, 43), (8, 6, 33), (4, 11, 37),
+                                        (16, 16, 21), (8, 1, 70)])
 def test_time2_kernels_tight(F_, heads, S):
     """The k2-free temporal step (time2_logits / softmax / out, time2_dl / bwd + the two batched GEMMs over g):
     out, d(q2), d(x~), d(Wk) and the exact zeros of the dead proj_kv parts, against fp64 on the same bf16 values."""
