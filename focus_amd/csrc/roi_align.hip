@@ -55,13 +55,14 @@ __device__ __forceinline__ Nbr locate(float y, float x, int H, int W) {
 
 // grid: (PH, K); block 256 threads sweep (pw, channel-quad) of one output row of one RoI.
 template <typename T>
-__global__ __launch_bounds__(256) void roi_fwd_kernel(const T* __restrict__ feat, int64_t img_stride,
-                                                      const float* __restrict__ rois,
+__global__ __launch_bounds__(256) void roi_fwd_kernel(const T* __restrict__ feat, int64_t img_stride, int ipb,
+                                                      int64_t batch_stride, const float* __restrict__ rois,
                                                       const int32_t* __restrict__ roi_img, T* __restrict__ out, int C,
                                                       int H, int W, int PH, int PW, float scale, int sr, int aligned) {
     const int k = blockIdx.y, ph = blockIdx.x;
     const Geom g = roi_geometry(rois + 4 * k, scale, PH, PW, sr, aligned);
-    const T* img = feat + (int64_t)roi_img[k] * img_stride;
+    const int ri = roi_img[k];
+    const T* img = feat + (int64_t)(ri / ipb) * batch_stride + (int64_t)(ri % ipb) * img_stride;
     const int cq = C >> 2;
     for (int it = threadIdx.x; it < PW * cq; it += 256) {
         const int pw = it / cq, c = (it % cq) * 4;
@@ -147,6 +148,7 @@ __device__ __forceinline__ void locate1(float v, int L, int* low, int* high, flo
 template <typename T>
 __global__ __launch_bounds__(1024) void roi_bwd_sep_kernel(const T* __restrict__ dout, const float* __restrict__ rois,
                                                            const int32_t* __restrict__ roi_img, T* __restrict__ dfeat,
+                                                           int64_t img_stride, int ipb, int64_t batch_stride,
                                                            int C, int H, int W, int K, int PH, int PW, float scale,
                                                            int sr, int aligned) {
     extern __shared__ __attribute__((aligned(16))) float gst[];   // [bins][RB_CS]: dout / count of the current RoI
@@ -233,7 +235,9 @@ __global__ __launch_bounds__(1024) void roi_bwd_sep_kernel(const T* __restrict__
     }
 #pragma unroll
     for (int y = 0; y < RB_HMAX; ++y)
-        if (y < H) st<T>(dfeat + (((int64_t)img * H + y) * W + x) * C + c0 + ch, acc[y]);
+        if (y < H)
+            st<T>(dfeat + (int64_t)(img / ipb) * batch_stride + (int64_t)(img % ipb) * img_stride + (int64_t)(y * W + x) * C + c0 + ch,
+                  acc[y]);
 }
 
 // 1 when the separable kernel takes the shape (else: atomic kernel + cast)
@@ -259,21 +263,22 @@ __global__ void roi_indices_kernel(const float* __restrict__ rois, int32_t* __re
 
 }  // namespace
 
-extern "C" int focus_roi_align_fwd(const void* feat, int64_t img_stride, const float* rois, const int32_t* roi_img,
-                                   void* out, int NI, int C, int H, int W, int K, int PH, int PW, float scale,
-                                   int sr, int aligned, int dtype, void* stream) {
+extern "C" int focus_roi_align_fwd(const void* feat, int64_t img_stride, int imgs_per_batch, int64_t batch_stride,
+                                   const float* rois, const int32_t* roi_img, void* out, int NI, int C, int H, int W,
+                                   int K, int PH, int PW, float scale, int sr, int aligned, int dtype, void* stream) {
     (void)NI;
     if (!feat || !rois || !roi_img || !out) return FOCUS_ERR_NULL;
     if (K <= 0) return FOCUS_OK;
+    if (imgs_per_batch <= 0 || (img_stride & 3) || (batch_stride & 3)) return FOCUS_ERR_SHAPE;
     if ((C & 3) || PH <= 0 || PW <= 0 || K > 65535 * 1024) return FOCUS_ERR_SHAPE;
     if (K > 65535) return FOCUS_ERR_SHAPE;
     dim3 grid(PH, K);
     if (dtype == FOCUS_BF16)
         hipLaunchKernelGGL((roi_fwd_kernel<bf16_t>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)feat,
-                           img_stride, rois, roi_img, (bf16_t*)out, C, H, W, PH, PW, scale, sr, aligned);
+                           img_stride, imgs_per_batch, batch_stride, rois, roi_img, (bf16_t*)out, C, H, W, PH, PW, scale, sr, aligned);
     else
         hipLaunchKernelGGL((roi_fwd_kernel<float>), grid, dim3(256), 0, (hipStream_t)stream, (const float*)feat,
-                           img_stride, rois, roi_img, (float*)out, C, H, W, PH, PW, scale, sr, aligned);
+                           img_stride, imgs_per_batch, batch_stride, rois, roi_img, (float*)out, C, H, W, PH, PW, scale, sr, aligned);
     FOCUS_CHECK_LAUNCH();
     return FOCUS_OK;
 }
@@ -283,21 +288,24 @@ extern "C" size_t focus_roi_align_bwd_workspace_bytes(int NI, int C, int H, int 
     return (size_t)NI * H * W * C * sizeof(float);
 }
 
-extern "C" int focus_roi_align_bwd(const void* dout, const float* rois, const int32_t* roi_img, void* dfeat, void* ws,
+extern "C" int focus_roi_align_bwd(const void* dout, const float* rois, const int32_t* roi_img, void* dfeat,
+                                   int64_t img_stride, int imgs_per_batch, int64_t batch_stride, void* ws,
                                    size_t ws_bytes, int NI, int C, int H, int W, int K, int PH, int PW, float scale,
                                    int sr, int aligned, int dtype, void* stream) {
     if (!dout || !rois || !roi_img || !dfeat) return FOCUS_ERR_NULL;
-    if ((C & 3) || PH <= 0 || PW <= 0 || K > 65535 || NI <= 0 || NI > 65535) return FOCUS_ERR_SHAPE;
+    if ((C & 3) || PH <= 0 || PW <= 0 || K > 65535 || NI <= 0 || NI > 65535 || imgs_per_batch <= 0) return FOCUS_ERR_SHAPE;
+    const bool dense = img_stride == (int64_t)H * W * C && batch_stride == img_stride * imgs_per_batch;
+    if (!dense && !roi_sep_ok(C, H, W, PH, PW)) return FOCUS_ERR_SHAPE;   // the atomic path accumulates into a dense map
     hipStream_t s = (hipStream_t)stream;
     if (roi_sep_ok(C, H, W, PH, PW)) {
         dim3 grid(C / RB_CS, NI), blk(64 * W);
         const size_t lds = (size_t)PH * PW * RB_CS * sizeof(float);
         if (dtype == FOCUS_BF16)
             hipLaunchKernelGGL((roi_bwd_sep_kernel<bf16_t>), grid, blk, lds, s, (const bf16_t*)dout, rois, roi_img,
-                               (bf16_t*)dfeat, C, H, W, K, PH, PW, scale, sr, aligned);
+                               (bf16_t*)dfeat, img_stride, imgs_per_batch, batch_stride, C, H, W, K, PH, PW, scale, sr, aligned);
         else
             hipLaunchKernelGGL((roi_bwd_sep_kernel<float>), grid, blk, lds, s, (const float*)dout, rois, roi_img,
-                               (float*)dfeat, C, H, W, K, PH, PW, scale, sr, aligned);
+                               (float*)dfeat, img_stride, imgs_per_batch, batch_stride, C, H, W, K, PH, PW, scale, sr, aligned);
         FOCUS_CHECK_LAUNCH();
         return FOCUS_OK;
     }

@@ -481,14 +481,16 @@ class _ScaleAddFn(torch.autograd.Function):
     """out = x + scale[b] * y  (per-sample scale: stochastic depth on a residual branch), one pass each way."""
 
     @staticmethod
-    def forward(ctx, x, y, scale):
+    def forward(ctx, x, y, scale, keep):
         _need_gpu(x, y, scale)
         x, y = x.contiguous(), y.contiguous()
         B = x.shape[0]
         per = x.numel() // B
         out = torch.empty_like(x)
-        _lib.check(_lib.lib().focus_scale_add(_p(x), _p(y), _p(scale), _p(out), B, per, _dt(x), _stream()), "scale_add")
+        _lib.check(_lib.lib().focus_scale_add(_p(x), _p(y), _p(scale), keep, _p(out), B, per, _dt(x), _stream()),
+                   "scale_add")
         ctx.save_for_backward(scale)
+        ctx.keep = keep
         return out
 
     @staticmethod
@@ -497,9 +499,9 @@ class _ScaleAddFn(torch.autograd.Function):
         dout = dout.contiguous()
         B = dout.shape[0]
         dy = torch.empty_like(dout)
-        _lib.check(_lib.lib().focus_scale_add(None, _p(dout), _p(scale), _p(dy), B, dout.numel() // B, _dt(dout),
-                                              _stream()), "scale_add_bwd")
-        return dout, dy, None
+        _lib.check(_lib.lib().focus_scale_add(None, _p(dout), _p(scale), ctx.keep, _p(dy), B, dout.numel() // B,
+                                              _dt(dout), _stream()), "scale_add_bwd")
+        return dout, dy, None, None
 
 
 def residual_drop_path(x, y, drop_prob, training):
@@ -507,8 +509,8 @@ def residual_drop_path(x, y, drop_prob, training):
     if drop_prob == 0.0 or not training:
         return x + y
     keep = 1.0 - drop_prob
-    mask = (keep + torch.rand(x.shape[0], dtype=torch.float32, device=x.device)).floor_()
-    return _ScaleAddFn.apply(x, y, mask / keep)
+    # mask = floor(keep + u) and mask / keep are formed inside the kernel from the draws u
+    return _ScaleAddFn.apply(x, y, torch.rand(x.shape[0], dtype=torch.float32, device=x.device), keep)
 
 
 # --------------------------------------------------------------------------------------------------
@@ -898,39 +900,139 @@ def small_attention(q, k, v, heads, scale):
 # RoIAlign, per-RoI max, box layout
 # --------------------------------------------------------------------------------------------------
 class _RoiAlignFn(torch.autograd.Function):
-    """feat_tokens [NI, H*W, C] channels-last (a contiguous tensor); rois [K,4] fp32 xyxy pixels."""
+    """RoIAlign over channels-last token maps.  `feat` is either a dense map [NI, H*W, C] (tok_T == 0) or the residual
+    stream itself [B, 1 + T*H*W, C] (tok_T == T): the maps of image (b, t) are then read in place behind the cls row,
+    and the backward returns a gradient of the stream's shape (cls rows zero) -- no slice copy in, no slice_backward
+    + zero-fill out.  rois [K,4] fp32 xyxy pixels."""
 
     @staticmethod
-    def forward(ctx, feat, rois, roi_img, H, W, PH, PW, scale, sampling_ratio, aligned):
+    def forward(ctx, feat, rois, roi_img, tok_T, H, W, PH, PW, scale, sampling_ratio, aligned):
         _need_gpu(feat, rois, roi_img)
         feat = feat.contiguous()
-        NI, HW, C = feat.shape
-        assert HW == H * W
+        C = feat.shape[-1]
+        if tok_T:
+            B = feat.shape[0]
+            assert feat.shape[1] == 1 + tok_T * H * W
+            NI, ipb, bstride, off = B * tok_T, tok_T, (1 + tok_T * H * W) * C, C
+        else:
+            NI, HW, _ = feat.shape
+            assert HW == H * W
+            ipb, bstride, off = NI, NI * H * W * C, 0
         K = rois.shape[0]
         out = torch.empty(K, PH * PW, C, device=feat.device, dtype=feat.dtype)
-        _lib.check(_lib.lib().focus_roi_align_fwd(_p(feat), HW * C, _p(rois), _p(roi_img), _p(out), NI, C, H, W, K, PH,
-                                                  PW, scale, sampling_ratio, int(aligned), _dt(feat), _stream()),
-                   "roi_align_fwd")
+        _lib.check(_lib.lib().focus_roi_align_fwd(_p(feat, off), H * W * C, ipb, bstride, _p(rois), _p(roi_img), _p(out), NI,
+                                                  C, H, W, K, PH, PW, scale, sampling_ratio, int(aligned), _dt(feat),
+                                                  _stream()), "roi_align_fwd")
         ctx.save_for_backward(rois, roi_img)
-        ctx.args = (NI, C, H, W, K, PH, PW, scale, sampling_ratio, int(aligned), feat.dtype)
+        ctx.args = (NI, C, H, W, K, PH, PW, scale, sampling_ratio, int(aligned), feat.dtype, ipb, bstride, off, feat.shape)
         return out
 
     @staticmethod
     def backward(ctx, dout):
         rois, roi_img = ctx.saved_tensors
-        NI, C, H, W, K, PH, PW, scale, sr, al, dt = ctx.args
+        NI, C, H, W, K, PH, PW, scale, sr, al, dt, ipb, bstride, off, shp = ctx.args
         dout = dout.contiguous()
         L = _lib.lib()
-        dfeat = torch.empty(NI, H * W, C, device=dout.device, dtype=dt)
+        dfeat = torch.empty(shp, device=dout.device, dtype=dt)
+        if off:
+            dfeat[:, 0].zero_()                                   # cls rows: no RoI reads them
         nb = L.focus_roi_align_bwd_workspace_bytes(NI, C, H, W, PH, PW)
         ws = torch.empty(nb // 4, device=dout.device, dtype=torch.float32) if nb else None
-        _lib.check(L.focus_roi_align_bwd(_p(dout), _p(rois), _p(roi_img), _p(dfeat), _p(ws), nb, NI, C, H, W, K, PH, PW,
-                                         scale, sr, al, _dt(dout), _stream()), "roi_align_bwd")
-        return dfeat, None, None, None, None, None, None, None, None, None
+        _lib.check(L.focus_roi_align_bwd(_p(dout), _p(rois), _p(roi_img), _p(dfeat, off), H * W * C, ipb, bstride, _p(ws), nb,
+                                         NI, C, H, W, K, PH, PW, scale, sr, al, _dt(dout), _stream()), "roi_align_bwd")
+        return dfeat, None, None, None, None, None, None, None, None, None, None
 
 
 def roi_align_tokens(feat, rois, roi_img, H, W, PH, PW, spatial_scale, sampling_ratio=-1, aligned=True):
-    return _RoiAlignFn.apply(feat, rois, roi_img, H, W, PH, PW, float(spatial_scale), sampling_ratio, aligned)
+    return _RoiAlignFn.apply(feat, rois, roi_img, 0, H, W, PH, PW, float(spatial_scale), sampling_ratio, aligned)
+
+
+def roi_align_stream(x, rois, roi_img, T, H, W, PH, PW, spatial_scale, sampling_ratio=-1, aligned=True):
+    """RoIAlign of the patch tokens of the residual stream x [B, 1+T*H*W, C], read in place (image index = b*T + t).
+    Shapes whose backward needs the dense atomic path (focus_roi_align_bwd_workspace_bytes > 0) take a dense copy."""
+    B, _, C = x.shape
+    if _lib.lib().focus_roi_align_bwd_workspace_bytes(B * T, C, H, W, PH, PW):
+        return roi_align_tokens(x[:, 1:].reshape(B * T, H * W, C), rois, roi_img, H, W, PH, PW, spatial_scale,
+                                sampling_ratio, aligned)
+    return _RoiAlignFn.apply(x, rois, roi_img, T, H, W, PH, PW, float(spatial_scale), sampling_ratio, aligned)
+
+
+class _OrvitAssembleFn(torch.autograd.Function):
+    """all = cat(cls, per frame [patch tokens, object tokens]) (orvit.py:145-147) and its adjoint, one pass each."""
+
+    @staticmethod
+    def forward(ctx, x, obj, T, HW):
+        _need_gpu(x, obj)
+        x, obj = x.contiguous(), obj.contiguous()
+        B, _, C = x.shape
+        O = obj.shape[2]
+        assert x.shape[1] == 1 + T * HW and obj.shape[:2] == (B, T) and obj.dtype == x.dtype
+        out = torch.empty(B, 1 + T * (HW + O), C, device=x.device, dtype=x.dtype)
+        _lib.check(_lib.lib().focus_orvit_assemble(_p(x), _p(obj), _p(out), B, T, HW, O, C, _dt(x), _stream()),
+                   "orvit_assemble")
+        ctx.args = (B, T, HW, O, C)
+        return out
+
+    @staticmethod
+    def backward(ctx, dall):
+        B, T, HW, O, C = ctx.args
+        dall = dall.contiguous()
+        dx = torch.empty(B, 1 + T * HW, C, device=dall.device, dtype=dall.dtype)
+        dobj = torch.empty(B, T, O, C, device=dall.device, dtype=dall.dtype)
+        _lib.check(_lib.lib().focus_orvit_assemble_bwd(_p(dall), _p(dx), _p(dobj), B, T, HW, O, C, _dt(dall), _stream()),
+                   "orvit_assemble_bwd")
+        return dx, dobj, None, None
+
+
+def orvit_assemble(x, obj, T, HW):
+    """x [B,1+T*HW,C], obj [B,T,O,C] -> [B, 1+T*(HW+O), C]."""
+    return _OrvitAssembleFn.apply(x, obj, T, HW)
+
+
+class _OrvitMergeFn(torch.autograd.Function):
+    """x + s_b * (patch/cls rows of y + [0; mm]) (orvit.py:152-169: slice, reshape copy, motion residual, cat, drop-path,
+    residual add) as one pass; the adjoint writes dy (object rows zero) and dmm, dx is dout itself."""
+
+    @staticmethod
+    def forward(ctx, x, y, mm, draws, keep, T, HW):
+        _need_gpu(x, y)
+        x, y = x.contiguous(), y.contiguous()
+        B, _, C = x.shape
+        O = (y.shape[1] - 1) // T - HW
+        assert y.shape[1] == 1 + T * (HW + O) and x.shape[1] == 1 + T * HW
+        scale = None
+        if draws is not None:                                     # stochastic depth: s_b = floor(keep + u_b) / keep
+            scale = torch.floor(keep + draws) / keep
+        if mm is not None:
+            mm = mm.contiguous()
+        out = torch.empty_like(x)
+        _lib.check(_lib.lib().focus_orvit_merge(_p(x), _p(y), _p(mm) if mm is not None else None,
+                                                _p(scale) if scale is not None else None, _p(out), B, T, HW, O, C, _dt(x),
+                                                _stream()), "orvit_merge")
+        ctx.scale = scale
+        ctx.args = (B, T, HW, O, C, mm is not None)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        B, T, HW, O, C, has_mm = ctx.args
+        dout = dout.contiguous()
+        dy = torch.empty(B, 1 + T * (HW + O), C, device=dout.device, dtype=dout.dtype)
+        dmm = torch.empty(B, T * HW, C, device=dout.device, dtype=dout.dtype) if has_mm else None
+        sc = ctx.scale
+        _lib.check(_lib.lib().focus_orvit_merge_bwd(_p(dout), _p(sc) if sc is not None else None, _p(dy),
+                                                    _p(dmm) if has_mm else None, B, T, HW, O, C, _dt(dout), _stream()),
+                   "orvit_merge_bwd")
+        return dout, dy, dmm, None, None, None, None
+
+
+def orvit_merge(x, y, mm, T, HW, drop_prob=0.0, training=False):
+    """x [B,1+T*HW,C] + drop_path(cat(y[:, :1], patch rows of y + mm)); y [B,1+T*(HW+O),C], mm [B,T*HW,C] or None."""
+    draws = None
+    keep = 1.0 - drop_prob
+    if drop_prob > 0.0 and training:
+        draws = torch.rand(x.shape[0], dtype=torch.float32, device=x.device)
+    return _OrvitMergeFn.apply(x, y, mm, draws, keep, T, HW)
 
 
 def roi_align_indices(rois, H, W, PH, PW, spatial_scale, sampling_ratio=-1, aligned=True):

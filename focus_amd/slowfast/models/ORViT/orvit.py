@@ -74,31 +74,32 @@ class ORViT(nn.Module):
         Tratio = box_tensors.shape[1] // T
         box_tensors = box_tensors[:, ::Tratio].float()                     # [BS,T,O,4]
         O = box_tensors.shape[-2]
-        cls_token, patch_tokens = x[:, :1], x[:, 1:]                      # tokens stay channels-last
+        HW = H * W
 
-        # object tokens: RoIAlign -> patch_to_d -> max over the RoI cells (orvit.py:135-139)
-        crops = self.crop_layer.crop_tokens(patch_tokens, box_tensors, T, H, W)          # [BS*T*O, HW, d]
+        # object tokens: RoIAlign (patch tokens read in place from x) -> patch_to_d -> max over the RoI cells (:135-139)
+        crops = self.crop_layer.crop_stream(x, box_tensors, T, H, W)                        # [BS*T*O, HW, d]
         p2d = self.patch_to_d
         pre = ops.mlp(crops, p2d[0].weight, None, p2d[2].weight, None, act=ops.EPI_RELU)  # last ReLU commutes with max
         obj = torch.relu(ops.cell_amax(pre)).view(BS, T, O, d)
         box_emb = _relu_pair(self.c_coord_to_feature, box_tensors, x.dtype)
         obj = obj + self.box_categories.to(x.dtype) + box_emb                               # :141-143
 
-        all_tokens = torch.cat([patch_tokens.reshape(BS, T, H * W, d), obj], dim=2).flatten(1, 2)
-        all_tokens = torch.cat([cls_token, all_tokens], dim=1)                              # :145-147
+        # :145-147 (two cats) as one pass; :152-169 (slice, reshape copy, motion residual, cat, drop-path, add) as another
+        all_tokens = ops.orvit_assemble(x, obj, T, HW)                                      # [BS, 1+T*(HW+O), d]
         n1 = self.norm1
-        all_tokens, _ = self.attn(ops.layer_norm(all_tokens, n1.weight, n1.bias, n1.eps), [T, H * W + O, 1])
-        cls_token2, all_tokens = all_tokens[:, :1], all_tokens[:, 1:]
-        new_patch = all_tokens.reshape(BS, T, H * W + O, d)[:, :, :H * W].reshape(BS, T * H * W, d)   # :157
-
+        y, _ = self.attn(ops.layer_norm(all_tokens, n1.weight, n1.bias, n1.eps), [T, HW + O, 1])
+        mm = None
         if self.with_motion_stream:
             motion_emb = self.motion_stream(box_tensors, H, W, dtype=x.dtype)                # [BS,T*H*W,d]
-            new_patch = self.motion_mlp(motion_emb, residual=new_patch)                      # :162-163
-        new_tokens = torch.cat([cls_token2, new_patch], dim=1)
-        x = x + self.drop_path(new_tokens)                                                   # :169
+            mm = self.motion_mlp(motion_emb)                                                 # :162-163
+        dp = 0.0 if isinstance(self.drop_path, nn.Identity) else self.drop_path.drop_prob
+        x = ops.orvit_merge(x, y, mm, T, HW, dp, self.training)                              # :169
         n2 = self.norm2
         xr, h = ops.layer_norm_fork(x, n2.weight, n2.bias, n2.eps)
-        x = xr + self.drop_path(self.mlp(h))                                                 # :170
+        if dp == 0.0 or not self.training:
+            x = self.mlp(h, residual=xr)                                                     # :170, add in the fc2 epilogue
+        else:
+            x = ops.residual_drop_path(xr, self.mlp(h), dp, True)
         return x, thw
 
 

@@ -183,21 +183,25 @@ int focus_traj_time2_bwd(const void* q2, const void* xt, const void* wkT, int64_
 /* ------------------------------------------------------------------------------------------------
  * RoIAlign over patch-token feature maps (ORViT/utils.py:58-75 -> torchvision.ops.roi_align with
  * output_size=(H,W), sampling_ratio=-1, aligned=True).  Channels-last on both sides:
- *   feat  [NI, H*W, C] with image stride `img_stride` elements (tokens are read in place from the
- *         residual stream [B,1+T*H*W,C]; the caller passes the pointer to token 1);
+ *   feat  image i = (b, t) = (i / imgs_per_batch, i % imgs_per_batch) starts at feat + b*batch_stride + t*img_stride
+ *         (elements): the tokens are read in place from the residual stream [B,1+T*H*W,C] (pointer to token 1,
+ *         img_stride = H*W*C, imgs_per_batch = T, batch_stride = (1+T*H*W)*C); a dense [NI,H*W,C] map is
+ *         imgs_per_batch = NI, img_stride = H*W*C;
  *   rois  [K,4] fp32 xyxy in input pixels, roi_img [K] int32 image index;
  *   out   [K, PH*PW, C].
  * The integer side (sampling grid size, neighbour indices) is bit-exact with oracle/roi_align_ref.c.
  * ----------------------------------------------------------------------------------------------*/
-int focus_roi_align_fwd(const void* feat, int64_t img_stride, const float* rois, const int32_t* roi_img,
-                        void* out, int NI, int C, int H, int W, int K, int PH, int PW, float spatial_scale,
-                        int sampling_ratio, int aligned, int dtype, void* stream);
-/* dfeat [NI, H*W, C] dense, `dtype`, fully written (no zero-initialisation needed).  Maps up to 16x16 with up to
+int focus_roi_align_fwd(const void* feat, int64_t img_stride, int imgs_per_batch, int64_t batch_stride,
+                        const float* rois, const int32_t* roi_img, void* out, int NI, int C, int H, int W, int K,
+                        int PH, int PW, float spatial_scale, int sampling_ratio, int aligned, int dtype, void* stream);
+/* dfeat: image maps addressed like feat, `dtype`, every map fully written (no zero-initialisation needed; rows between
+ * the maps -- the cls row of a token buffer -- are not touched).  Maps up to 16x16 with up to
  * 14x14 bins use the separable form dfeat = sum_rois Ay . dout . Ax^T (no atomics, accumulators in registers); other
- * shapes go through fp32 atomics into `ws` (focus_roi_align_bwd_workspace_bytes, 0 for the separable path) + a cast. */
+ * shapes go through fp32 atomics into `ws` (focus_roi_align_bwd_workspace_bytes, 0 for the separable path) + a cast
+ * and need the dense addressing (FOCUS_ERR_SHAPE otherwise). */
 size_t focus_roi_align_bwd_workspace_bytes(int NI, int C, int H, int W, int PH, int PW);
-int focus_roi_align_bwd(const void* dout, const float* rois, const int32_t* roi_img, void* dfeat, void* ws,
-                        size_t ws_bytes, int NI, int C, int H, int W, int K, int PH, int PW, float spatial_scale,
+int focus_roi_align_bwd(const void* dout, const float* rois, const int32_t* roi_img, void* dfeat, int64_t img_stride,
+                        int imgs_per_batch, int64_t batch_stride, void* ws, size_t ws_bytes, int NI, int C, int H, int W, int K, int PH, int PW, float spatial_scale,
                         int sampling_ratio, int aligned, int dtype, void* stream);
 /* Debug/parity export of the integer side: grid [K,2], nbr [K,PH,PW,4] (int32). */
 int focus_roi_align_indices(const float* rois, int32_t* grid, int32_t* nbr, int H, int W, int K, int PH,
@@ -209,6 +213,26 @@ int focus_cell_amax_fwd(const void* x, void* y, int32_t* arg, int K, int cells, 
 /* dx [K, cells, C] is fully written (zeros except the arg-max cell). */
 int focus_cell_amax_bwd(const void* dy, const int32_t* arg, void* dx, int K, int cells, int C, int dtype,
                         void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * ORViT token plumbing (ORViT/orvit.py:145-147, :152-157, :165-169), one pass each way instead of cat / slice / add chains.
+ * x   [B, 1+T*HW, C]     residual stream (cls row + patch tokens)
+ * obj [B, T, O, C]       object tokens
+ * all [B, 1+T*(HW+O), C] cls row, then per frame its HW patch tokens followed by its O object tokens
+ * assemble: all = cat(cls, cat(patch.view(B,T,HW,C), obj, dim=2).flatten(1,2)); the adjoint scatters d(all) into
+ *           dx (every row written) and dobj.  Pure row copies: any dtype, C * elem_size % 16 == 0.
+ * merge:    out[b,0] = x[b,0] + s_b*y[b,0];  out[b,1+t*HW+p] = x[..] + s_b*(y[b,1+t*(HW+O)+p] + mm[b,t*HW+p])
+ *           (y = attention output over `all`, mm = motion-stream MLP output or NULL, s = per-sample stochastic-depth
+ *           scale or NULL for 1); adjoint: dy (object rows zero), dmm = s*dout[:,1:] (or NULL); dx is dout itself.
+ * ----------------------------------------------------------------------------------------------*/
+int focus_orvit_assemble(const void* x, const void* obj, void* all, int B, int T, int HW, int O, int C, int dtype,
+                         void* stream);
+int focus_orvit_assemble_bwd(const void* dall, void* dx, void* dobj, int B, int T, int HW, int O, int C, int dtype,
+                             void* stream);
+int focus_orvit_merge(const void* x, const void* y, const void* mm, const float* scale, void* out, int B, int T, int HW,
+                      int O, int C, int dtype, void* stream);
+int focus_orvit_merge_bwd(const void* dout, const float* scale, void* dy, void* dmm, int B, int T, int HW, int O, int C,
+                          int dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Box layout (ORViT/utils.py:8-28 -> layout.py:28-63,98-130,205-237), closed form of SURVEY.md A4:
@@ -289,11 +313,12 @@ int focus_diag_scatter_add(const void* dxdiag, void* dxt, int B, int S, int F, i
  * addressing row 4*g + (l%16)/4, column 4*(l%4), and returns the 4 int16 each lane received: out [64][4]. */
 int focus_debug_tr16_probe(int16_t* out, void* stream);
 
-/* out[b, i] = (x ? x[b, i] : 0) + scale[b] * y[b, i]   for b < B, i < per  (per % 8 == 0).
- * Stochastic depth on a residual branch in one pass (common.py:46-60: x + drop_path(y), scale = mask/keep_prob)
- * and its adjoint (dy = scale * dout with x == NULL). */
-int focus_scale_add(const void* x, const void* y, const float* scale, void* out, int B, int64_t per, int dtype,
-                    void* stream);
+/* out[b, i] = (x ? x[b, i] : 0) + s[b] * y[b, i]   for b < B, i < per  (per % 8 == 0).
+ * Stochastic depth on a residual branch in one pass (common.py:46-60: x + drop_path(y)) and its adjoint (dy = s * dout
+ * with x == NULL).  keep == 0: s = scale.  keep > 0: scale holds the U[0,1) draws and s[b] = floor(keep + scale[b]) / keep
+ * (the reference's mask / keep_prob, formed in the kernel instead of by three elementwise launches). */
+int focus_scale_add(const void* x, const void* y, const float* scale, float keep, void* out, int B, int64_t per,
+                    int dtype, void* stream);
 
 /* dtype conversion (weights shadow copies, gradient casts): n elements. */
 int focus_cast(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t n, void* stream);
