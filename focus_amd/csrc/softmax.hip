@@ -25,6 +25,27 @@ __global__ __launch_bounds__(256) void softmax_fwd_kernel(const T* __restrict__ 
     if (lse && lane == 0) lse[row] = m + __logf(s);
 }
 
+// Causal rows: row r = (.., i) with i = r % period sees keys 0 .. i; the masked tail is written as exact zeros (the
+// reference fills it with -inf before its softmax, transformer.py:41-44), so focus_softmax_bwd needs no mask.
+template <typename T>
+__global__ __launch_bounds__(256) void softmax_causal_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int64_t rows,
+                                                                 int L, int64_t stride, int period, float scale) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int valid = min(L, (int)(row % period) + 1);
+    const T* xr = x + row * stride;
+    T* yr = y + row * stride;
+    float m = -INFINITY;
+    for (int i = lane; i < valid; i += 64) m = fmaxf(m, scale * ld<T>(xr + i));
+    m = wave_max(m);
+    float s = 0.f;
+    for (int i = lane; i < valid; i += 64) s += __expf(scale * ld<T>(xr + i) - m);
+    s = wave_sum(s);
+    const float inv = 1.f / s;
+    for (int i = lane; i < L; i += 64) st<T>(yr + i, i < valid ? __expf(scale * ld<T>(xr + i) - m) * inv : 0.f);
+}
+
 // Recompute probabilities from saved log-sum-exp: y = exp(scale*x - lse).
 template <typename T>
 __global__ __launch_bounds__(256) void softmax_from_lse_kernel(const T* __restrict__ x, T* __restrict__ y,
@@ -88,6 +109,24 @@ extern "C" int focus_softmax_fwd(const void* x, void* y, int64_t rows, int L, in
                                  int dtype, void* stream) {
     if (!x || !y) return FOCUS_ERR_NULL;
     return focus_softmax_fwd_lse(x, y, nullptr, rows, L, stride, scale, dtype, (hipStream_t)stream);
+}
+
+extern "C" int focus_softmax_causal_fwd(const void* x, void* y, int64_t rows, int L, int64_t stride, int period, float scale,
+                                        int dtype, void* stream) {
+    if (!x || !y) return FOCUS_ERR_NULL;
+    if (rows <= 0 || L <= 0) return FOCUS_OK;
+    if (period <= 0) return FOCUS_ERR_SHAPE;
+    const int64_t nb = cdiv64(rows, 4);
+    if (nb > 0x7fffffff) return FOCUS_ERR_SHAPE;
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == FOCUS_BF16)
+        hipLaunchKernelGGL((softmax_causal_fwd_kernel<bf16_t>), dim3((unsigned)nb), dim3(256), 0, s, (const bf16_t*)x,
+                           (bf16_t*)y, rows, L, stride, period, scale);
+    else
+        hipLaunchKernelGGL((softmax_causal_fwd_kernel<float>), dim3((unsigned)nb), dim3(256), 0, s, (const float*)x,
+                           (float*)y, rows, L, stride, period, scale);
+    FOCUS_CHECK_LAUNCH();
+    return FOCUS_OK;
 }
 
 extern "C" int focus_softmax_bwd(const void* dy, const void* y, void* dx, int64_t rows, int L, int64_t stride,

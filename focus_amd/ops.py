@@ -849,51 +849,66 @@ def traj_time2_block(q2, xt, w_kv, b_kv, cls_out, heads):
 # Small joint attention (motion stream: attention.py:369-385; slot predictor: transformer.py:23-49)
 # --------------------------------------------------------------------------------------------------
 class _SmallAttnFn(torch.autograd.Function):
-    """softmax(scale * q k^T) v per head on short sequences; q,k,v [B,N,C] (may be views of one buffer)."""
+    """softmax(scale * q k^T [causal]) [* drop] v per head as strided batched GEMMs + a row softmax; q [B,Nq,C],
+    k, v [B,Nk,C] (may be views of one buffer).  `drop` [B,h,Nq,Nk] is an inverted-dropout mask (already scaled by
+    1/(1-p)) applied to the probabilities (transformer.py:45), or None."""
 
     @staticmethod
-    def forward(ctx, q, k, v, heads, scale):
+    def forward(ctx, q, k, v, heads, scale, causal, drop):
         _need_gpu(q, k, v)
         B, N, C = q.shape
+        M = k.shape[1]
         d = C // heads
         dev, dt = q.device, q.dtype
         q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
-        att = torch.empty(B, heads, N, N, device=dev, dtype=dt)
-        gemm(N, N, d, (q, 0), (C, 1, N * C, d), (k, 0), (1, C, N * C, d), (att, 0), (N, 1, heads * N * N, N * N),
-             batch=(B, heads))
-        _lib.check(_lib.lib().focus_softmax_fwd(_p(att), _p(att), B * heads * N, N, N, scale, _dt(att), _stream()),
-                   "softmax_fwd")
+        att = torch.empty(B, heads, N, M, device=dev, dtype=dt)
+        sa = (M, 1, heads * N * M, N * M)
+        gemm(N, M, d, (q, 0), (C, 1, N * C, d), (k, 0), (1, C, M * C, d), (att, 0), sa, batch=(B, heads))
+        L = _lib.lib()
+        if causal:
+            assert N == M, "causal self-attention"
+            _lib.check(L.focus_softmax_causal_fwd(_p(att), _p(att), B * heads * N, M, M, N, scale, _dt(att), _stream()),
+                       "softmax_causal_fwd")
+        else:
+            _lib.check(L.focus_softmax_fwd(_p(att), _p(att), B * heads * N, M, M, scale, _dt(att), _stream()),
+                       "softmax_fwd")
+        attd = att if drop is None else att * drop
         out = torch.empty(B, N, C, device=dev, dtype=dt)
-        gemm(N, d, N, (att, 0), (N, 1, heads * N * N, N * N), (v, 0), (C, 1, N * C, d), (out, 0), (C, 1, N * C, d),
-             batch=(B, heads))
-        ctx.save_for_backward(q, k, v, att)
+        gemm(N, d, M, (attd, 0), sa, (v, 0), (C, 1, M * C, d), (out, 0), (C, 1, N * C, d), batch=(B, heads))
+        ctx.save_for_backward(q, k, v, att, drop)
         ctx.heads, ctx.scale = heads, scale
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        q, k, v, att = ctx.saved_tensors
+        q, k, v, att, drop = ctx.saved_tensors
         heads, scale = ctx.heads, ctx.scale
         B, N, C = q.shape
+        M = k.shape[1]
         d = C // heads
         dout = dout.contiguous()
-        sa = (N, 1, heads * N * N, N * N)
-        sx = (C, 1, N * C, d)
+        sa = (M, 1, heads * N * M, N * M)
+        sat = (1, M, heads * N * M, N * M)
+        sq = (C, 1, N * C, d)
+        sk = (C, 1, M * C, d)
+        attd = att if drop is None else att * drop
         datt = torch.empty_like(att)
         # dA = dout . v^T ; dV = A^T . dout
-        gemm(N, N, d, (dout, 0), sx, (v, 0), (1, C, N * C, d), (datt, 0), sa, batch=(B, heads))
+        gemm(N, M, d, (dout, 0), sq, (v, 0), (1, C, M * C, d), (datt, 0), sa, batch=(B, heads))
         dv = torch.empty_like(v)
-        gemm(N, d, N, (att, 0), (1, N, heads * N * N, N * N), (dout, 0), sx, (dv, 0), sx, batch=(B, heads))
-        _lib.check(_lib.lib().focus_softmax_bwd(_p(datt), _p(att), _p(datt), B * heads * N, N, N, scale, _dt(att),
+        gemm(M, d, N, (attd, 0), sat, (dout, 0), sq, (dv, 0), sk, batch=(B, heads))
+        if drop is not None:
+            datt = datt * drop
+        _lib.check(_lib.lib().focus_softmax_bwd(_p(datt), _p(att), _p(datt), B * heads * N, M, M, scale, _dt(att),
                                                 _stream()), "softmax_bwd")
         dq, dk = torch.empty_like(q), torch.empty_like(k)
-        gemm(N, d, N, (datt, 0), sa, (k, 0), sx, (dq, 0), sx, batch=(B, heads))
-        gemm(N, d, N, (datt, 0), (1, N, heads * N * N, N * N), (q, 0), sx, (dk, 0), sx, batch=(B, heads))
-        return dq, dk, dv, None, None
+        gemm(N, d, M, (datt, 0), sa, (k, 0), sk, (dq, 0), sq, batch=(B, heads))
+        gemm(M, d, N, (datt, 0), sat, (q, 0), sq, (dk, 0), sk, batch=(B, heads))
+        return dq, dk, dv, None, None, None, None
 
 
-def small_attention(q, k, v, heads, scale):
-    return _SmallAttnFn.apply(q, k, v, heads, scale)
+def small_attention(q, k, v, heads, scale, causal=False, drop=None):
+    return _SmallAttnFn.apply(q, k, v, heads, scale, causal, drop)
 
 
 # --------------------------------------------------------------------------------------------------

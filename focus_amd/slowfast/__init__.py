@@ -15,7 +15,7 @@ def install_as_slowfast():
     for sub in ("config", "config.defaults", "models", "models.build", "models.attention", "models.common",
                 "models.stem_helper", "models.video_model_builder", "models.losses", "models.optimizer",
                 "models.ORViT", "models.ORViT.orvit", "models.ORViT.utils", "models.ORViT.layout",
-                "models.STEVE", "models.STEVE.steve", "models.STEVE.utils", "models.STEVE.transformer",
-                "utils", "utils.box_ops", "utils.distributed", "utils.misc"):
+                "models.STEVE", "models.STEVE.steve", "models.STEVE.utils", "models.STEVE.transformer", "models.STEVE.dvae",
+                "utils", "utils.box_ops", "utils.distributed", "utils.misc", "utils.lr_policy"):
         sys.modules.setdefault("slowfast." + sub, importlib.import_module(__name__ + "." + sub))
     return pkg

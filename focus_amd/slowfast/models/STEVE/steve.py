@@ -1,13 +1,18 @@
-"""STEVE slot attention over video -- the iterative slot update (mirror of
-slowfast/models/STEVE/steve.py:11-105).  The dVAE / CNN encoder / autoregressive decoder around it are
-"next" in SURVEY.md section 8(f) and are not built yet."""
+"""STEVE: slot attention over video with a dVAE token target and an autoregressive transformer decoder (mirror of
+slowfast/models/STEVE/steve.py).  The iterative slot update (SlotAttentionVideo, :11-105) is the hot path and runs on
+the HIP kernels; the model around it (STEVE.forward, :253-330 -- SURVEY.md section 8(f) rank 1) keeps the reference's
+module tree and state_dict keys: convolutions (dVAE, CNN encoder) and the Gumbel-softmax stay on ATen/MIOpen, every
+Linear / LayerNorm / FFN / attention of the encoder MLP, the slot projection and the decoder goes through the C ABI."""
 import torch
 import torch.nn as nn
+import torch.nn.functional as F
 
 from focus_amd import ops
 
-from .transformer import TransformerEncoder
-from .utils import gru_cell, linear
+from ..build import MODEL_REGISTRY
+from .dvae import dVAE
+from .transformer import TransformerDecoder, TransformerEncoder
+from .utils import Conv2dBlock, conv2d, gru_cell, gumbel_softmax, linear
 
 
 class SlotAttentionVideo(nn.Module):
@@ -76,3 +81,222 @@ class SlotAttentionVideo(nn.Module):
             slots_collect.append(slots)
             slots = self.predictor(slots)
         return torch.stack(slots_collect, dim=1), torch.stack(attns_collect, dim=1)
+
+
+class LearnedPositionalEmbedding1D(nn.Module):
+    """steve.py:108-122 (dropout 0.1 on the sum, ATen, training mode only)."""
+
+    def __init__(self, num_inputs, input_size, dropout=0.1):
+        super().__init__()
+        self.dropout = nn.Dropout(dropout)
+        self.pe = nn.Parameter(torch.zeros(1, num_inputs, input_size), requires_grad=True)
+        nn.init.trunc_normal_(self.pe)
+
+    def forward(self, input, offset=0):
+        T = input.shape[1]
+        return self.dropout(input + self.pe[:, offset:offset + T].to(input.dtype))
+
+
+class CartesianPositionalEmbedding(nn.Module):
+    """steve.py:125-145: a 1x1 conv of the (x, y, 1-x, 1-y) grid added to the CNN features."""
+
+    def __init__(self, channels, image_size):
+        super().__init__()
+        self.projection = conv2d(4, channels, 1)
+        self.pe = nn.Parameter(self.build_grid(image_size).unsqueeze(0), requires_grad=False)
+
+    def build_grid(self, side_length):
+        coords = torch.linspace(0.0, 1.0, side_length + 1)
+        coords = 0.5 * (coords[:-1] + coords[1:])
+        grid_y, grid_x = torch.meshgrid(coords, coords, indexing="ij")
+        return torch.stack((grid_x, grid_y, 1 - grid_x, 1 - grid_y), dim=0)
+
+    def forward(self, inputs):
+        return inputs + self.projection(self.pe)
+
+
+class OneHotDictionary(nn.Module):
+    """steve.py:147-159: embedding of the arg-max token."""
+
+    def __init__(self, vocab_size, emb_size):
+        super().__init__()
+        self.dictionary = nn.Embedding(vocab_size, emb_size)
+
+    def forward(self, x):
+        return self.dictionary(torch.argmax(x, dim=-1))
+
+
+class BaseCNN(nn.Module):
+    """steve.py:162-174."""
+
+    def __init__(self, args):
+        super().__init__()
+        self.fenc = nn.Sequential(
+            Conv2dBlock(args.SLOTS.IMG_CHANNELS, args.SLOTS.CNN_HID_SIZE, 5, 1 if args.SLOTS.IMG_SIZE == 64 else 2, 2),
+            Conv2dBlock(args.SLOTS.CNN_HID_SIZE, args.SLOTS.CNN_HID_SIZE, 5, 1, 2),
+            Conv2dBlock(args.SLOTS.CNN_HID_SIZE, args.SLOTS.CNN_HID_SIZE, 5, 1, 2),
+            conv2d(args.SLOTS.CNN_HID_SIZE, args.SLOTS.DECODER.DIM, 5, 1, 2),
+        )
+
+    def forward(self, x):
+        return self.fenc(x)
+
+
+class Res18Block(nn.Module):
+    """steve.py:176-203 (needs torchvision's resnet18, which this image does not ship: fails loudly when asked for)."""
+
+    def __init__(self, args):
+        super().__init__()
+        try:
+            from torchvision.models import resnet18
+        except ImportError as e:
+            raise NotImplementedError("MODEL.CNN_NAME='res18' needs torchvision (steve.py:179)") from e
+        self.res18 = resnet18()
+        self.res18.conv1 = nn.Conv2d(args.SLOTS.IMG_CHANNELS, args.SLOTS.CNN_HID_SIZE, 3, 1, 1)
+        self.fenc = nn.Sequential(*list(self.res18.children())[:-5])
+        self.upconv = nn.ConvTranspose2d(args.SLOTS.CNN_HID_SIZE, args.SLOTS.DECODER.DIM, 3, stride=2, padding=1, dilation=1,
+                                         output_padding=1)
+
+    def forward(self, x):
+        return self.upconv(F.relu(self.fenc(x)))
+
+
+def fetch_visual_encoder(args):
+    if args.MODEL.CNN_NAME == "base":
+        return BaseCNN(args)
+    if args.MODEL.CNN_NAME == "res18":
+        return Res18Block(args)
+    raise ValueError("Incorrect cnn name provided!")
+
+
+class STEVEEncoder(nn.Module):
+    """steve.py:215-236."""
+
+    def __init__(self, args):
+        super().__init__()
+        self.cnn = fetch_visual_encoder(args)
+        self.pos = CartesianPositionalEmbedding(args.SLOTS.DECODER.DIM,
+                                                args.SLOTS.IMG_SIZE if args.SLOTS.IMG_SIZE == 64 else args.SLOTS.IMG_SIZE // 2)
+        self.layer_norm = nn.LayerNorm(args.SLOTS.DECODER.DIM)
+        self.mlp = nn.Sequential(linear(args.SLOTS.DECODER.DIM, args.SLOTS.DECODER.DIM, weight_init="kaiming"), nn.ReLU(),
+                                 linear(args.SLOTS.DECODER.DIM, args.SLOTS.DECODER.DIM))
+        self.savi = SlotAttentionVideo(args.SLOTS.NUM_ITERS, args.SLOTS.NUM_SLOTS, args.SLOTS.DIM, args.SLOTS.SIZE,
+                                       args.SLOTS.MLP_HID_SIZE, args.SLOTS.NUM_PREDICTOR_BLOCKS,
+                                       args.SLOTS.NUM_PREDICTOR_HEADS, args.SLOTS.PREDICTOR_DROPOUT)
+        self.slot_proj = linear(args.SLOTS.SIZE, args.SLOTS.DIM, bias=False)
+
+
+class STEVEDecoder(nn.Module):
+    """steve.py:239-251."""
+
+    def __init__(self, args):
+        super().__init__()
+        self.dict = OneHotDictionary(args.SLOTS.VOCAB_SIZE, args.SLOTS.DECODER.DIM)
+        self.bos = nn.Parameter(torch.Tensor(1, 1, args.SLOTS.DECODER.DIM))
+        nn.init.xavier_uniform_(self.bos)
+        self.pos = LearnedPositionalEmbedding1D(1 + (args.SLOTS.IMG_SIZE // 4) ** 2, args.SLOTS.DECODER.DIM)
+        self.tf = TransformerDecoder(args.SLOTS.DECODER.NUM_BLOCKS, (args.SLOTS.IMG_SIZE // 4) ** 2, args.SLOTS.DECODER.DIM,
+                                     args.SLOTS.DECODER.NUM_HEADS, args.SLOTS.DECODER.DROPOUT)
+        self.head = linear(args.SLOTS.DECODER.DIM, args.SLOTS.VOCAB_SIZE, bias=False)
+
+
+@MODEL_REGISTRY.register()
+class STEVE(nn.Module):
+    """steve.py:253-392.  forward(video [B,T,C,H,W], tau, hard) -> (recon clamped to [0,1], cross_entropy, dvae_mse,
+    attns [B,T,K,C,H,W]).  `compute_dtype` (torch.bfloat16 under TRAIN.MIXED_PRECISION) is the storage type of the token
+    path (encoder MLP, slot attention, decoder); the convolutions, the Gumbel-softmax and the losses stay fp32.
+    `noise` = dict(gumbel_soft, gumbel_hard: Exp(1) draws of the two gumbel_softmax calls; slots: the N(0,1) slot
+    initialisation) fixes the random draws for parity tests; each is drawn as the reference draws it when absent."""
+
+    def __init__(self, args):
+        super().__init__()
+        self.num_iterations = args.SLOTS.NUM_ITERS
+        self.num_slots = args.SLOTS.NUM_SLOTS
+        self.cnn_hidden_size = args.SLOTS.CNN_HID_SIZE
+        self.slot_size = args.SLOTS.SIZE
+        self.mlp_hidden_size = args.SLOTS.MLP_HID_SIZE
+        self.img_channels = args.SLOTS.IMG_CHANNELS
+        self.image_size = args.SLOTS.IMG_SIZE
+        self.vocab_size = args.SLOTS.VOCAB_SIZE
+        self.d_model = args.SLOTS.DECODER.DIM
+        self.compute_dtype = torch.bfloat16 if args.TRAIN.MIXED_PRECISION else torch.float32
+        self.dvae = dVAE(args.SLOTS.VOCAB_SIZE, args.SLOTS.IMG_CHANNELS)
+        self.steve_encoder = STEVEEncoder(args)
+        self.steve_decoder = STEVEDecoder(args)
+
+    # ---- shared by forward / encode (steve.py:294-313, :333-353) ----
+    def _slots(self, video, noise=None):
+        B, T, C, H, W = video.shape
+        enc = self.steve_encoder
+        emb = enc.pos(enc.cnn(video.flatten(end_dim=1)))                                  # B*T, d_model, H_enc, W_enc
+        H_enc, W_enc = emb.shape[-2:]
+        emb_set = emb.permute(0, 2, 3, 1).flatten(start_dim=1, end_dim=2).to(self.compute_dtype)    # B*T, H_enc*W_enc, d_model
+        ln = enc.layer_norm
+        emb_set = ops.mlp(ops.layer_norm(emb_set, ln.weight, ln.bias, ln.eps), enc.mlp[0].weight, enc.mlp[0].bias,
+                          enc.mlp[2].weight, enc.mlp[2].bias, act=ops.EPI_RELU)
+        emb_set = emb_set.reshape(B, T, H_enc * W_enc, self.d_model)
+        slots, attns = enc.savi(emb_set, noise=noise)                                     # [B,T,K,Ds], [B,T,N,K]
+        attns = attns.float().transpose(-1, -2).reshape(B, T, self.num_slots, 1, H_enc, W_enc) \
+            .repeat_interleave(H // H_enc, dim=-2).repeat_interleave(W // W_enc, dim=-1)  # B, T, K, 1, H, W
+        return slots, attns
+
+    def forward(self, video, tau, hard, noise=None):
+        B, T, C, H, W = video.size()
+        noise = noise or {}
+        dec = self.steve_decoder
+        video_flat = video.flatten(end_dim=1)                                             # B*T, C, H, W
+
+        # dvae encode (:262-271)
+        z_logits = F.log_softmax(self.dvae.encoder(video_flat), dim=1)                    # B*T, vocab, H_enc, W_enc
+        z_soft = gumbel_softmax(z_logits, tau, hard, dim=1, noise=noise.get("gumbel_soft"))
+        z_hard = gumbel_softmax(z_logits, tau, True, dim=1, noise=noise.get("gumbel_hard")).detach()
+        z_hard = z_hard.permute(0, 2, 3, 1).flatten(start_dim=1, end_dim=2)               # B*T, H_enc*W_enc, vocab
+        target = torch.argmax(z_hard, dim=-1)                                             # the one-hot's index
+        z_emb = dec.dict.dictionary(target)                                               # B*T, H_enc*W_enc, d_model
+        z_emb = torch.cat([dec.bos.expand(B * T, -1, -1), z_emb], dim=1)
+        z_emb = dec.pos(z_emb)
+
+        # dvae recon (:274-275)
+        dvae_recon = self.dvae.decoder(z_soft).reshape(B, T, C, H, W)
+        dvae_mse = ((video - dvae_recon) ** 2).sum() / (B * T)
+
+        # slots (:277-300)
+        slots, attns = self._slots(video, noise.get("slots"))
+        attns = video.unsqueeze(2) * attns + (1.0 - attns)                                # B, T, K, C, H, W
+
+        # decode (:303-306): cross entropy of the hard tokens under the decoder's prediction, summed over the tokens
+        slots = ops.linear(slots, self.steve_encoder.slot_proj.weight)                    # B, T, K, d_model
+        pred = dec.tf(z_emb[:, :-1].to(self.compute_dtype), slots.flatten(end_dim=1))     # B*T, H_enc*W_enc, d_model
+        pred = ops.linear(pred, dec.head.weight)                                          # B*T, H_enc*W_enc, vocab
+        ntok = pred.shape[1]
+        cross_entropy = ops.label_smoothing_ce(pred.reshape(-1, self.vocab_size), target.reshape(-1), 0.0) * ntok
+        return dvae_recon.clamp(0.0, 1.0), cross_entropy, dvae_mse, attns
+
+    def encode(self, video):
+        """steve.py:331-357 -> (slots, attns_vis, attns)."""
+        slots, attns = self._slots(video)
+        attns_vis = video.unsqueeze(2) * attns + (1.0 - attns)
+        return slots, attns_vis, attns
+
+    def decode(self, slots):
+        """steve.py:359-381: greedy autoregressive token generation, then the dVAE decoder."""
+        B, num_slots, slot_size = slots.size()
+        H_enc, W_enc = self.image_size // 4, self.image_size // 4
+        gen_len = H_enc * W_enc
+        dec = self.steve_decoder
+        slots = ops.linear(slots.to(self.compute_dtype), self.steve_encoder.slot_proj.weight)
+        z_gen = slots.new_zeros(0, dtype=torch.long)
+        input = dec.bos.expand(B, 1, -1)
+        for _ in range(gen_len):
+            decoder_output = dec.tf(dec.pos(input).to(self.compute_dtype), slots)
+            z_next = ops.linear(decoder_output[:, -1:].contiguous(), dec.head.weight).argmax(dim=-1)      # B, 1
+            z_gen = torch.cat((z_gen, z_next), dim=1)
+            input = torch.cat((input, dec.dict.dictionary(z_next)), dim=1)
+        z_gen = F.one_hot(z_gen, self.vocab_size).transpose(1, 2).float().reshape(B, -1, H_enc, W_enc)
+        return self.dvae.decoder(z_gen).clamp(0.0, 1.0)
+
+    def reconstruct_autoregressive(self, video):
+        """steve.py:383-392."""
+        B, T, C, H, W = video.size()
+        slots, attns, _ = self.encode(video)
+        return self.decode(slots.flatten(end_dim=1)).reshape(B, T, C, H, W)

@@ -33,3 +33,34 @@ def construct_optimizer(model, cfg):
     from focus_amd import ops
     opt.register_step_post_hook(lambda *_a, **_k: ops.invalidate_shadows())
     return opt
+
+
+def construct_optimizer_slot(model, cfg):
+    """optimizer.py:13-40: three parameter groups -- dVAE, encoder, decoder -- whose learning rates set_slot_lr rewrites
+    every step."""
+    base = model.module if hasattr(model, "module") else model
+    named = list(base.named_parameters())
+    optim_params = [
+        {"params": [p for n, p in named if "dvae" in n], "lr": cfg.SLOTS_OPTIM.DVAE},
+        {"params": [p for n, p in named if "steve_encoder" in n], "lr": 0.0},
+        {"params": [p for n, p in named if "steve_decoder" in n], "lr": 0.0},
+    ]
+    method = cfg.SOLVER.OPTIMIZING_METHOD
+    if method == "sgd":
+        opt = torch.optim.SGD(optim_params, lr=cfg.SOLVER.BASE_LR, momentum=cfg.SOLVER.MOMENTUM,
+                              weight_decay=cfg.SOLVER.WEIGHT_DECAY, dampening=cfg.SOLVER.DAMPENING,
+                              nesterov=cfg.SOLVER.NESTEROV)
+    elif method == "adam":
+        opt = torch.optim.Adam(optim_params)
+    else:
+        raise NotImplementedError("Does not support {} optimizer".format(method))
+    from focus_amd import ops
+    opt.register_step_post_hook(lambda *_a, **_k: ops.invalidate_shadows())
+    return opt
+
+
+def set_slot_lr(optimizer, cfg, lr_decay_factor, lr_warmup_factor_enc, lr_warmup_factor_dec):
+    """optimizer.py:213-222."""
+    optimizer.param_groups[0]["lr"] = cfg.SLOTS_OPTIM.DVAE
+    optimizer.param_groups[1]["lr"] = lr_decay_factor * lr_warmup_factor_enc * cfg.SLOTS_OPTIM.ENC
+    optimizer.param_groups[2]["lr"] = lr_decay_factor * lr_warmup_factor_dec * cfg.SLOTS_OPTIM.DEC

@@ -34,6 +34,58 @@ def train_step(model, optimizer, loss_fun, inputs, labels, meta, cfg, check_nan=
     return preds, loss
 
 
+def slot_train_step(model, optimizer, video, global_step, cfg, noise=None):
+    """One iteration of slot_train_epoch (tools/steve_train_net.py:57-126): schedules -> forward -> mse + cross_entropy ->
+    NaN check -> zero_grad -> backward -> clip-norm -> step.  Returns (loss, mse, cross_entropy, recon, attns, tau).
+    TRAIN.MIXED_PRECISION selects bf16 storage inside the model (no autocast / GradScaler: see the module docstring)."""
+    import math
+    from .slowfast.models import optimizer as optim
+    from .slowfast.utils import lr_policy as lrp
+    so = cfg.SLOTS_OPTIM
+    tau = lrp.cosine_anneal(global_step, so.TAU_START, so.TAU_FINAL, 0, so.TAU_STEPS)                # :60-66
+    lr_warmup_factor_enc = lrp.linear_warmup(global_step, 0.0, 1.0, 0.0, so.WARMUP_STEPS)             # :68-73
+    lr_warmup_factor_dec = lrp.linear_warmup(global_step, 0.0, 1.0, 0, so.WARMUP_STEPS)               # :75-80
+    lr_decay_factor = math.exp(global_step / so.HALF_LIFE * math.log(0.5))                            # :82
+    optim.set_slot_lr(optimizer, cfg, lr_decay_factor, lr_warmup_factor_enc, lr_warmup_factor_dec)    # :85-89
+    recon, cross_entropy, mse, attns = model(video, tau, cfg.SLOTS.HARD) if noise is None else \
+        model(video, tau, cfg.SLOTS.HARD, noise=noise)                                                # :98
+    mse = mse.mean()                                                                                  # :101-102
+    cross_entropy = cross_entropy.mean()
+    loss = mse + cross_entropy                                                                        # :104
+    misc.check_nan_losses(float(loss.detach()))                                                       # :108
+    optimizer.zero_grad()                                                                             # :111
+    loss.backward()
+    if cfg.SOLVER.CLIP_GRAD_VAL:                                                                      # :116-123
+        torch.nn.utils.clip_grad_value_(model.parameters(), cfg.SOLVER.CLIP_GRAD_VAL)
+    elif cfg.SOLVER.CLIP_GRAD_L2NORM:
+        torch.nn.utils.clip_grad_norm_(model.parameters(), cfg.SOLVER.CLIP_GRAD_L2NORM)
+    optimizer.step()                                                                                  # :126
+    return loss, mse, cross_entropy, recon, attns, tau
+
+
+def slot_train_epoch(train_loader, model, optimizer, scaler, train_meter, cur_epoch, cfg, writer=None):
+    """tools/steve_train_net.py:33-160 with the reference's argument list (scaler and train_meter are accepted and unused:
+    bf16 needs no loss scaling, and the reference never touches the meter either).  `train_loader` yields video tensors
+    [B,T,C,H,W]; `writer`, if given, receives the same scalar dict through add_scalars(dict, global_step=...).
+    Returns {'tau', 'global_step'} like the reference (:153-158).  The end-of-epoch autoregressive visualisation
+    (:146-150, slot_misc.visualize + add_video) is dataset/tensorboard plumbing and is not part of this path."""
+    model.train()
+    data_size = len(train_loader)
+    tau, global_step = None, cur_epoch * data_size
+    for cur_iter, video in enumerate(train_loader):
+        global_step = cur_epoch * data_size + cur_iter
+        if cfg.NUM_GPUS:
+            video = video.cuda(non_blocking=True)
+        loss, mse, ce, _recon, _attns, tau = slot_train_step(model, optimizer, video, global_step, cfg)
+        if writer is not None:
+            with torch.no_grad():
+                writer.add_scalars({"TRAIN/loss": loss.item(), "TRAIN/cross_entropy": ce.item(), "TRAIN/mse": mse.item(),
+                                    "TRAIN/tau": tau, "TRAIN/lr_dvae": optimizer.param_groups[0]["lr"],
+                                    "TRAIN/lr_enc": optimizer.param_groups[1]["lr"],
+                                    "TRAIN/lr_dec": optimizer.param_groups[2]["lr"]}, global_step=global_step)
+    return {"tau": tau, "global_step": global_step}
+
+
 def synthetic_batch(cfg, batch, device, seed=0):
     """Synthetic clips of BASELINE.md section 3: frames ~ N(0,1) [B,3,T,H,W], boxes [B,T,O,4] cxcywh with
     cx,cy ~ U(0.3,0.7), w,h ~ U(0.1,0.5) kept inside the frame, one object slot emptied, labels ~ randint.

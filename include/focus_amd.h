@@ -133,6 +133,10 @@ int focus_softmax_fwd(const void* x, void* y, int64_t rows, int L, int64_t strid
                       void* stream);
 int focus_softmax_bwd(const void* dy, const void* y, void* dx, int64_t rows, int L, int64_t stride,
                       float scale, int dtype, void* stream);
+/* Causal variant (STEVE/transformer.py:145-166, self_attn_mask = triu(1)): row r sees columns 0 .. r % period, the
+ * masked tail of y is exact zeros; its backward is focus_softmax_bwd. */
+int focus_softmax_causal_fwd(const void* x, void* y, int64_t rows, int L, int64_t stride, int period, float scale,
+                             int dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Trajectory attention (attention.py:499-557).  qkv is the output of the fused qkv Linear,

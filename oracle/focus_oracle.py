@@ -450,3 +450,122 @@ def slot_attention_video(p, inputs, noise, num_iterations, pred_heads, pred_bloc
         attn_out.append(a_vis)
         slots = slot_predictor(p, pre + "predictor", slots, pred_heads, pred_blocks, eps_ln)
     return torch.stack(slots_out, dim=1), torch.stack(attn_out, dim=1)
+
+
+# ----------------------------------------------------------------------------------------------
+# STEVE.forward (steve.py:253-330): dVAE tokens, CNN encoder, slot attention, autoregressive decoder
+# ----------------------------------------------------------------------------------------------
+def _conv(p, name, x, stride=1, padding=0):
+    return torch.nn.functional.conv2d(x, p[name + ".weight"], p.get(name + ".bias"), stride, padding)
+
+
+def _conv_block(p, name, x, stride=1, padding=0):
+    """Conv2dBlock (STEVE/utils.py:82-92): conv named `.m` + ReLU."""
+    return torch.relu(_conv(p, name + ".m", x, stride, padding))
+
+
+def dvae_encoder(p, x, name="dvae.encoder"):
+    """dvae.py:9-18: 4x4/stride-4 conv, six 1x1 conv blocks, 1x1 conv to the vocabulary."""
+    x = _conv_block(p, name + ".0", x, 4)
+    for i in range(1, 7):
+        x = _conv_block(p, name + ".%d" % i, x)
+    return _conv(p, name + ".7", x)
+
+
+def dvae_decoder(p, z, name="dvae.decoder"):
+    """dvae.py:20-32."""
+    ps = torch.nn.functional.pixel_shuffle
+    x = _conv_block(p, name + ".0", z)
+    x = _conv_block(p, name + ".1", x, 1, 1)
+    x = _conv_block(p, name + ".2", x)
+    x = _conv_block(p, name + ".3", x)
+    x = ps(_conv_block(p, name + ".4", x), 2)
+    x = _conv_block(p, name + ".6", x, 1, 1)
+    x = _conv_block(p, name + ".7", x)
+    x = _conv_block(p, name + ".8", x)
+    x = ps(_conv_block(p, name + ".9", x), 2)
+    return _conv(p, name + ".11", x)
+
+
+def gumbel_softmax(logits, tau, hard, dim, noise):
+    """STEVE/utils.py:47-61 with the Exp(1) draw as an explicit input."""
+    eps = torch.finfo(logits.dtype).tiny
+    g = (logits - (noise + eps).log()) / tau
+    y_soft = torch.softmax(g, dim)
+    if hard:
+        index = y_soft.argmax(dim, keepdim=True)
+        y_hard = torch.zeros_like(logits).scatter_(dim, index, 1.0)
+        return y_hard - y_soft.detach() + y_soft
+    return y_soft
+
+
+def decoder_mha(p, name, q_in, kv_in, heads, causal):
+    """MultiHeadAttention.forward (transformer.py:23-49) with the decoder's triu(1) mask (:126-127), dropout off."""
+    d = q_in.shape[-1] // heads
+    q = split_heads(q_in @ p[name + ".proj_q.weight"].t(), heads) * d ** -0.5
+    k = split_heads(kv_in @ p[name + ".proj_k.weight"].t(), heads)
+    v = split_heads(kv_in @ p[name + ".proj_v.weight"].t(), heads)
+    a = q @ k.transpose(-1, -2)
+    if causal:
+        T = a.shape[-1]
+        a = a.masked_fill(torch.triu(torch.ones(T, T, dtype=torch.bool), diagonal=1), float("-inf"))
+    a = torch.softmax(a, dim=-1)
+    return merge_heads(a @ v) @ p[name + ".proj_o.weight"].t()
+
+
+def transformer_decoder(p, name, x, enc, heads, num_blocks, eps=1e-5):
+    """TransformerDecoder.forward (transformer.py:146-166, :185-193); block 0 is_first."""
+    for j in range(num_blocks):
+        bn = "%s.blocks.%d" % (name, j)
+        if j == 0:
+            x = layer_norm(p, bn + ".self_attn_layer_norm", x, eps)
+            x = x + decoder_mha(p, bn + ".self_attn", x, x, heads, True)
+        else:
+            y = layer_norm(p, bn + ".self_attn_layer_norm", x, eps)
+            x = x + decoder_mha(p, bn + ".self_attn", y, y, heads, True)
+        y = layer_norm(p, bn + ".encoder_decoder_attn_layer_norm", x, eps)
+        x = x + decoder_mha(p, bn + ".encoder_decoder_attn", y, enc, heads, False)
+        y = layer_norm(p, bn + ".ffn_layer_norm", x, eps)
+        x = x + linear(p, bn + ".ffn.2", torch.relu(linear(p, bn + ".ffn.0", y)))
+    return layer_norm(p, name + ".layer_norm", x, eps)
+
+
+def steve_forward(p, video, tau, hard, noise, cfg):
+    """STEVE.forward (steve.py:253-330), eval-mode dropout.  video [B,T,C,H,W]; noise = dict(gumbel_soft, gumbel_hard
+    [B*T,vocab,H/4,W/4] Exp(1) draws, slots [B,K,Ds] N(0,1) draw); cfg = dict(img_size, num_slots, num_iters,
+    pred_heads, pred_blocks, dec_heads, dec_blocks).  Returns (recon clamped, cross_entropy, dvae_mse, attns)."""
+    B, T, C, H, W = video.shape
+    vf = video.flatten(end_dim=1)
+    z_logits = torch.log_softmax(dvae_encoder(p, vf), dim=1)                                   # :262
+    z_soft = gumbel_softmax(z_logits, tau, hard, 1, noise["gumbel_soft"])                      # :263
+    z_hard = gumbel_softmax(z_logits, tau, True, 1, noise["gumbel_hard"]).detach()             # :264
+    z_hard = z_hard.permute(0, 2, 3, 1).flatten(start_dim=1, end_dim=2)
+    z_emb = p["steve_decoder.dict.dictionary.weight"][torch.argmax(z_hard, dim=-1)]            # :266 (OneHotDictionary)
+    z_emb = torch.cat([p["steve_decoder.bos"].expand(B * T, -1, -1), z_emb], dim=1)
+    z_emb = z_emb + p["steve_decoder.pos.pe"][:, :z_emb.shape[1]]                              # :268
+    recon = dvae_decoder(p, z_soft).reshape(B, T, C, H, W)                                     # :271
+    mse = ((video - recon) ** 2).sum() / (B * T)
+    # CNN encoder (steve.py:162-174: stride 1 at 64 px, else 2) + cartesian position embedding (:125-145)
+    s0 = 1 if cfg["img_size"] == 64 else 2
+    e = _conv_block(p, "steve_encoder.cnn.fenc.0", vf, s0, 2)
+    e = _conv_block(p, "steve_encoder.cnn.fenc.1", e, 1, 2)
+    e = _conv_block(p, "steve_encoder.cnn.fenc.2", e, 1, 2)
+    e = _conv(p, "steve_encoder.cnn.fenc.3", e, 1, 2)
+    e = e + _conv(p, "steve_encoder.pos.projection", p["steve_encoder.pos.pe"])
+    He, We = e.shape[-2:]
+    es = e.permute(0, 2, 3, 1).flatten(start_dim=1, end_dim=2)
+    es = layer_norm(p, "steve_encoder.layer_norm", es, 1e-5)
+    es = linear(p, "steve_encoder.mlp.2", torch.relu(linear(p, "steve_encoder.mlp.0", es)))
+    es = es.reshape(B, T, He * We, -1)
+    slots, attns = slot_attention_video(p, es, noise["slots"], cfg["num_iters"], cfg["pred_heads"], cfg["pred_blocks"],
+                                        name="steve_encoder.savi")
+    K = cfg["num_slots"]
+    attns = attns.transpose(-1, -2).reshape(B, T, K, 1, He, We).repeat_interleave(H // He, dim=-2) \
+        .repeat_interleave(W // We, dim=-1)
+    attns = video.unsqueeze(2) * attns + (1.0 - attns)                                         # :300
+    slots = slots @ p["steve_encoder.slot_proj.weight"].t()                                    # :303
+    pred = transformer_decoder(p, "steve_decoder.tf", z_emb[:, :-1], slots.flatten(end_dim=1), cfg["dec_heads"],
+                               cfg["dec_blocks"])
+    pred = pred @ p["steve_decoder.head.weight"].t()
+    ce = -(z_hard * torch.log_softmax(pred, dim=-1)).sum() / (B * T)                           # :306
+    return recon.clamp(0.0, 1.0), ce, mse, attns

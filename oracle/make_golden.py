@@ -273,6 +273,67 @@ def main_r2():
     print("wrote round-2 fixtures")
 
 
+
+def steve_cfg():
+    """Reduced STEVE config: 16 px frames -> 4x4 = 16 dVAE tokens, 8x8 = 64 CNN cells, vocabulary 32, width 32."""
+    return ns(SLOTS=ns(NUM_ITERS=2, NUM_SLOTS=3, CNN_HID_SIZE=16, SIZE=16, DIM=32, MLP_HID_SIZE=32, IMG_CHANNELS=3,
+                       IMG_SIZE=16, VOCAB_SIZE=32, NUM_PREDICTOR_BLOCKS=1, NUM_PREDICTOR_HEADS=2, PREDICTOR_DROPOUT=0.0,
+                       DECODER=ns(DIM=32, NUM_BLOCKS=2, NUM_HEADS=2, DROPOUT=0.1)),
+              MODEL=ns(CNN_NAME="base"), TRAIN=ns(MIXED_PRECISION=False))
+
+
+def main_steve():
+    """11. STEVE.forward (steve.py:253-330) of the reference's registered STEVE class at a reduced shape, eval mode (the
+    decoder / positional dropouts draw nothing), fp64 with fp32-representable weights; the three random draws forward()
+    makes -- two Exp(1) tensors in gumbel_softmax (utils.py:51) and the N(0,1) slot initialisation (steve.py:56) -- are
+    captured by drawing them first from the same seed in the same order.  Loss = mse + cross_entropy as in
+    tools/steve_train_net.py:97-103."""
+    torch.set_grad_enabled(True)
+    mods = load_reference(_roi_align_tv)
+    g = torch.Generator().manual_seed(20263)
+    cfg = steve_cfg()
+    torch.manual_seed(3)
+    m = mods["steve"].STEVE(cfg).double()
+    with torch.no_grad():
+        for n, prm in m.named_parameters():
+            if not prm.requires_grad:
+                continue
+            if prm.dim() == 1 and ("norm" in n) and n.endswith("weight"):
+                prm.copy_(1.0 + 0.1 * torch.randn(prm.shape, generator=g))
+            elif n.endswith("bias"):
+                prm.copy_(0.05 * torch.randn(prm.shape, generator=g))
+            else:
+                prm.copy_((prm + 0.02 * torch.randn(prm.shape, generator=g)).float().double())
+            prm.copy_(prm.float().double())
+    m.eval()
+    B, T, C, S = 2, 2, 3, 16
+    video = torch.rand(B, T, C, S, S, generator=g).double()
+    tau, hard = 0.7, True
+    torch.manual_seed(91)
+    e1 = torch.empty(B * T, 32, S // 4, S // 4, dtype=torch.float64).exponential_()
+    e2 = torch.empty(B * T, 32, S // 4, S // 4, dtype=torch.float64).exponential_()
+    n0 = torch.empty(B, 3, 16, dtype=torch.float64).normal_()
+    torch.manual_seed(91)
+    recon, ce, mse, attns = m(video, tau, hard)
+    (mse + ce).backward()
+    keys = ["dvae.encoder.0.m.weight", "dvae.encoder.7.bias", "dvae.decoder.1.m.weight", "dvae.decoder.11.weight",
+            "steve_encoder.cnn.fenc.0.m.weight", "steve_encoder.cnn.fenc.3.bias", "steve_encoder.pos.projection.weight",
+            "steve_encoder.layer_norm.weight", "steve_encoder.mlp.0.weight", "steve_encoder.savi.project_k.weight",
+            "steve_encoder.savi.gru.weight_hh", "steve_encoder.savi.slot_mu", "steve_encoder.slot_proj.weight",
+            "steve_decoder.dict.dictionary.weight", "steve_decoder.bos", "steve_decoder.pos.pe",
+            "steve_decoder.tf.blocks.0.self_attn.proj_q.weight", "steve_decoder.tf.blocks.1.self_attn.proj_k.weight",
+            "steve_decoder.tf.blocks.1.encoder_decoder_attn.proj_k.weight",
+            "steve_decoder.tf.blocks.1.encoder_decoder_attn_layer_norm.bias", "steve_decoder.tf.blocks.1.ffn.0.weight",
+            "steve_decoder.tf.layer_norm.weight", "steve_decoder.head.weight"]
+    sd = {k: v for k, v in m.state_dict().items() if v.is_floating_point()}
+    np.savez(os.path.join(OUT, "steve_forward_small.npz"), video=video.numpy().astype(np.float32), tau=tau, hard=hard,
+             gumbel_soft=e1.numpy(), gumbel_hard=e2.numpy(), slots_noise=n0.numpy(), recon=recon.detach().numpy(),
+             cross_entropy=ce.detach().numpy(), mse=mse.detach().numpy(), attns=attns.detach().numpy(),
+             state_keys=np.array(sorted(m.state_dict().keys())),
+             **{k: v.astype(np.float32) for k, v in pack("p.", sd).items()}, **grads_of(m, keys))
+    print("wrote steve_forward_small.npz")
+
+
 def _load_losses():
     """The reference's own slowfast/models/losses.py (plain torch + the stubbed logger)."""
     from oracle._ref_loader import _load
@@ -288,6 +349,10 @@ def mods_loss(logits, labels):
 
 
 if __name__ == "__main__":
-    if "--r2-only" not in sys.argv:
-        main()
-    main_r2()
+    if "--steve-only" in sys.argv:
+        main_steve()
+    else:
+        if "--r2-only" not in sys.argv:
+            main()
+        main_r2()
+        main_steve()

@@ -67,3 +67,82 @@ def test_slot_attention_baseline_shape_slice_vs_oracle(oracle):
                   "mlp.0.weight", "norm_slots.weight", "slot_mu", "predictor.blocks.0.attn.proj_o.weight"):
             gr = p[k].grad
             close(named[k].grad, gr, tol * 3, "grad %s %s" % (k, dtype), floor=1e-2 * float(gr.abs().max()) + 1e-12)
+
+
+# ------------------------------------------------------------------------------------------------
+# STEVE.forward (steve.py:253-330) and one iteration of slot_train_epoch (tools/steve_train_net.py:57-126)
+# ------------------------------------------------------------------------------------------------
+def _steve_small(mixed):
+    from focus_amd.slowfast.config.defaults import get_cfg
+    from focus_amd.slowfast.models import MODEL_REGISTRY
+    cfg = get_cfg()
+    cfg.MODEL.MODEL_NAME = "STEVE"
+    cfg.NUM_GPUS = 1
+    cfg.TRAIN.MIXED_PRECISION = mixed
+    s = cfg.SLOTS
+    s.NUM_ITERS, s.NUM_SLOTS, s.CNN_HID_SIZE, s.SIZE, s.DIM, s.MLP_HID_SIZE, s.IMG_SIZE, s.VOCAB_SIZE = 2, 3, 16, 16, 32, 32, 16, 32
+    s.NUM_PREDICTOR_BLOCKS, s.NUM_PREDICTOR_HEADS = 1, 2
+    s.DECODER.DIM, s.DECODER.NUM_BLOCKS, s.DECODER.NUM_HEADS = 32, 2, 2
+    return cfg, MODEL_REGISTRY.get("STEVE")(cfg)
+
+
+@pytest.mark.parametrize("mixed", [False, True])
+def test_steve_forward_vs_reference_fixture(mixed):
+    """The registered STEVE class against the fixture the reference's STEVE produced (oracle/make_golden.py main_steve):
+    recon, cross entropy, mse, attns, and 23 parameter gradients of mse + cross_entropy.  eval() switches the decoder's
+    dropouts off as in the fixture; the Gumbel draws and the slot initialisation are the captured ones."""
+    from conftest import load_golden
+    from test_gpu_parity import check_param_grads
+    a, p = load_golden("steve_forward_small")
+    cfg, m = _steve_small(mixed)
+    missing, unexpected = m.load_state_dict(p, strict=False)
+    assert not unexpected
+    assert all(k.endswith("self_attn_mask") for k in missing), missing          # bool buffers: built by the ctor
+    m = m.to(dev()).eval()
+    d = dev()
+    noise = {"gumbel_soft": torch.from_numpy(a["gumbel_soft"]).float().to(d),
+             "gumbel_hard": torch.from_numpy(a["gumbel_hard"]).float().to(d),
+             "slots": torch.from_numpy(a["slots_noise"]).float().to(d)}
+    video = torch.from_numpy(a["video"]).to(d)
+    recon, ce, mse, attns = m(video, float(a["tau"]), bool(a["hard"]), noise=noise)
+    tol = 3e-2 if mixed else 1e-3
+    close(recon, a["recon"], tol, "recon")
+    close(attns, a["attns"], tol, "attns")
+    close(ce, a["cross_entropy"], tol, "cross_entropy")
+    close(mse, a["mse"], 1e-3, "mse")                                # the dVAE stays fp32 in both modes
+    (mse + ce).backward()
+    # bf16: the CNN / encoder gradients come back through the decoder's cross-attention, the slot projection and
+    # T x iterations slot updates (GRU + softmax over slots) in bf16 storage: the deep-chain factor of the module header
+    check_param_grads(m, a, 1e-1 if mixed else 2e-3)
+
+
+def test_slot_train_step_runs_the_reference_schedule():
+    """Two iterations of the slot loop: learning rates follow set_slot_lr (optimizer.py:213-222) with the warm-up /
+    half-life factors of steve_train_net.py:68-82, tau follows cosine_anneal, every parameter group moves."""
+    import math
+    from focus_amd.slowfast.models.optimizer import construct_optimizer_slot
+    from focus_amd.train import slot_train_step
+    cfg, m = _steve_small(False)
+    cfg.SOLVER.OPTIMIZING_METHOD = "adam"
+    cfg.SOLVER.CLIP_GRAD_L2NORM = 1.0
+    cfg.SLOTS_OPTIM.WARMUP_STEPS, cfg.SLOTS_OPTIM.TAU_STEPS, cfg.SLOTS_OPTIM.HALF_LIFE = 10, 20, 50
+    m = m.to(dev()).train()
+    opt = construct_optimizer_slot(m, cfg)
+    ntrain = sum(1 for p in m.parameters() if p.requires_grad)
+    assert len(opt.param_groups) == 3 and sum(len(g["params"]) for g in opt.param_groups) >= ntrain
+    before = {n: p.detach().clone() for n, p in m.named_parameters() if p.requires_grad}
+    g = torch.Generator().manual_seed(0)
+    video = torch.rand(2, 2, 3, 16, 16, generator=g).to(dev())
+    losses = []
+    for step in range(2):
+        loss, mse, ce, recon, attns, tau = slot_train_step(m, opt, video, step, cfg)
+        losses.append(float(loss))
+        assert math.isfinite(losses[-1]) and recon.shape == video.shape and attns.shape == (2, 2, 3, 3, 16, 16)
+        decay = math.exp(step / 50 * math.log(0.5))
+        warm = (step + 1) / 10
+        assert opt.param_groups[0]["lr"] == cfg.SLOTS_OPTIM.DVAE
+        assert abs(opt.param_groups[1]["lr"] - decay * warm * cfg.SLOTS_OPTIM.ENC) < 1e-12
+        assert abs(opt.param_groups[2]["lr"] - decay * warm * cfg.SLOTS_OPTIM.DEC) < 1e-12
+        assert abs(tau - (0.45 * math.cos(math.pi * step / 20) + 0.55)) < 1e-12
+    moved = {n.split(".")[0] for n, p in m.named_parameters() if p.requires_grad and not torch.equal(p.detach(), before[n])}
+    assert moved == {"dvae", "steve_encoder", "steve_decoder"}

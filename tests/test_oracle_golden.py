@@ -146,3 +146,45 @@ def test_motionformer_hr_small_ek_heads(oracle):
     close(loss, a["loss"], 1e-6)
     loss.backward()
     check_grads(a, p, 2e-4)
+
+
+STEVE_CFG = dict(img_size=16, num_slots=3, num_iters=2, pred_heads=2, pred_blocks=1, dec_heads=2, dec_blocks=2)
+
+
+def steve_noise(a, dtype=torch.float64):
+    return {"gumbel_soft": T(a["gumbel_soft"], dtype), "gumbel_hard": T(a["gumbel_hard"], dtype),
+            "slots": T(a["slots_noise"], dtype)}
+
+
+def test_steve_forward(oracle):
+    """STEVE.forward (steve.py:253-330): fixture from the reference's registered STEVE class, eval-mode dropout, the two
+    Gumbel draws and the slot initialisation captured; recon, cross entropy, mse, attns and 23 parameter gradients."""
+    a, p = load_golden("steve_forward_small", dtype=torch.float64)
+    p = leafify(p)
+    recon, ce, mse, attns = oracle.steve_forward(p, T(a["video"], torch.float64), float(a["tau"]), bool(a["hard"]),
+                                                 steve_noise(a), STEVE_CFG)
+    close(recon, a["recon"], 1e-12)
+    close(attns, a["attns"], 1e-12)
+    close(ce, a["cross_entropy"], 1e-12)
+    close(mse, a["mse"], 1e-12)
+    (mse + ce).backward()
+    check_grads(a, p, 1e-10)
+
+
+def test_steve_state_dict_keys_match_the_reference():
+    """The registered STEVE class builds the reference's module tree: same state_dict keys and shapes (checkpoints of the
+    reference load unchanged).  Construction needs no GPU."""
+    from focus_amd.slowfast.config.defaults import get_cfg
+    from focus_amd.slowfast.models import MODEL_REGISTRY
+    a, p = load_golden("steve_forward_small")
+    cfg = get_cfg()
+    cfg.MODEL.MODEL_NAME = "STEVE"
+    s = cfg.SLOTS
+    s.NUM_ITERS, s.NUM_SLOTS, s.CNN_HID_SIZE, s.SIZE, s.DIM, s.MLP_HID_SIZE, s.IMG_SIZE, s.VOCAB_SIZE = 2, 3, 16, 16, 32, 32, 16, 32
+    s.NUM_PREDICTOR_BLOCKS, s.NUM_PREDICTOR_HEADS = 1, 2
+    s.DECODER.DIM, s.DECODER.NUM_BLOCKS, s.DECODER.NUM_HEADS = 32, 2, 2
+    m = MODEL_REGISTRY.get("STEVE")(cfg)
+    sd = m.state_dict()
+    assert sorted(sd.keys()) == [str(k) for k in a["state_keys"]]
+    for k, v in p.items():
+        assert tuple(sd[k].shape) == tuple(v.shape), k
