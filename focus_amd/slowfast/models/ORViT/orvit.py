@@ -9,6 +9,25 @@ from ..common import DropPath
 from .utils import Mlp, ObjectsCrops, box2spatial_layout
 
 
+import os
+
+# The motion stream (orvit.py:159-161) depends on the box coordinates only: 32 tokens per clip, i.e. GEMMs of 256 rows
+# that occupy a handful of CUs for 20-60 us each (1.3 ms per bench step when serialised with the main branch).  It is
+# issued on a second HIP stream, forked before the RoI / attention work of the block and joined before motion_mlp, so
+# those launches run beside the block's large kernels; autograd replays the same fork / join for its backward
+# (33.3 vs 34.3 ms per bench step).  Not under DistributedDataParallel: its reducer orders a bucket's all-reduce after
+# the stream of the LAST gradient hook only, which does not cover gradients produced on another stream.
+_SIDE_STREAMS = {}
+_USE_SIDE_STREAM = os.environ.get("FOCUS_MOTION_SIDE_STREAM", "1") != "0"
+
+
+def _side_stream(device):
+    s = _SIDE_STREAMS.get(device)
+    if s is None:
+        s = _SIDE_STREAMS[device] = torch.cuda.Stream(device=device)
+    return s
+
+
 def _relu_pair(seq, x, dtype=None):
     """nn.Sequential(Linear(no bias), ReLU, Linear(no bias), ReLU) on the 4-d box coordinates: the first layer
     (K=4) stays in fp32 on the raw coordinates, the second runs in the compute dtype (MFMA when bf16)."""
@@ -76,6 +95,19 @@ class ORViT(nn.Module):
         O = box_tensors.shape[-2]
         HW = H * W
 
+        motion_emb, side = None, None
+        if self.with_motion_stream:
+            multi_rank = torch.distributed.is_available() and torch.distributed.is_initialized() and \
+                torch.distributed.get_world_size() > 1
+            if x.is_cuda and _USE_SIDE_STREAM and not multi_rank:
+                main, side = torch.cuda.current_stream(), _side_stream(x.device)
+                side.wait_stream(main)
+                box_tensors.record_stream(side)
+                with torch.cuda.stream(side):
+                    motion_emb = self.motion_stream(box_tensors, H, W, dtype=x.dtype)        # [BS,T*H*W,d]
+            else:
+                motion_emb = self.motion_stream(box_tensors, H, W, dtype=x.dtype)
+
         # object tokens: RoIAlign (patch tokens read in place from x) -> patch_to_d -> max over the RoI cells (:135-139)
         crops = self.crop_layer.crop_stream(x, box_tensors, T, H, W)                        # [BS*T*O, HW, d]
         p2d = self.patch_to_d
@@ -90,7 +122,9 @@ class ORViT(nn.Module):
         y, _ = self.attn(ops.layer_norm(all_tokens, n1.weight, n1.bias, n1.eps), [T, HW + O, 1])
         mm = None
         if self.with_motion_stream:
-            motion_emb = self.motion_stream(box_tensors, H, W, dtype=x.dtype)                # [BS,T*H*W,d]
+            if side is not None:
+                torch.cuda.current_stream().wait_stream(side)
+                motion_emb.record_stream(torch.cuda.current_stream())
             mm = self.motion_mlp(motion_emb)                                                 # :162-163
         dp = 0.0 if isinstance(self.drop_path, nn.Identity) else self.drop_path.drop_prob
         x = ops.orvit_merge(x, y, mm, T, HW, dp, self.training)                              # :169
