@@ -409,6 +409,10 @@ bool focus_gemm_mfma_nt_ok(const focus_gemm_desc& d) {
     return true;
 }
 
+// which kernel family the last focus_gemm() on this thread dispatched to (bench.py attributes its per-launch timings)
+static thread_local int g_last_kernel = FOCUS_GEMM_KERNEL_GENERIC;
+extern "C" int focus_gemm_last_kernel(void) { return g_last_kernel; }
+
 int focus_gemm_mfma_nt(const focus_gemm_desc& d, hipStream_t s) {
     if (!focus_gemm_mfma_nt_ok(d)) return FOCUS_ERR_ALIGN;
     const int nbatch = d.batch0 * d.batch1;
@@ -421,12 +425,14 @@ int focus_gemm_mfma_nt(const focus_gemm_desc& d, hipStream_t s) {
     if (can_split && t128 < CUS && d.K >= 1024) {
         int splits = (int)std::min<int64_t>((2 * CUS + t128 - 1) / t128, d.K / 256);
         if (splits < 1) splits = 1;
+        g_last_kernel = FOCUS_GEMM_KERNEL_NT;
         return launch_nt<128, 128, 2, 2>(d, splits, s);
     }
     if (focus_gemm_mfma_ws_ok(d)) {
         const int rc = focus_gemm_mfma_ws(d, s);
-        if (rc != FOCUS_ERR_SHAPE) return rc;
+        if (rc != FOCUS_ERR_SHAPE) { g_last_kernel = FOCUS_GEMM_KERNEL_NT_WS; return rc; }
     }
+    g_last_kernel = FOCUS_GEMM_KERNEL_NT;
     return launch_nt<128, 128, 2, 2>(d, 1, s);
 }
 
@@ -441,12 +447,16 @@ extern "C" int focus_gemm(const focus_gemm_desc* desc, void* stream) {
     if (d.accumulate && d.dtype_c != FOCUS_F32) return FOCUS_ERR_DTYPE;
     if (d.epilogue >= FOCUS_EPI_DGELU && !d.aux) return FOCUS_ERR_NULL;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (focus_gemm_mfma_tn_ok(d)) return focus_gemm_mfma_tn(d, s);     // checked first: in this form aux is its slab workspace
+    if (focus_gemm_mfma_tn_ok(d)) {                                    // checked first: in this form aux is its slab workspace
+        g_last_kernel = FOCUS_GEMM_KERNEL_TN;
+        return focus_gemm_mfma_tn(d, s);
+    }
     if (d.aux && d.epilogue == FOCUS_EPI_NONE) d.aux = nullptr;
     if (focus_gemm_mfma_nt_ok(d)) {
         const int rc = focus_gemm_mfma_nt(d, s);
         if (rc != FOCUS_ERR_SHAPE) return rc;      // shape/epilogue the MFMA instances do not cover
     }
+    g_last_kernel = FOCUS_GEMM_KERNEL_GENERIC;
     return focus_gemm_generic(d, s);
 }
 

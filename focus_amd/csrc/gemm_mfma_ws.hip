@@ -109,10 +109,12 @@ __global__ __launch_bounds__(64 * (BM * BN / 4096 + NLOAD)) void gemm_nt_ws_kern
         constexpr int INFLIGHT = (AHEAD - 1) * PIECES;     // DMA pieces that may stay outstanding across a barrier
         setup(0);
         issue(0);
-        if (AHEAD > 1 && total > 1) {
-            issue(1);
+        if (AHEAD > 1 && total >= AHEAD) {
+#pragma unroll
+            for (int a = 1; a < AHEAD; ++a) issue(a);
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(INFLIGHT) : "memory");
         } else {
+            for (int a = 1; a < AHEAD && a < total; ++a) issue(a);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         __builtin_amdgcn_s_barrier();                      // step 0 is in LDS
@@ -270,7 +272,8 @@ bool focus_gemm_mfma_ws_ok(const focus_gemm_desc& d) {
 
 template <int BM, int BN, int EPI, int NLOAD>
 static int launch_ws_n(const focus_gemm_desc& d, hipStream_t s) {
-    constexpr int NSTAGE = (BM + BN) * 128 * 3 <= 160 * 1024 ? 3 : 2;
+    constexpr int FIT = 160 * 1024 / ((BM + BN) * 128);
+    constexpr int NSTAGE = FIT >= 4 ? 4 : FIT;                    // ring depth: what fits the 160 KiB of LDS, at most 4
     const int tiles_m = (d.M + BM - 1) / BM, tiles_n = (d.N + BN - 1) / BN;
     const int nbatch = d.batch0 * d.batch1;
     const size_t lds = (size_t)NSTAGE * (BM + BN) * 128;
@@ -334,6 +337,10 @@ int focus_gemm_mfma_ws(const focus_gemm_desc& d, hipStream_t s) {
         const bool use192 = force ? force == 192 : (t192 >= 128 && c192 < c128);
         if (use192 && t192 >= 128) return launch_ws_epi<192, 256>(d, s);
     }
+    // narrow outputs (per-head products: N = head dim, batched over the heads): 4 consumers on a 256 x 64 tile, no MFMA
+    // work on padding columns, and the 3-stage ring instead of the uniform kernel's one K-step in flight
+    if (d.N <= 64 && d.M >= 2048 && d.epilogue == FOCUS_EPI_NONE && (int64_t)((d.M + 255) / 256) * d.batch0 * d.batch1 >= 192)
+        return launch_ws<256, 64, FOCUS_EPI_NONE>(d, s);
     if (d.N >= 256 && tw >= 192) return launch_ws_epi<128, 256>(d, s);   // 512-byte row segments of C
     if (d.M >= 256 && t256 >= 192) return launch_ws_epi<256, 128>(d, s);
     return FOCUS_ERR_SHAPE;   // too few tiles for one 8-consumer workgroup per CU: the caller uses the uniform kernel

@@ -20,7 +20,7 @@
 //                   the softmax over f (attn2 [B,S,h,F]); time2_out_kernel forms out = sum_f a x~ (reads x~ once more).
 //   backward (time2_dlg_kernel, then time2_dx_kernel):
 //     dl[s,f,h]   = scale a (da - sum_f a da),  da[s,f,h] = dout[s,h,:] . x~[s,f,h,:]
-//     g[s,h,c]    = sum_f dl[s,f,h] x~[s,f,c]   ( = du )  -> HBM [B,S,h,C] bf16: the host forms
+//     g[s,h,c]    = sum_f dl[s,f,h] x~[s,f,c]   ( = du )  -> HBM [h,B*S,C] bf16: the host forms
 //                   dq2 = g[:,h,:] . Wk[h]^T  and  dWk[h] = q2[:,h,:]^T . g[:,h,:]  from it (two batched GEMMs).
 //     dx~[s,f,c]  = a[s,f,h(c)] dout[s,c] + sum_h dl[s,f,h] U[s,h,c]     MFMA 16x16x32, M = channels, N = (query, frame),
 //                   K = (query, head); U^T gathered from the LDS image by ds_read_b64_tr_b16.
@@ -379,7 +379,8 @@ __global__ __launch_bounds__(256) void time2_out_kernel(const bf16_t* __restrict
 // backward 1/2 (streaming, reads x~ once): block = RPB whole query rows, thread = (row, 8-channel group).
 //   da[f]  = dout[s,h,:] . x~[s,f,h,:]  (8-lane reduction inside the head);  dl[f] = scale * a (da - sum_f a da)
 //   dl of the row's heads meet in LDS, then  g[s,h,c8] = sum_f dl[s,f,h] x~[s,f,c8]  for every head h from the x~
-//   registers the thread already holds -> g [row][h][C] bf16 (= d loss / d u), dl [row][f][16] bf16 for time2_dx_kernel.
+//   registers the thread already holds -> g [h][row][C] bf16 (= d loss / d u; head-major, so that each head's slice is a
+//   dense matrix for the two GEMMs that consume it), dl [row][f][16] bf16 for time2_dx_kernel.
 template <int FT>
 __global__ __launch_bounds__(256) void time2_dlg_kernel(const bf16_t* __restrict__ xt, const float* __restrict__ attn2,
                                                         const bf16_t* __restrict__ dout, int64_t dobs,
@@ -441,7 +442,7 @@ __global__ __launch_bounds__(256) void time2_dlg_kernel(const bf16_t* __restrict
 #pragma unroll
             for (int k = 0; k < 8; ++k) g8[k] = fmaf(d, xv[f][k], g8[k]);
         }
-        if (act) *reinterpret_cast<uint4*>(gout + ((int64_t)row * HEADS + hh) * C + cg * 8) = pack8(g8);
+        if (act) *reinterpret_cast<uint4*>(gout + ((int64_t)hh * rows + row) * C + cg * 8) = pack8(g8);
     }
 }
 

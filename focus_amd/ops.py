@@ -87,6 +87,8 @@ def gemm(M, N, K, A, sA, B, sB, C, sC, batch=(1, 1), bias=None, residual=None, a
         e0.record()
         _lib.check(_lib.lib().focus_gemm(ctypes.byref(d), _stream()), "gemm")
         e1.record()
+        if kind == "nt" and _lib.lib().focus_gemm_last_kernel() == 2:
+            kind = "nt_ws"                                        # the wave-specialised kernel (gemm_mfma_ws.hip)
         GEMM_TIMING.append((2.0 * M * N * K * batch[0] * batch[1], e0, e1, kind, (M, N, K, batch[0] * batch[1], epilogue)))
         return
     _lib.check(_lib.lib().focus_gemm(ctypes.byref(d), _stream()), "gemm")
@@ -806,24 +808,24 @@ class _TrajTime2BlockFn(torch.autograd.Function):
         dcat = dcat.contiguous()                 # [B, 1+S, C]: rows 1.. are read in place (batch stride (S+1)*C)
         wkT = shadow(w_kv, xt.dtype, transposed=True)
         dxt = torch.empty_like(xt)
-        g = torch.empty(B, S, heads, C, device=dev, dtype=xt.dtype)
+        g = torch.empty(heads, B * S, C, device=dev, dtype=xt.dtype)         # head-major: each head's GEMM operand is dense
         dl = torch.empty(B, S, F_, 16, device=dev, dtype=xt.dtype)           # [.., h padded to 16]
         _lib.check(L.focus_traj_time2_bwd(_p(q2), _p(xt), _p(wkT), wkT.stride(0), _p(attn2), _p(dcat, C), (S + 1) * C,
                                           _p(dxt), _p(g), _p(dl), B, S, F_, heads, d, _dt(xt), _stream()), "traj_time2_bwd")
         R = B * S
         dq2 = dw = db = None
         if ctx.needs_input_grad[0]:
-            # dq2[r, h*d+dd] = sum_c g[r,h,c] Wk[h*d+dd, c]   (one launch, batched over the heads)
+            # dq2[r, h*d+dd] = sum_c g[h,r,c] Wk[h*d+dd, c]   (one launch, batched over the heads)
             wk = shadow(w_kv, xt.dtype)                                  # [2C, C] row-major: rows :C are Wk
             dq2 = torch.empty(B, S, C, device=dev, dtype=xt.dtype)
-            gemm(R, d, C, (g, 0), (heads * C, 1, 0, C), (wk, 0), (1, C, 0, d * C), (dq2, 0), (C, 1, 0, d),
+            gemm(R, d, C, (g, 0), (C, 1, 0, R * C), (wk, 0), (1, C, 0, d * C), (dq2, 0), (C, 1, 0, d),
                  batch=(1, heads))
         if ctx.needs_input_grad[2]:
-            # dWk[h*d+dd, c] = sum_r q2[r, h*d+dd] g[r,h,c]   (batched weight-gradient product; slabs summed once)
+            # dWk[h*d+dd, c] = sum_r q2[r, h*d+dd] g[h,r,c]   (batched weight-gradient product; slabs summed once)
             dw = torch.empty(2 * C, C, device=dev, dtype=torch.float32)
             nbw = L.focus_gemm_tn_batched_workspace_bytes(d, C, R, heads)
             wsw = torch.empty(max(nbw, 16) // 4, device=dev, dtype=torch.float32)
-            gemm(d, C, R, (q2, 0), (1, C, 0, d), (g, 0), (heads * C, 1, 0, C), (dw, 0), (C, 1, 0, d * C),
+            gemm(d, C, R, (q2, 0), (1, C, 0, d), (g, 0), (C, 1, 0, R * C), (dw, 0), (C, 1, 0, d * C),
                  batch=(1, heads), aux=(wsw, 0))
             dw[C:].zero_()                      # v2 half: no output use, exactly zero gradient
             if ctx.has_b and ctx.needs_input_grad[3]:

@@ -78,6 +78,15 @@ typedef struct focus_gemm_desc {
 
 int focus_gemm(const focus_gemm_desc* desc, void* stream);
 
+/* Kernel family the last focus_gemm() call of this thread dispatched to (measurement attribution only). */
+enum focus_gemm_kernel {
+    FOCUS_GEMM_KERNEL_GENERIC = 0,   /* gemm_generic.hip (fp32 / odd strides)                       */
+    FOCUS_GEMM_KERNEL_NT = 1,        /* gemm_mfma.hip uniform 128x128 (few tiles, split-K)          */
+    FOCUS_GEMM_KERNEL_NT_WS = 2,     /* gemm_mfma_ws.hip wave-specialised (the step's dominant kernel) */
+    FOCUS_GEMM_KERNEL_TN = 3         /* gemm_mfma_tn*.hip (weight gradients)                        */
+};
+int focus_gemm_last_kernel(void);
+
 /* Tuning hook: force the row-tile height of the wave-specialised NT kernel (128 or 192; 0 = automatic choice by the
  * modelled rounds-x-tile-time cost).  Used by tools/gemm_tile_ab.py for A/B timing inside one process. */
 int focus_gemm_tile_override(int bm);
@@ -173,9 +182,9 @@ int focus_traj_time_bwd(const void* q2, const void* k2, const void* xt, const fl
  * Wk^T (the transposed shadow of proj_kv.weight).  q2 [B,S,C] is the UN-scaled proj_q output.
  *   fwd: out rows [B,S,C] at batch stride out_bstride (see focus_traj_time_fwd); attn2 [B,S,h,F] fp32 (saved);
  *        ws: focus_traj_time2_workspace_bytes() bytes of scratch.
- *   bwd: dxt [B,S,F,C] (fully written: a*dout + sum_h dl*u); g [B,S,h,C] bf16 = d(loss)/d(u), from which the caller
- *        forms  dq2[:, h*64+dd] = sum_c g[:,h,c] Wk[h*64+dd, c]  and  dWk[h*64+dd, c] = sum_s q2[s,h*64+dd] g[s,h,c]
- *        (two batched GEMMs over the heads); dl [B,S,F,16] bf16 scratch.  proj_kv.bias gets its exact zero gradient. */
+ *   bwd: dxt [B,S,F,C] (fully written: a*dout + sum_h dl*u); g [h,B*S,C] bf16 = d(loss)/d(u), head-major so that each
+ *        head's slice is a dense matrix, from which the caller forms  dq2[:, h*64+dd] = sum_c g[h,:,c] Wk[h*64+dd, c]
+ *        and  dWk[h*64+dd, c] = sum_s q2[s,h*64+dd] g[h,s,c]  (two batched GEMMs over the heads); dl [B,S,F,16] bf16 scratch.  proj_kv.bias gets its exact zero gradient. */
 size_t focus_traj_time2_workspace_bytes(int B, int S, int F, int heads, int d);
 int focus_traj_time2_fwd(const void* q2, const void* xt, const void* wkT, int64_t ldw, void* out, int64_t out_bstride,
                          float* attn2, void* ws, size_t ws_bytes, int B, int S, int F, int heads, int d, int dtype,
