@@ -342,13 +342,19 @@ def bench_steve(a, dev):
     x = torch.randn(B, T, N, D, device=dev, dtype=torch.bfloat16, generator=g).requires_grad_(True)
     noise = torch.randn(B, K, D, device=dev, generator=g)
 
-    def step():
-        slots, attn = m(x, noise=noise)
-        (slots.float().square().mean() + attn.float().mean()).backward()
+    def reset_grads():
         x.grad = None
         for p in m.parameters():
             p.grad = None
+
+    def fwd_bwd():
+        slots, attn = m(x, noise=noise)
+        (slots.float().square().mean() + attn.float().mean()).backward()
         return slots, attn
+
+    def step():
+        reset_grads()
+        return fwd_bwd()
     for _ in range(max(1, min(a.warmup, 2))):
         step()
     torch.cuda.synchronize()
@@ -357,7 +363,23 @@ def bench_steve(a, dev):
     for _ in range(n):
         slots, attn = step()
     torch.cuda.synchronize()
-    ms = 1e3 * (time.perf_counter() - t0) / n
+    eager_ms = 1e3 * (time.perf_counter() - t0) / n
+    ms, graphed = eager_ms, False
+    if not a.steve_eager:
+        # the step is launch bound (~2900 kernels): replay it from one HIP graph (focus_amd.train.GraphedStep)
+        from focus_amd.train import GraphedStep
+        ref_slots, ref_grad = slots.detach().clone(), x.grad.detach().clone()
+        del slots, attn             # no output of an eager run (and with it that run's autograd graph) may be alive at capture
+        reset_grads()               # captured with no .grad present: every replay assigns fresh gradients (no accumulation)
+        gs = GraphedStep(fwd_bwd, reset=reset_grads)
+        gs.replay()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            slots, attn = gs.replay()
+        torch.cuda.synchronize()
+        ms, graphed = 1e3 * (time.perf_counter() - t0) / n, True
+        assert torch.equal(slots, ref_slots) and torch.equal(x.grad, ref_grad), "graph replay differs from the eager step"
     fwd_bytes = (B * T * N * D * 2) * (1 + 2 + 2) + B * T * N * K * 2         # inputs, write k/v, read k/v, attn out
     alg = 3.0 * fwd_bytes
     ach = alg / (ms * 1e-3) / 1e9
@@ -367,6 +389,7 @@ def bench_steve(a, dev):
                         "batch=%d, fwd+bwd bf16 (BASELINE configs[2])" % B,
             "ms_per_step": round(ms, 3), "clips_per_s": round(B / (ms * 1e-3), 2),
             "slot_updates_per_s": round(B * T * IT * K / (ms * 1e-3), 1), "steps": n,
+            "launch": "one HIP graph replay per step" if graphed else "eager", "eager_ms_per_step": round(eager_ms, 3),
             "roofline": {"bound": "hbm", "achieved": round(ach, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                          "frac": round(ach / PEAK_HBM_GBS, 4), "traffic": None,
                          "algorithmic_bytes_per_step": int(alg),
@@ -435,6 +458,7 @@ def main(argv=None, job=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--gemm-shapes", action="store_true", help="print per-shape GEMM timings to stderr")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--steve-eager", action="store_true", help="time the STEVE sub-record eagerly (no HIP graph)")
     ap.add_argument("--backend", default="nccl", help="process-group backend (nccl = RCCL; gloo for a rehearsal)")
     ap.add_argument("--bf16-grads", action="store_true", help="cfg.DDP_BF16_GRADS: bf16 gradient buckets on the wire")
     ap.add_argument("--same-device", action="store_true",

@@ -18,3 +18,6 @@ int focus_gemm_mfma_ws(const focus_gemm_desc& d, hipStream_t s);
 struct focus_tn_plan { int kind, tiles_i, tiles_j, splits, m_per_split; };
 focus_tn_plan focus_gemm_tn_ws_plan(int M, int N, int K);
 int focus_gemm_mfma_tn_ws(const focus_gemm_desc& d, const focus_tn_plan& pl, float* csum, hipStream_t s);
+// small row counts (M <= 1024, K <= 1536): one 32x32 tile per workgroup, in-workgroup split-K, operands in registers
+bool focus_gemm_mfma_small_ok(const focus_gemm_desc& d);
+int focus_gemm_mfma_small(const focus_gemm_desc& d, hipStream_t s);

@@ -417,6 +417,10 @@ int focus_gemm_mfma_nt(const focus_gemm_desc& d, hipStream_t s) {
     if (!focus_gemm_mfma_nt_ok(d)) return FOCUS_ERR_ALIGN;
     const int nbatch = d.batch0 * d.batch1;
     if (nbatch > 65535) return FOCUS_ERR_SHAPE;
+    if (focus_gemm_mfma_small_ok(d)) {                                // few rows: latency-shaped kernel (gemm_mfma_small.hip)
+        g_last_kernel = FOCUS_GEMM_KERNEL_NT_SMALL;
+        return focus_gemm_mfma_small(d, s);
+    }
     constexpr int CUS = 256;
     const int64_t t128 = (int64_t)((d.M + 127) / 128) * ((d.N + 127) / 128) * nbatch;
     // split-K only for plain fp32-output products (weight gradients): tiny output, long reduction

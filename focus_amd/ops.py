@@ -1192,11 +1192,23 @@ def label_smoothing_ce(logits, target, smoothing=0.1):
 # --------------------------------------------------------------------------------------------------
 # Slot attention
 # --------------------------------------------------------------------------------------------------
+class SlotKVGrad:
+    """Shared gradient accumulator for the k_t / v_t of ONE frame.  The corrector iterations of a frame all read the same
+    k_t, v_t (steve.py:68-83); autograd would sum their three 50 MB gradients with separate add kernels (96 adds per
+    BASELINE step).  Iterations that carry the same SlotKVGrad add into one buffer inside the backward kernel
+    (focus_slot_attn_bwd accumulate=1); the node whose backward runs last hands the sum to autograd, the others return
+    None.  Valid because every iteration of a frame is on the path to the loss (the slots chain through them)."""
+
+    def __init__(self):
+        self.dk = self.dv = None
+        self.pending = 0
+
+
 class _SlotAttnFn(torch.autograd.Function):
     """One corrector iteration of steve.py:76-83 on one frame.  k_t, v_t [B,N,D]; q [B,K,D]."""
 
     @staticmethod
-    def forward(ctx, k_t, v_t, q, eps):
+    def forward(ctx, k_t, v_t, q, eps, acc):
         _need_gpu(k_t, v_t, q)
         k_t, v_t, q = k_t.contiguous(), v_t.contiguous(), q.contiguous()
         B, N, D = k_t.shape
@@ -1212,6 +1224,9 @@ class _SlotAttnFn(torch.autograd.Function):
                                          B, N, K, D, eps, _dt(k_t), _stream()), "slot_attn_fwd")
         ctx.save_for_backward(k_t, v_t, q, attn, cs, upd)
         ctx.eps = eps
+        ctx.acc = acc
+        if acc is not None:
+            acc.pending += 1
         return upd, attn
 
     @staticmethod
@@ -1221,19 +1236,32 @@ class _SlotAttnFn(torch.autograd.Function):
         K = q.shape[1]
         dupd = dupd.contiguous()
         dattn = dattn.contiguous() if dattn is not None else None
-        dk, dv, dq = torch.empty_like(k_t), torch.empty_like(v_t), torch.empty_like(q)
+        acc = ctx.acc
+        accumulate = 0
+        if acc is not None and acc.dk is not None:
+            dk, dv, accumulate = acc.dk, acc.dv, 1
+        else:
+            dk, dv = torch.empty_like(k_t), torch.empty_like(v_t)
+            if acc is not None:
+                acc.dk, acc.dv = dk, dv
+        dq = torch.empty_like(q)
         L = _lib.lib()
         nb = L.focus_slot_attn_workspace_bytes(B, N, K, D)
         ws = torch.empty(nb, device=k_t.device, dtype=torch.uint8)
         _lib.check(L.focus_slot_attn_bwd(_p(k_t), _p(v_t), N * D, _p(q), _p(attn), N * K, _p(cs), _p(upd), _p(dupd),
-                                         _p(dattn), _p(dk), _p(dv), 0, _p(dq), _p(ws), nb, B, N, K, D, ctx.eps,
+                                         _p(dattn), _p(dk), _p(dv), accumulate, _p(dq), _p(ws), nb, B, N, K, D, ctx.eps,
                                          _dt(k_t), _stream()), "slot_attn_bwd")
-        return dk, dv, dq, None
+        if acc is not None:
+            acc.pending -= 1
+            if acc.pending > 0:
+                return None, None, dq, None, None                 # the sum leaves with the last iteration's node
+            acc.dk = acc.dv = None
+        return dk, dv, dq, None, None
 
 
-def slot_attn_step(k_t, v_t, q, eps):
-    """-> (updates [B,K,D], attn_vis [B,N,K])."""
-    return _SlotAttnFn.apply(k_t, v_t, q, eps)
+def slot_attn_step(k_t, v_t, q, eps, acc=None):
+    """-> (updates [B,K,D], attn_vis [B,N,K]).  acc: a SlotKVGrad shared by the iterations of one frame (optional)."""
+    return _SlotAttnFn.apply(k_t, v_t, q, eps, acc)
 
 
 class _GruGatesFn(torch.autograd.Function):

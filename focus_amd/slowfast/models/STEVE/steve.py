@@ -67,10 +67,11 @@ class SlotAttentionVideo(nn.Module):
             x_t = ops.layer_norm(frames[t], ni.weight, ni.bias, ni.eps)
             k_t = ops.linear(x_t, self.project_k.weight, alpha=k_scale)      # k * Ds^-0.5 in the GEMM epilogue
             v_t = ops.linear(x_t, self.project_v.weight)
+            kv_grad = ops.SlotKVGrad()                            # d(k_t), d(v_t) of the iterations summed in-kernel
             for i in range(self.num_iterations):
                 slots_prev = slots
                 q = ops.linear(ops.layer_norm(slots, ns.weight, ns.bias, ns.eps), self.project_q.weight)
-                updates, attn_vis = ops.slot_attn_step(k_t, v_t, q, self.epsilon)          # :76-83
+                updates, attn_vis = ops.slot_attn_step(k_t, v_t, q, self.epsilon, kv_grad)  # :76-83
                 slots = ops.gru_cell(updates.view(-1, Ds), slots_prev.reshape(-1, Ds), self.gru.weight_ih,
                                      self.gru.weight_hh, self.gru.bias_ih, self.gru.bias_hh).view(B, K, Ds)
                 if i < self.num_iterations - 1:

@@ -86,6 +86,39 @@ def slot_train_epoch(train_loader, model, optimizer, scaler, train_meter, cur_ep
     return {"tau": tau, "global_step": global_step}
 
 
+class GraphedStep:
+    """One HIP graph for a launch-bound step (the STEVE slot update issues ~2900 kernels of 3-30 us per step: the host,
+    not the GPU, sets its eager time).  `fn` takes no arguments, reads its inputs from tensors that stay in place, and
+    runs forward + backward (gradients it leaves in .grad are rewritten by every replay).  Warm-up runs on a side stream
+    as torch.cuda.graphs requires; `replay()` re-issues the whole step with one launch.
+    Constraint found the hard way: no output of an EARLIER eager run of `fn` may still be referenced when the capture
+    starts -- a live output keeps that run's autograd graph alive, and ending the capture then crashes inside the HIP
+    runtime (ROCm 7.2).  Warm-up outputs are dropped here; callers drop theirs (bench.py: `del slots, attn`)."""
+
+    def __init__(self, fn, warmup=2, reset=None):
+        """reset: called before every warm-up run and before the capture (e.g. set .grad to None, so that the captured
+        backward ASSIGNS gradients instead of accumulating into tensors from outside the graph)."""
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                if reset is not None:
+                    reset()
+                fn()
+        torch.cuda.current_stream().wait_stream(side)
+        if reset is not None:
+            reset()
+        import gc
+        gc.collect()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.outputs = fn()
+
+    def replay(self):
+        self.graph.replay()
+        return self.outputs
+
+
 def synthetic_batch(cfg, batch, device, seed=0):
     """Synthetic clips of BASELINE.md section 3: frames ~ N(0,1) [B,3,T,H,W], boxes [B,T,O,4] cxcywh with
     cx,cy ~ U(0.3,0.7), w,h ~ U(0.1,0.5) kept inside the frame, one object slot emptied, labels ~ randint.

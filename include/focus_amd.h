@@ -83,7 +83,8 @@ enum focus_gemm_kernel {
     FOCUS_GEMM_KERNEL_GENERIC = 0,   /* gemm_generic.hip (fp32 / odd strides)                       */
     FOCUS_GEMM_KERNEL_NT = 1,        /* gemm_mfma.hip uniform 128x128 (few tiles, split-K)          */
     FOCUS_GEMM_KERNEL_NT_WS = 2,     /* gemm_mfma_ws.hip wave-specialised (the step's dominant kernel) */
-    FOCUS_GEMM_KERNEL_TN = 3         /* gemm_mfma_tn*.hip (weight gradients)                        */
+    FOCUS_GEMM_KERNEL_TN = 3,        /* gemm_mfma_tn*.hip (weight gradients)                        */
+    FOCUS_GEMM_KERNEL_NT_SMALL = 4   /* gemm_mfma_small.hip (M <= 1024 rows: recurrent / motion-stream Linears) */
 };
 int focus_gemm_last_kernel(void);
 
