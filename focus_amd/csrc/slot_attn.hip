@@ -349,16 +349,19 @@ __global__ __launch_bounds__(256) void slot_fwd_mfma_kernel(const bf16_t* __rest
     }
 }
 
-template <int KS>
+// DEFER: the d(k_t), d(v_t) part is left to slot_kv_grad_kernel (once per frame, for all iterations): this launch only
+// writes its rows of w = (attn + eps) / colsum and d(logits) to wl [B,N,32] bf16 (slots 0..15 | 16..31) and forms dq.
+template <int KS, bool DEFER>
 __global__ __launch_bounds__(256) void slot_bwd_mfma_kernel(const bf16_t* __restrict__ kt, const bf16_t* __restrict__ vt,
                                                             int64_t kv_bs, const bf16_t* __restrict__ q,
                                                             const bf16_t* __restrict__ attn, int64_t attn_bs,
                                                             const float* __restrict__ colsum, const bf16_t* __restrict__ upd,
                                                             const bf16_t* __restrict__ dupd, const bf16_t* __restrict__ dattn,
                                                             bf16_t* __restrict__ dkt, bf16_t* __restrict__ dvt, int accumulate,
-                                                            float* __restrict__ partial, int N, int K, float eps) {
+                                                            bf16_t* __restrict__ wl, float* __restrict__ partial, int N, int K,
+                                                            float eps) {
     constexpr int D = KS * 32;
-    __shared__ __attribute__((aligned(16))) float sW[4][64][16];          // (attn + eps) / colsum per (row, slot)
+    __shared__ __attribute__((aligned(16))) float sW[DEFER ? 1 : 4][DEFER ? 1 : 64][16];   // (attn + eps) / colsum per (row, slot)
     __shared__ __attribute__((aligned(16))) float sL[4][64][16];          // d logits per (row, slot)
     __shared__ float sr[16], scs[16];
     __shared__ float red[4][16][D];
@@ -419,7 +422,20 @@ __global__ __launch_bounds__(256) void slot_bwd_mfma_kernel(const bf16_t* __rest
         }
         wg.x = wv[0]; wg.y = wv[1]; wg.z = wv[2]; wg.w = wv[3];
         dl.x = lv[0]; dl.y = lv[1]; dl.z = lv[2]; dl.w = lv[3];
-        *reinterpret_cast<float4*>(&sW[w][tb * 16 + t16][4 * g]) = wg;
+        if (DEFER) {
+            if (valid) {
+                bf16_t* o = wl + ((int64_t)b * N + n) * 32 + 4 * g;
+                uint2 pw, pl;
+                pw.x = (uint32_t)f32_to_bf16(wv[0]) | ((uint32_t)f32_to_bf16(wv[1]) << 16);
+                pw.y = (uint32_t)f32_to_bf16(wv[2]) | ((uint32_t)f32_to_bf16(wv[3]) << 16);
+                pl.x = (uint32_t)f32_to_bf16(lv[0]) | ((uint32_t)f32_to_bf16(lv[1]) << 16);
+                pl.y = (uint32_t)f32_to_bf16(lv[2]) | ((uint32_t)f32_to_bf16(lv[3]) << 16);
+                *reinterpret_cast<uint2*>(o) = pw;
+                *reinterpret_cast<uint2*>(o + 16) = pl;
+            }
+        } else {
+            *reinterpret_cast<float4*>(&sW[w][tb * 16 + t16][4 * g]) = wg;
+        }
         *reinterpret_cast<float4*>(&sL[w][tb * 16 + t16][4 * g]) = dl;
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -432,8 +448,8 @@ __global__ __launch_bounds__(256) void slot_bwd_mfma_kernel(const bf16_t* __rest
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             const bool ok = lact && k < K;
-            sq[k][c] = ok ? bf16_to_f32(qb[k * D + lane * 4 + c]) : 0.f;
-            sd[k][c] = ok ? bf16_to_f32(dub[k * D + lane * 4 + c]) : 0.f;
+            sq[k][c] = ok && !DEFER ? bf16_to_f32(qb[k * D + lane * 4 + c]) : 0.f;
+            sd[k][c] = ok && !DEFER ? bf16_to_f32(dub[k * D + lane * 4 + c]) : 0.f;
             dQ[k][c] = 0.f;
         }
     }
@@ -449,24 +465,29 @@ __global__ __launch_bounds__(256) void slot_bwd_mfma_kernel(const bf16_t* __rest
             const int n = n0 + t0 + u;
             const float k0 = __uint_as_float(kr[u].x << 16), k1 = __uint_as_float(kr[u].x & 0xffff0000u);
             const float k2 = __uint_as_float(kr[u].y << 16), k3 = __uint_as_float(kr[u].y & 0xffff0000u);
-            const float4* wr = reinterpret_cast<const float4*>(&sW[w][t0 + u][0]);
+            const float4* wr = reinterpret_cast<const float4*>(&sW[DEFER ? 0 : w][DEFER ? 0 : t0 + u][0]);
             const float4* lr = reinterpret_cast<const float4*>(&sL[w][t0 + u][0]);
             float ww[16], ll[16];
 #pragma unroll
             for (int c4 = 0; c4 < 4; ++c4) {
-                const float4 x = wr[c4], y = lr[c4];
-                ww[c4 * 4 + 0] = x.x; ww[c4 * 4 + 1] = x.y; ww[c4 * 4 + 2] = x.z; ww[c4 * 4 + 3] = x.w;
+                const float4 y = lr[c4];
                 ll[c4 * 4 + 0] = y.x; ll[c4 * 4 + 1] = y.y; ll[c4 * 4 + 2] = y.z; ll[c4 * 4 + 3] = y.w;
+                if (!DEFER) {
+                    const float4 x = wr[c4];
+                    ww[c4 * 4 + 0] = x.x; ww[c4 * 4 + 1] = x.y; ww[c4 * 4 + 2] = x.z; ww[c4 * 4 + 3] = x.w;
+                }
             }
             float dv[4] = {0.f, 0.f, 0.f, 0.f}, dk[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int k = 0; k < 16; ++k) {
+                if (!DEFER) {
 #pragma unroll
-                for (int c = 0; c < 4; ++c) { dv[c] = fmaf(ww[k], sd[k][c], dv[c]); dk[c] = fmaf(ll[k], sq[k][c], dk[c]); }
+                    for (int c = 0; c < 4; ++c) { dv[c] = fmaf(ww[k], sd[k][c], dv[c]); dk[c] = fmaf(ll[k], sq[k][c], dk[c]); }
+                }
                 dQ[k][0] = fmaf(ll[k], k0, dQ[k][0]); dQ[k][1] = fmaf(ll[k], k1, dQ[k][1]);
                 dQ[k][2] = fmaf(ll[k], k2, dQ[k][2]); dQ[k][3] = fmaf(ll[k], k3, dQ[k][3]);
             }
-            if (lact && n < N) {
+            if (!DEFER && lact && n < N) {
                 const int64_t ro = (int64_t)b * kv_bs + (int64_t)n * D + lane * 4;
                 if (accumulate) {
                     const uint2 ok = *reinterpret_cast<const uint2*>(dkt + ro), ov = *reinterpret_cast<const uint2*>(dvt + ro);
@@ -493,6 +514,85 @@ __global__ __launch_bounds__(256) void slot_bwd_mfma_kernel(const bf16_t* __rest
     for (int i = threadIdx.x; i < K * D; i += 256) {
         const int k = i / D, e = i - k * D;
         out[i] = red[0][k][e] + red[1][k][e] + red[2][k][e] + red[3][k][e];
+    }
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// d(k_t), d(v_t) of ONE frame for all of its corrector iterations at once (steve.py:68-83 applies every iteration to the
+// same k_t, v_t):
+//     dk[n,:] = sum_i sum_k dlogits_i[n,k] q_i[k,:]        dv[n,:] = sum_i sum_k w_i[n,k] dupd_i[k,:]
+// = two products [rows x (iterations x 16 slots)] . [(iterations x 16 slots) x D] on the matrix pipe.  The per-iteration
+// backward launches only write their 64-byte (w, dlogits) rows; dk and dv (2 x 50 MB per frame at the BASELINE shape) are
+// written once instead of three times written and twice re-read, and the 2 x 16 x D rank-1 updates per row leave the VALU.
+// Block = 256 rows (4 waves x 4 tiles of 16); the stacked, transposed slot matrices [d][64 slots] sit in LDS as the MFMA
+// A operand ("swapped" product: a lane ends with 4 consecutive channels of one row).
+// ------------------------------------------------------------------------------------------------
+struct KvGradArgs { const bf16_t* wl[4]; const bf16_t* q[4]; const bf16_t* du[4]; };
+constexpr int SROW = 64 * 2 + 16;                 // bytes per channel row of the stacked slot image (64 slots + pad)
+
+template <int KS>
+__global__ __launch_bounds__(256) void slot_kv_grad_kernel(const KvGradArgs a, int iters, bf16_t* __restrict__ dkt,
+                                                           bf16_t* __restrict__ dvt, int64_t kv_bs, int N, int K) {
+    constexpr int D = KS * 32;
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // [2][D][SROW]: Q^T stack, dU^T stack
+    const int b = blockIdx.y, chunk = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int t16 = lane & 15, g = lane >> 4;
+    // stacked transposed slot matrices: img[m][d][i*16 + k] = (m ? dupd_i : q_i)[b][k][d], zero for k >= K or i >= iters
+    for (int e = tid; e < 2 * D * 64; e += 256) {
+        const int m = e / (D * 64), r = e - m * D * 64, d = r >> 6, sl = r & 63, i = sl >> 4, k = sl & 15;
+        bf16_t v = 0;
+        if (i < iters && k < K) v = (m ? a.du[i] : a.q[i])[((int64_t)b * K + k) * D + d];
+        *reinterpret_cast<bf16_t*>(smem + (m * D + d) * SROW + sl * 2) = v;
+    }
+    __syncthreads();
+    const int n0 = chunk * MROWS + w * 64;
+    // B operands (column = row n of the tile, k = 8 consecutive stacked slots): (w | dlogits) rows straight from HBM
+    SPk8 fw[4][2], fl[4][2];
+#pragma unroll
+    for (int tb = 0; tb < 4; ++tb) {
+        const int n = min(n0 + tb * 16 + t16, N - 1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int i = 2 * ks + (g >> 1);                      // iteration of this lane group's 8 slots
+            fw[tb][ks].u = make_uint4(0, 0, 0, 0);
+            fl[tb][ks].u = make_uint4(0, 0, 0, 0);
+            if (i < iters) {
+                const bf16_t* row = a.wl[i] + ((int64_t)b * N + n) * 32 + 8 * (g & 1);
+                fw[tb][ks].u = *reinterpret_cast<const uint4*>(row);
+                fl[tb][ks].u = *reinterpret_cast<const uint4*>(row + 16);
+            }
+        }
+    }
+#pragma unroll 2
+    for (int dt = 0; dt < D / 16; ++dt) {
+        SPk8 aq[2], au[2];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            aq[ks].u = *reinterpret_cast<const uint4*>(smem + (dt * 16 + t16) * SROW + (ks * 32 + g * 8) * 2);
+            au[ks].u = *reinterpret_cast<const uint4*>(smem + (D + dt * 16 + t16) * SROW + (ks * 32 + g * 8) * 2);
+        }
+#pragma unroll
+        for (int tb = 0; tb < 4; ++tb) {
+            sf32x4 ck = {0.f, 0.f, 0.f, 0.f}, cv = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                ck = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aq[ks].v, fl[tb][ks].v, ck, 0, 0, 0);
+                cv = __builtin_amdgcn_mfma_f32_16x16x32_bf16(au[ks].v, fw[tb][ks].v, cv, 0, 0, 0);
+            }
+            const int n = n0 + tb * 16 + t16;                     // lane (row n, g): channels dt*16 + 4 g .. + 3
+            if (n < N) {
+                const int64_t ro = (int64_t)b * kv_bs + (int64_t)n * D + dt * 16 + 4 * g;
+                uint2 o1, o2;
+                o1.x = (uint32_t)f32_to_bf16(ck[0]) | ((uint32_t)f32_to_bf16(ck[1]) << 16);
+                o1.y = (uint32_t)f32_to_bf16(ck[2]) | ((uint32_t)f32_to_bf16(ck[3]) << 16);
+                o2.x = (uint32_t)f32_to_bf16(cv[0]) | ((uint32_t)f32_to_bf16(cv[1]) << 16);
+                o2.y = (uint32_t)f32_to_bf16(cv[2]) | ((uint32_t)f32_to_bf16(cv[3]) << 16);
+                *reinterpret_cast<uint2*>(dkt + ro) = o1;
+                *reinterpret_cast<uint2*>(dvt + ro) = o2;
+            }
+        }
     }
 }
 
@@ -572,15 +672,19 @@ extern "C" int focus_slot_attn_bwd(const void* k_t, const void* v_t, int64_t kv_
                                    const void* attn_vis, int64_t attn_bs, const float* colsum, const void* upd,
                                    const void* dupd, const void* dattn_vis, void* dk_t, void* dv_t, int accumulate,
                                    void* dq, void* partial, size_t partial_bytes, int B, int N, int K, int D,
-                                   float eps, int dtype, void* stream) {
-    if (!k_t || !v_t || !q || !attn_vis || !colsum || !upd || !dupd || !dk_t || !dv_t || !dq || !partial)
-        return FOCUS_ERR_NULL;
+                                   float eps, int dtype, void* wl, void* stream) {
+    if (!k_t || !v_t || !q || !attn_vis || !colsum || !upd || !dupd || !dq || !partial) return FOCUS_ERR_NULL;
+    if (!wl && (!dk_t || !dv_t)) return FOCUS_ERR_NULL;
+    if (wl && !focus_slot_kv_grad_ok(K, D, dtype, 1)) return FOCUS_ERR_SHAPE;
     if (B <= 0 || N <= 0 || K <= 0 || K > 32 || D <= 0 || D > 256 || B > 65535) return FOCUS_ERR_SHAPE;
     if (partial_bytes < focus_slot_attn_workspace_bytes(B, N, K, D)) return FOCUS_ERR_WORKSPACE;
     hipStream_t s = (hipStream_t)stream;
-    if (slot_mfma_ok(k_t, v_t, q, kv_bs, K, D, dtype) && focus_aligned(dk_t, 8) && focus_aligned(dv_t, 8)) {
+    if (wl && !(slot_mfma_ok(k_t, v_t, q, kv_bs, K, D, dtype) && focus_aligned(wl, 16))) return FOCUS_ERR_ALIGN;
+    if (slot_mfma_ok(k_t, v_t, q, kv_bs, K, D, dtype) && (wl || (focus_aligned(dk_t, 8) && focus_aligned(dv_t, 8)))) {
         dim3 gm(nchunks_mfma(N), B);
-#define SBM(KS) hipLaunchKernelGGL((slot_bwd_mfma_kernel<KS>), gm, dim3(256), 0, s, (const bf16_t*)k_t, (const bf16_t*)v_t, kv_bs, (const bf16_t*)q, (const bf16_t*)attn_vis, attn_bs, colsum, (const bf16_t*)upd, (const bf16_t*)dupd, (const bf16_t*)dattn_vis, (bf16_t*)dk_t, (bf16_t*)dv_t, accumulate, (float*)partial, N, K, eps)
+#define SBM(KS) do { \
+        if (wl) hipLaunchKernelGGL((slot_bwd_mfma_kernel<KS, true>), gm, dim3(256), 0, s, (const bf16_t*)k_t, (const bf16_t*)v_t, kv_bs, (const bf16_t*)q, (const bf16_t*)attn_vis, attn_bs, colsum, (const bf16_t*)upd, (const bf16_t*)dupd, (const bf16_t*)dattn_vis, (bf16_t*)nullptr, (bf16_t*)nullptr, 0, (bf16_t*)wl, (float*)partial, N, K, eps); \
+        else hipLaunchKernelGGL((slot_bwd_mfma_kernel<KS, false>), gm, dim3(256), 0, s, (const bf16_t*)k_t, (const bf16_t*)v_t, kv_bs, (const bf16_t*)q, (const bf16_t*)attn_vis, attn_bs, colsum, (const bf16_t*)upd, (const bf16_t*)dupd, (const bf16_t*)dattn_vis, (bf16_t*)dk_t, (bf16_t*)dv_t, accumulate, (bf16_t*)nullptr, (float*)partial, N, K, eps); } while (0)
         if (D == 64) SBM(2); else if (D == 128) SBM(4); else if (D == 192) SBM(6); else SBM(8);
 #undef SBM
         FOCUS_CHECK_LAUNCH();
@@ -614,6 +718,41 @@ extern "C" int focus_slot_attn_bwd(const void* k_t, const void* v_t, int64_t kv_
     else
         hipLaunchKernelGGL((slot_bwd_finish<float>), dim3(K, B), dim3(64), 0, s, (const float*)partial, (float*)dq,
                            nchunks(N), K, D);
+    FOCUS_CHECK_LAUNCH();
+    return FOCUS_OK;
+}
+
+extern "C" int focus_slot_kv_grad_ok(int K, int D, int dtype, int iters) {
+    static const bool enabled = !(getenv("FOCUS_SLOT_KV_DEFER") && atoi(getenv("FOCUS_SLOT_KV_DEFER")) == 0);
+    return enabled && dtype == FOCUS_BF16 && K >= 1 && K <= 16 && (D == 64 || D == 128 || D == 192 || D == 256) && iters >= 1 &&
+           iters <= 4;
+}
+
+extern "C" int focus_slot_kv_grad(const void* wl0, const void* wl1, const void* wl2, const void* wl3, const void* q0,
+                                  const void* q1, const void* q2, const void* q3, const void* du0, const void* du1,
+                                  const void* du2, const void* du3, int iters, void* dk_t, void* dv_t, int64_t kv_bs, int B,
+                                  int N, int K, int D, int dtype, void* stream) {
+    if (!dk_t || !dv_t) return FOCUS_ERR_NULL;
+    if (B <= 0 || N <= 0 || B > 65535 || !focus_slot_kv_grad_ok(K, D, dtype, iters) || (kv_bs & 3)) return FOCUS_ERR_SHAPE;
+    KvGradArgs a;
+    const void* wl[4] = {wl0, wl1, wl2, wl3};
+    const void* q[4] = {q0, q1, q2, q3};
+    const void* du[4] = {du0, du1, du2, du3};
+    for (int i = 0; i < 4; ++i) {
+        if (i < iters && (!wl[i] || !q[i] || !du[i])) return FOCUS_ERR_NULL;
+        if (i < iters && !focus_aligned(wl[i], 16)) return FOCUS_ERR_ALIGN;
+        a.wl[i] = (const bf16_t*)wl[i]; a.q[i] = (const bf16_t*)q[i]; a.du[i] = (const bf16_t*)du[i];
+    }
+    if (!focus_aligned(dk_t, 8) || !focus_aligned(dv_t, 8)) return FOCUS_ERR_ALIGN;
+    hipStream_t s = (hipStream_t)stream;
+    dim3 grid(nchunks_mfma(N), B);
+    const size_t lds = (size_t)2 * D * SROW;
+#define SKV(KS) do { \
+        static bool once = (hipFuncSetAttribute((const void*)slot_kv_grad_kernel<KS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess); \
+        (void)once; \
+        hipLaunchKernelGGL((slot_kv_grad_kernel<KS>), grid, dim3(256), lds, s, a, iters, (bf16_t*)dk_t, (bf16_t*)dv_t, kv_bs, N, K); } while (0)
+    if (D == 64) SKV(2); else if (D == 128) SKV(4); else if (D == 192) SKV(6); else SKV(8);
+#undef SKV
     FOCUS_CHECK_LAUNCH();
     return FOCUS_OK;
 }

@@ -1193,15 +1193,19 @@ def label_smoothing_ce(logits, target, smoothing=0.1):
 # Slot attention
 # --------------------------------------------------------------------------------------------------
 class SlotKVGrad:
-    """Shared gradient accumulator for the k_t / v_t of ONE frame.  The corrector iterations of a frame all read the same
-    k_t, v_t (steve.py:68-83); autograd would sum their three 50 MB gradients with separate add kernels (96 adds per
-    BASELINE step).  Iterations that carry the same SlotKVGrad add into one buffer inside the backward kernel
-    (focus_slot_attn_bwd accumulate=1); the node whose backward runs last hands the sum to autograd, the others return
-    None.  Valid because every iteration of a frame is on the path to the loss (the slots chain through them)."""
+    """Shared gradient state for the k_t / v_t of ONE frame.  The corrector iterations of a frame all read the same k_t,
+    v_t (steve.py:68-83); autograd would sum their three 50 MB gradients with separate add kernels (96 adds per BASELINE
+    step).  Iterations that carry the same SlotKVGrad hand autograd ONE gradient, from the node whose backward runs
+    last (the others return None) -- valid because every iteration of a frame is on the path to the loss (the slots
+    chain through them).  bf16 / K <= 16 / <= 4 iterations: the per-iteration backward only writes its 64-byte
+    (w, dlogits) rows and the last node forms dk, dv for all iterations with one MFMA kernel (focus_slot_kv_grad);
+    otherwise the backward kernels add into one buffer (focus_slot_attn_bwd accumulate=1)."""
 
     def __init__(self):
         self.dk = self.dv = None
         self.pending = 0
+        self.total = 0
+        self.items = []              # deferred mode: (wl, q, dupd) per iteration
 
 
 class _SlotAttnFn(torch.autograd.Function):
@@ -1227,6 +1231,7 @@ class _SlotAttnFn(torch.autograd.Function):
         ctx.acc = acc
         if acc is not None:
             acc.pending += 1
+            acc.total += 1
         return upd, attn
 
     @staticmethod
@@ -1237,6 +1242,28 @@ class _SlotAttnFn(torch.autograd.Function):
         dupd = dupd.contiguous()
         dattn = dattn.contiguous() if dattn is not None else None
         acc = ctx.acc
+        L = _lib.lib()
+        nb = L.focus_slot_attn_workspace_bytes(B, N, K, D)
+        ws = torch.empty(nb, device=k_t.device, dtype=torch.uint8)
+        dq = torch.empty_like(q)
+        if acc is not None and L.focus_slot_kv_grad_ok(K, D, _dt(k_t), acc.total):
+            # deferred: this launch writes its (w, dlogits) rows; the frame's last node forms dk, dv for all iterations
+            wl = torch.empty(B, N, 32, device=k_t.device, dtype=k_t.dtype)
+            _lib.check(L.focus_slot_attn_bwd(_p(k_t), _p(v_t), N * D, _p(q), _p(attn), N * K, _p(cs), _p(upd), _p(dupd),
+                                             _p(dattn), None, None, 0, _p(dq), _p(ws), nb, B, N, K, D, ctx.eps,
+                                             _dt(k_t), _p(wl), _stream()), "slot_attn_bwd")
+            acc.items.append((wl, q, dupd))
+            acc.pending -= 1
+            if acc.pending > 0:
+                return None, None, dq, None, None
+            it = acc.items + [(None, None, None)] * (4 - len(acc.items))
+            dk, dv = torch.empty_like(k_t), torch.empty_like(v_t)
+            _lib.check(L.focus_slot_kv_grad(*[_p(e[0]) for e in it], *[_p(e[1]) for e in it], *[_p(e[2]) for e in it],
+                                            len(acc.items), _p(dk), _p(dv), N * D, B, N, K, D, _dt(k_t), _stream()),
+                       "slot_kv_grad")
+            acc.items = []
+            acc.total = 0
+            return dk, dv, dq, None, None
         accumulate = 0
         if acc is not None and acc.dk is not None:
             dk, dv, accumulate = acc.dk, acc.dv, 1
@@ -1244,18 +1271,15 @@ class _SlotAttnFn(torch.autograd.Function):
             dk, dv = torch.empty_like(k_t), torch.empty_like(v_t)
             if acc is not None:
                 acc.dk, acc.dv = dk, dv
-        dq = torch.empty_like(q)
-        L = _lib.lib()
-        nb = L.focus_slot_attn_workspace_bytes(B, N, K, D)
-        ws = torch.empty(nb, device=k_t.device, dtype=torch.uint8)
         _lib.check(L.focus_slot_attn_bwd(_p(k_t), _p(v_t), N * D, _p(q), _p(attn), N * K, _p(cs), _p(upd), _p(dupd),
                                          _p(dattn), _p(dk), _p(dv), accumulate, _p(dq), _p(ws), nb, B, N, K, D, ctx.eps,
-                                         _dt(k_t), _stream()), "slot_attn_bwd")
+                                         _dt(k_t), None, _stream()), "slot_attn_bwd")
         if acc is not None:
             acc.pending -= 1
             if acc.pending > 0:
                 return None, None, dq, None, None                 # the sum leaves with the last iteration's node
             acc.dk = acc.dv = None
+            acc.total = 0
         return dk, dv, dq, None, None
 
 

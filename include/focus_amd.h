@@ -270,12 +270,22 @@ int focus_slot_attn_fwd(const void* k_t, const void* v_t, int64_t kv_bstride, co
                         int64_t attn_bstride, void* upd, float* colsum, void* partial, size_t partial_bytes,
                         int B, int N, int K, int D, float eps, int dtype, void* stream);
 /* dattn_vis may be NULL (no cotangent on the visualised attention).  dk_t/dv_t written at the same
- * strides as k_t/v_t (accumulate=1: added to the existing contents). */
+ * strides as k_t/v_t (accumulate=1: added to the existing contents).
+ * wl != NULL (focus_slot_kv_grad_ok): d(k_t), d(v_t) are NOT formed here (dk_t, dv_t may be NULL); the launch writes its
+ * rows of w = (attn + eps) / colsum and d(logits) to wl [B,N,32] bf16 (slots 0..15 | 16..31) for focus_slot_kv_grad. */
 int focus_slot_attn_bwd(const void* k_t, const void* v_t, int64_t kv_bstride, const void* q,
                         const void* attn_vis, int64_t attn_bstride, const float* colsum, const void* upd,
                         const void* dupd,
                         const void* dattn_vis, void* dk_t, void* dv_t, int accumulate, void* dq, void* partial,
-                        size_t partial_bytes, int B, int N, int K, int D, float eps, int dtype, void* stream);
+                        size_t partial_bytes, int B, int N, int K, int D, float eps, int dtype, void* wl, void* stream);
+/* d(k_t), d(v_t) of one frame for all `iters` (<= 4) corrector iterations that read it (steve.py:68-83), from the wl rows
+ * of their backward launches and their q / dupd [B,K,D]:  dk = sum_i dlogits_i . q_i,  dv = sum_i w_i . dupd_i  (two MFMA
+ * products with the iterations stacked along the reduction).  bf16, K <= 16, D in {64,128,192,256}. */
+int focus_slot_kv_grad_ok(int K, int D, int dtype, int iters);
+int focus_slot_kv_grad(const void* wl0, const void* wl1, const void* wl2, const void* wl3, const void* q0, const void* q1,
+                       const void* q2, const void* q3, const void* du0, const void* du1, const void* du2, const void* du3,
+                       int iters, void* dk_t, void* dv_t, int64_t kv_bstride, int B, int N, int K, int D, int dtype,
+                       void* stream);
 
 /* nn.GRUCell gate math (STEVE/utils.py:107-118): gi, gh [R,3D] (bias already added), h [R,D] -> hn. */
 int focus_gru_gates_fwd(const void* gi, const void* gh, const void* h, void* hn, int R, int D, int dtype,

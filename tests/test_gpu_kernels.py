@@ -279,6 +279,67 @@ def test_slot_attention_kernels_tight():
     ck.done()
 
 
+@pytest.mark.parametrize("iters,N,K,D", [(3, 4096, 11, 192), (1, 300, 16, 64), (4, 1000, 7, 128), (2, 77, 3, 256)])
+def test_slot_kv_grad_shared_by_the_iterations_of_a_frame(iters, N, K, D):
+    """d(k_t), d(v_t) when `iters` corrector iterations read the same k_t, v_t (steve.py:68-83) through one SlotKVGrad:
+    the per-iteration backward writes (w, dlogits) rows, slot_kv_grad_kernel forms both gradients once.  Against fp64 on
+    the same bf16 values, with the magnitude-scaled bounds of the single-iteration test summed over the iterations."""
+    from focus_amd import ops
+    B = 2
+    d = dev()
+    g = torch.Generator().manual_seed(10 * iters + K)
+    k = bf(torch.randn(B, N, D, generator=g) * D ** -0.5)
+    v = bf(torch.randn(B, N, D, generator=g))
+    qs = [bf(torch.randn(B, K, D, generator=g)) for _ in range(iters)]
+    cus = [bf(torch.randn(B, K, D, generator=g)) for _ in range(iters)]
+    cas = [bf(torch.randn(B, N, K, generator=g) * 1e-2) for _ in range(iters)]
+    kr, vr = k.double().requires_grad_(), v.double().requires_grad_()
+    qr = [q.double().requires_grad_() for q in qs]
+    loss = 0.0
+    mag_v = mag_k = 0.0
+    avs = []
+    for i in range(iters):
+        av = torch.softmax(kr @ qr[i].transpose(-1, -2), dim=-1)
+        av.retain_grad()
+        avs.append(av)
+        aa = av + 1e-8
+        w_ = aa / aa.sum(dim=-2, keepdim=True)
+        loss = loss + ((w_.transpose(-1, -2) @ vr) * cus[i].double()).sum() + (av * cas[i].double()).sum()
+        mag_v = mag_v + w_.detach() @ cus[i].double().abs()
+    loss.backward()
+    with torch.no_grad():
+        for i in range(iters):
+            gabs = avs[i].grad.abs()
+            dlg = avs[i].detach() * (gabs + (avs[i].detach() * gabs).sum(-1, keepdim=True))
+            mag_k = mag_k + dlg @ qr[i].abs()
+    from focus_amd import _lib
+    assert _lib.lib().focus_slot_kv_grad_ok(K, D, 1, iters)              # the deferred kernel is what runs (FOCUS_BF16 = 1)
+    kg, vg = k.to(d).requires_grad_(), v.to(d).requires_grad_()
+    qg = [q.to(d).requires_grad_() for q in qs]
+    acc = ops.SlotKVGrad()
+    lg = 0.0
+    for i in range(iters):
+        u2, a2 = ops.slot_attn_step(kg, vg, qg[i], 1e-8, acc)
+        lg = lg + (u2.float() * cus[i].to(d).float()).sum() + (a2.float() * cas[i].to(d).float()).sum()
+    lg.backward()
+    ck = Check()
+    # one more bf16 rounding than the fused form: w and dlogits are stored as bf16 before the product
+    ck.tight(vg.grad, vr.grad, "slot dv (kv_grad)", rtol=1.5 * RT, mag=mag_v)
+    ck.tight(kg.grad, kr.grad, "slot dk (kv_grad)", rtol=1.5 * RT, mag=mag_k)
+    for i in range(iters):
+        assert qg[i].grad is not None and torch.isfinite(qg[i].grad.float()).all()
+    # and the same sums as autograd forms them from independent calls (no shared state), to bf16 accumulation accuracy
+    k2, v2 = k.to(d).requires_grad_(), v.to(d).requires_grad_()
+    l2 = 0.0
+    for i in range(iters):
+        u2, a2 = ops.slot_attn_step(k2, v2, qs[i].to(d), 1e-8)
+        l2 = l2 + (u2.float() * cus[i].to(d).float()).sum() + (a2.float() * cas[i].to(d).float()).sum()
+    l2.backward()
+    ck.tight(vg.grad, v2.grad.double(), "dv vs per-call path", rtol=2 * RT, mag=mag_v.to(d))
+    ck.tight(kg.grad, k2.grad.double(), "dk vs per-call path", rtol=2 * RT, mag=mag_k.to(d))
+    ck.done()
+
+
 @pytest.mark.parametrize("F_,heads,S", [(8, 12, 1568), (4, 2, 100), (16, 3, 50), (8, 16, 43), (8, 6, 33), (4, 11, 37),
                                         (16, 16, 21), (8, 1, 70)])
 def test_time2_kernels_tight(F_, heads, S):
