@@ -178,9 +178,12 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const focus_gemm_desc d
     }
 }
 
+__global__ void tn_reduce_many_kernel(const float* __restrict__ parts, float* __restrict__ out, int64_t n4, int splits, int N,
+                                      int64_t rsC);
+// Sum of the split slabs, few splits (large outputs): one float4 per thread, the splits walked in order.
 __global__ void tn_reduce_kernel(const float* __restrict__ parts, float* __restrict__ out, int64_t n4, int splits,
                                  int N, int64_t rsC) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // one float4 per thread
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n4) return;
     float4 s = reinterpret_cast<const float4*>(parts)[i];
     for (int k = 1; k < splits; ++k) {
@@ -189,6 +192,47 @@ __global__ void tn_reduce_kernel(const float* __restrict__ parts, float* __restr
     }
     const int64_t e = i * 4, row = e / N, col = e % N;
     *reinterpret_cast<float4*>(out + row * rsC + col) = s;
+}
+
+static void launch_tn_reduce(const float* parts, float* out, int64_t n4, int splits, int N, int64_t rsC, hipStream_t s) {
+    if (splits >= 16)
+        hipLaunchKernelGGL(tn_reduce_many_kernel, dim3((unsigned)cdiv64(n4, 16)), dim3(256), 0, s, parts, out, n4, splits, N, rsC);
+    else
+        hipLaunchKernelGGL(tn_reduce_kernel, dim3((unsigned)cdiv64(n4, 256)), dim3(256), 0, s, parts, out, n4, splits, N, rsC);
+}
+
+// Many splits (small outputs).  16 float4 columns x 16 split lanes per block: a small output with many splits (192 x 192 from
+// 128 slabs -- the per-frame k/v projection gradients of STEVE) used to be 36 blocks walking 128 slabs serially
+// (31 us, as long as the GEMM itself); the split lanes issue their loads together and meet in LDS.
+__global__ __launch_bounds__(256) void tn_reduce_many_kernel(const float* __restrict__ parts, float* __restrict__ out, int64_t n4,
+                                                             int splits, int N, int64_t rsC) {
+    __shared__ float4 red[16][16];
+    const int c = threadIdx.x & 15, sl = threadIdx.x >> 4;
+    const int64_t i = (int64_t)blockIdx.x * 16 + c;                     // one float4 column per 16 threads
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (i < n4) {
+        int k = sl;
+        for (; k + 48 < splits; k += 64) {                               // four loads in flight per thread
+            const float4 a = reinterpret_cast<const float4*>(parts)[(int64_t)k * n4 + i];
+            const float4 b = reinterpret_cast<const float4*>(parts)[(int64_t)(k + 16) * n4 + i];
+            const float4 cc = reinterpret_cast<const float4*>(parts)[(int64_t)(k + 32) * n4 + i];
+            const float4 d = reinterpret_cast<const float4*>(parts)[(int64_t)(k + 48) * n4 + i];
+            s.x += (a.x + b.x) + (cc.x + d.x); s.y += (a.y + b.y) + (cc.y + d.y);
+            s.z += (a.z + b.z) + (cc.z + d.z); s.w += (a.w + b.w) + (cc.w + d.w);
+        }
+        for (; k < splits; k += 16) {
+            const float4 v = reinterpret_cast<const float4*>(parts)[(int64_t)k * n4 + i];
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+    }
+    red[sl][c] = s;
+    __syncthreads();
+    if (sl == 0 && i < n4) {
+#pragma unroll
+        for (int r = 1; r < 16; ++r) { const float4 v = red[r][c]; s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w; }
+        const int64_t e = i * 4, row = e / N, col = e % N;
+        *reinterpret_cast<float4*>(out + row * rsC + col) = s;
+    }
 }
 
 // out[n] = sum_r parts[r][n] for a short, wide slab (bias-gradient partials: tens of rows, N columns).  tn_reduce_kernel
@@ -305,8 +349,7 @@ int focus_gemm_mfma_tn(const focus_gemm_desc& d, hipStream_t s) {
         if (rc != FOCUS_OK) return rc;
         if (d.aux) {
             const int64_t n4 = (int64_t)d.M * d.N / 4;
-            hipLaunchKernelGGL(tn_reduce_kernel, dim3((unsigned)cdiv64(n4, 256)), dim3(256), 0, s, (const float*)d.aux,
-                               (float*)d.C, n4, ws.splits, d.N, d.rsC);
+            launch_tn_reduce((const float*)d.aux, (float*)d.C, n4, ws.splits, d.N, d.rsC, s);
             FOCUS_CHECK_LAUNCH();
         }
         return FOCUS_OK;
@@ -325,8 +368,7 @@ int focus_gemm_mfma_tn(const focus_gemm_desc& d, hipStream_t s) {
     FOCUS_CHECK_LAUNCH();
     if (d.aux && !direct) {
         const int64_t n4 = (int64_t)nb * d.M * d.N / 4;
-        hipLaunchKernelGGL(tn_reduce_kernel, dim3((unsigned)cdiv64(n4, 256)), dim3(256), 0, s, (const float*)d.aux,
-                           (float*)d.C, n4, splits, d.N, d.rsC);
+        launch_tn_reduce((const float*)d.aux, (float*)d.C, n4, splits, d.N, d.rsC, s);
         FOCUS_CHECK_LAUNCH();
     }
     return FOCUS_OK;

@@ -92,19 +92,34 @@ __global__ __launch_bounds__(256) void slot_fwd_kernel(const T* __restrict__ kt,
     }
 }
 
-// grid (K, B): reduce partials over chunks, normalise.
+// grid (K, B), 256 threads = 64 channel lanes x 4 chunk lanes: reduce the partials over the chunks, normalise.  (With 64
+// threads walking the chunks one after the other the launch was a chain of dependent L2 round trips: 16.6 us for 16
+// chunks; here every thread's loads are independent and the four chunk lanes meet in LDS.)
 template <typename T>
-__global__ void slot_fwd_finish(const float* __restrict__ partial, T* __restrict__ upd, float* __restrict__ colsum,
-                                int nchunk, int K, int D) {
-    const int k = blockIdx.x, b = blockIdx.y;
+__global__ __launch_bounds__(256) void slot_fwd_finish(const float* __restrict__ partial, T* __restrict__ upd,
+                                                       float* __restrict__ colsum, int nchunk, int K, int D) {
+    __shared__ float red[4][4][64], redc[4];
+    const int k = blockIdx.x, b = blockIdx.y, lane = threadIdx.x & 63, cl = threadIdx.x >> 6;
     const float* p = partial + (int64_t)b * nchunk * K * (D + 1) + (int64_t)k * (D + 1);
-    float c = 0.f;
-    for (int ch = 0; ch < nchunk; ++ch) c += p[(int64_t)ch * K * (D + 1) + D];
-    if (threadIdx.x == 0) colsum[b * K + k] = c;
-    for (int e = threadIdx.x; e < D; e += blockDim.x) {
-        float s = 0.f;
-        for (int ch = 0; ch < nchunk; ++ch) s += p[(int64_t)ch * K * (D + 1) + e];
-        st<T>(upd + ((int64_t)b * K + k) * D + e, s / c);
+    float s[4] = {0.f, 0.f, 0.f, 0.f}, c = 0.f;
+    for (int ch = cl; ch < nchunk; ch += 4) {
+        const float* pc = p + (int64_t)ch * K * (D + 1);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (lane + 64 * j < D) s[j] += pc[lane + 64 * j];
+        if (lane == 0) c += pc[D];
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) red[cl][j][lane] = s[j];
+    if (lane == 0) redc[cl] = c;
+    __syncthreads();
+    if (cl == 0) {
+        c = redc[0] + redc[1] + redc[2] + redc[3];
+        if (lane == 0) colsum[b * K + k] = c;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (lane + 64 * j < D)
+                st<T>(upd + ((int64_t)b * K + k) * D + lane + 64 * j, (red[0][j][lane] + red[1][j][lane] + red[2][j][lane] + red[3][j][lane]) / c);
     }
 }
 
@@ -218,12 +233,25 @@ __global__ __launch_bounds__(256) void slot_bwd_kernel(const T* __restrict__ kt,
 }
 
 template <typename T>
-__global__ void slot_bwd_finish(const float* __restrict__ partial, T* __restrict__ dq, int nchunk, int K, int D) {
-    const int k = blockIdx.x, b = blockIdx.y;
-    for (int e = threadIdx.x; e < D; e += blockDim.x) {
-        float s = 0.f;
-        for (int ch = 0; ch < nchunk; ++ch) s += partial[(((int64_t)b * nchunk + ch) * K + k) * D + e];
-        st<T>(dq + ((int64_t)b * K + k) * D + e, s);
+__global__ __launch_bounds__(256) void slot_bwd_finish(const float* __restrict__ partial, T* __restrict__ dq, int nchunk, int K,
+                                                       int D) {
+    __shared__ float red[4][4][64];
+    const int k = blockIdx.x, b = blockIdx.y, lane = threadIdx.x & 63, cl = threadIdx.x >> 6;
+    float s[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int ch = cl; ch < nchunk; ch += 4) {
+        const float* pc = partial + (((int64_t)b * nchunk + ch) * K + k) * D;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (lane + 64 * j < D) s[j] += pc[lane + 64 * j];
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) red[cl][j][lane] = s[j];
+    __syncthreads();
+    if (cl == 0) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (lane + 64 * j < D)
+                st<T>(dq + ((int64_t)b * K + k) * D + lane + 64 * j, red[0][j][lane] + red[1][j][lane] + red[2][j][lane] + red[3][j][lane]);
     }
 }
 
@@ -530,6 +558,7 @@ __global__ __launch_bounds__(256) void slot_bwd_mfma_kernel(const bf16_t* __rest
 // ------------------------------------------------------------------------------------------------
 struct KvGradArgs { const bf16_t* wl[4]; const bf16_t* q[4]; const bf16_t* du[4]; };
 constexpr int SROW = 64 * 2 + 16;                 // bytes per channel row of the stacked slot image (64 slots + pad)
+constexpr int KVSUB = 2;                          // row blocks of 256 per workgroup (B = 32, N = 4096: 256 workgroups)
 
 template <int KS>
 __global__ __launch_bounds__(256) void slot_kv_grad_kernel(const KvGradArgs a, int iters, bf16_t* __restrict__ dkt,
@@ -540,14 +569,21 @@ __global__ __launch_bounds__(256) void slot_kv_grad_kernel(const KvGradArgs a, i
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int t16 = lane & 15, g = lane >> 4;
     // stacked transposed slot matrices: img[m][d][i*16 + k] = (m ? dupd_i : q_i)[b][k][d], zero for k >= K or i >= iters
-    for (int e = tid; e < 2 * D * 64; e += 256) {
-        const int m = e / (D * 64), r = e - m * D * 64, d = r >> 6, sl = r & 63, i = sl >> 4, k = sl & 15;
-        bf16_t v = 0;
-        if (i < iters && k < K) v = (m ? a.du[i] : a.q[i])[((int64_t)b * K + k) * D + d];
-        *reinterpret_cast<bf16_t*>(smem + (m * D + d) * SROW + sl * 2) = v;
+    // (one 16-byte read of 8 channels of a slot row -> 8 two-byte LDS writes; a workgroup keeps the image for KVSUB
+    // row blocks, so the transpose is amortised over 512 rows)
+    for (int e = tid; e < 2 * 64 * (D / 8); e += 256) {
+        const int m = e / (64 * (D / 8)), r = e - m * 64 * (D / 8), sl = r / (D / 8), d8 = r - sl * (D / 8);
+        const int i = sl >> 4, k = sl & 15;
+        SPk8 v;
+        v.u = make_uint4(0, 0, 0, 0);
+        if (i < iters && k < K) v.u = *reinterpret_cast<const uint4*>((m ? a.du[i] : a.q[i]) + ((int64_t)b * K + k) * D + d8 * 8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) *reinterpret_cast<bf16_t*>(smem + (m * D + d8 * 8 + j) * SROW + sl * 2) = v.e[j];
     }
     __syncthreads();
-    const int n0 = chunk * MROWS + w * 64;
+  for (int sub = 0; sub < KVSUB; ++sub) {
+    const int n0 = (chunk * KVSUB + sub) * MROWS + w * 64;
+    if (n0 >= N) break;
     // B operands (column = row n of the tile, k = 8 consecutive stacked slots): (w | dlogits) rows straight from HBM
     SPk8 fw[4][2], fl[4][2];
 #pragma unroll
@@ -594,6 +630,7 @@ __global__ __launch_bounds__(256) void slot_kv_grad_kernel(const KvGradArgs a, i
             }
         }
     }
+  }
 }
 
 inline bool slot_mfma_ok(const void* a, const void* b, const void* c, int64_t kv_bs, int K, int D, int dtype) {
@@ -636,7 +673,7 @@ extern "C" int focus_slot_attn_fwd(const void* k_t, const void* v_t, int64_t kv_
         if (D == 64) SFM(2); else if (D == 128) SFM(4); else if (D == 192) SFM(6); else SFM(8);
 #undef SFM
         FOCUS_CHECK_LAUNCH();
-        hipLaunchKernelGGL((slot_fwd_finish<bf16_t>), dim3(K, B), dim3(64), 0, s, (const float*)partial, (bf16_t*)upd, colsum,
+        hipLaunchKernelGGL((slot_fwd_finish<bf16_t>), dim3(K, B), dim3(256), 0, s, (const float*)partial, (bf16_t*)upd, colsum,
                            nchunks_mfma(N), K, D);
         FOCUS_CHECK_LAUNCH();
         return FOCUS_OK;
@@ -659,10 +696,10 @@ extern "C" int focus_slot_attn_fwd(const void* k_t, const void* v_t, int64_t kv_
 #undef SLOT_CASE
     FOCUS_CHECK_LAUNCH();
     if (dtype == FOCUS_BF16)
-        hipLaunchKernelGGL((slot_fwd_finish<bf16_t>), dim3(K, B), dim3(64), 0, s, (const float*)partial, (bf16_t*)upd,
+        hipLaunchKernelGGL((slot_fwd_finish<bf16_t>), dim3(K, B), dim3(256), 0, s, (const float*)partial, (bf16_t*)upd,
                            colsum, nchunks(N), K, D);
     else
-        hipLaunchKernelGGL((slot_fwd_finish<float>), dim3(K, B), dim3(64), 0, s, (const float*)partial, (float*)upd,
+        hipLaunchKernelGGL((slot_fwd_finish<float>), dim3(K, B), dim3(256), 0, s, (const float*)partial, (float*)upd,
                            colsum, nchunks(N), K, D);
     FOCUS_CHECK_LAUNCH();
     return FOCUS_OK;
@@ -688,7 +725,7 @@ extern "C" int focus_slot_attn_bwd(const void* k_t, const void* v_t, int64_t kv_
         if (D == 64) SBM(2); else if (D == 128) SBM(4); else if (D == 192) SBM(6); else SBM(8);
 #undef SBM
         FOCUS_CHECK_LAUNCH();
-        hipLaunchKernelGGL((slot_bwd_finish<bf16_t>), dim3(K, B), dim3(64), 0, s, (const float*)partial, (bf16_t*)dq,
+        hipLaunchKernelGGL((slot_bwd_finish<bf16_t>), dim3(K, B), dim3(256), 0, s, (const float*)partial, (bf16_t*)dq,
                            nchunks_mfma(N), K, D);
         FOCUS_CHECK_LAUNCH();
         return FOCUS_OK;
@@ -713,10 +750,10 @@ extern "C" int focus_slot_attn_bwd(const void* k_t, const void* v_t, int64_t kv_
 #undef SLOT_CASE
     FOCUS_CHECK_LAUNCH();
     if (dtype == FOCUS_BF16)
-        hipLaunchKernelGGL((slot_bwd_finish<bf16_t>), dim3(K, B), dim3(64), 0, s, (const float*)partial, (bf16_t*)dq,
+        hipLaunchKernelGGL((slot_bwd_finish<bf16_t>), dim3(K, B), dim3(256), 0, s, (const float*)partial, (bf16_t*)dq,
                            nchunks(N), K, D);
     else
-        hipLaunchKernelGGL((slot_bwd_finish<float>), dim3(K, B), dim3(64), 0, s, (const float*)partial, (float*)dq,
+        hipLaunchKernelGGL((slot_bwd_finish<float>), dim3(K, B), dim3(256), 0, s, (const float*)partial, (float*)dq,
                            nchunks(N), K, D);
     FOCUS_CHECK_LAUNCH();
     return FOCUS_OK;
@@ -745,7 +782,7 @@ extern "C" int focus_slot_kv_grad(const void* wl0, const void* wl1, const void* 
     }
     if (!focus_aligned(dk_t, 8) || !focus_aligned(dv_t, 8)) return FOCUS_ERR_ALIGN;
     hipStream_t s = (hipStream_t)stream;
-    dim3 grid(nchunks_mfma(N), B);
+    dim3 grid((nchunks_mfma(N) + KVSUB - 1) / KVSUB, B);
     const size_t lds = (size_t)2 * D * SROW;
 #define SKV(KS) do { \
         static bool once = (hipFuncSetAttribute((const void*)slot_kv_grad_kernel<KS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess); \
