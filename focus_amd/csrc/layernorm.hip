@@ -10,11 +10,11 @@ template <typename T, int NV>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, T* __restrict__ y,
                                                      float* __restrict__ mean, float* __restrict__ rstd, int rows,
-                                                     int D, float eps) {
+                                                     int D, float eps, int rpb, int64_t xbs) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
-    const T* xr = x + (int64_t)row * D;
+    const T* xr = x + (int64_t)(row / rpb) * xbs + (int64_t)(row % rpb) * D;   // row blocks of rpb rows, xbs elements apart
     f4 v[NV];
     float s = 0.f;
 #pragma unroll
@@ -54,8 +54,11 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
                                                      const float* __restrict__ gamma,
                                                      const float* __restrict__ mean,
                                                      const float* __restrict__ rstd, const T* __restrict__ dres,
-                                                     T* __restrict__ dx, float* __restrict__ partial, int rows, int D) {
+                                                     T* __restrict__ dx, float* __restrict__ partial, int rows, int D,
+                                                     int rpb, int64_t xbs) {
     __shared__ float red[4][64 * 4 + 4];
+    // x and dx live in row blocks of rpb rows, xbs elements apart (dense: rpb = rows); dy and dres are dense
+    auto xoff = [&](int row) __attribute__((always_inline)) { return (int64_t)(row / rpb) * xbs + (int64_t)(row % rpb) * D; };
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     f4 dg[NV], db[NV], g[NV];
 #pragma unroll
@@ -78,8 +81,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
         for (int i = 0; i < NV; ++i) {
             const int c = (i * 64 + lane) * 4;
             if (c < D) {
-                xa[i] = ld4<T>(x + (int64_t)row0 * D + c); da[i] = ld4<T>(dy + (int64_t)row0 * D + c);
-                xb[i] = ld4<T>(x + (int64_t)rowB * D + c); dbv[i] = ld4<T>(dy + (int64_t)rowB * D + c);
+                xa[i] = ld4<T>(x + xoff(row0) + c); da[i] = ld4<T>(dy + (int64_t)row0 * D + c);
+                xb[i] = ld4<T>(x + xoff(rowB) + c); dbv[i] = ld4<T>(dy + (int64_t)rowB * D + c);
             }
         }
 #pragma unroll
@@ -102,7 +105,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
                 }
             }
             const float m1 = wave_sum(s1) / (float)D, m2 = wave_sum(s2) / (float)D;
-            T* dxr = dx + (int64_t)(rr ? row1 : row0) * D;
+            T* dxr = dx + xoff(rr ? row1 : row0);
 #pragma unroll
             for (int i = 0; i < NV; ++i) {
                 const int c = (i * 64 + lane) * 4;
@@ -165,10 +168,10 @@ __global__ __launch_bounds__(256) void ln_bwd_finish(const float* __restrict__ p
 
 template <typename T>
 int ln_fwd_launch(const void* x, const float* g, const float* b, void* y, float* mean, float* rstd, int rows, int D,
-                  float eps, hipStream_t s) {
+                  float eps, int rpb, int64_t xbs, hipStream_t s) {
     const int nv = (D + 255) / 256;
     dim3 grid((rows + 3) / 4), blk(256);
-#define LN_FWD(NV) hipLaunchKernelGGL((ln_fwd_kernel<T, NV>), grid, blk, 0, s, (const T*)x, g, b, (T*)y, mean, rstd, rows, D, eps)
+#define LN_FWD(NV) hipLaunchKernelGGL((ln_fwd_kernel<T, NV>), grid, blk, 0, s, (const T*)x, g, b, (T*)y, mean, rstd, rows, D, eps, rpb, xbs)
     if (nv <= 1) LN_FWD(1); else if (nv <= 2) LN_FWD(2); else if (nv <= 3) LN_FWD(3); else if (nv <= 4) LN_FWD(4);
     else if (nv <= 8) LN_FWD(8); else LN_FWD(16);
 #undef LN_FWD
@@ -178,10 +181,10 @@ int ln_fwd_launch(const void* x, const float* g, const float* b, void* y, float*
 
 template <typename T>
 int ln_bwd_launch(const void* dy, const void* x, const float* g, const float* mean, const float* rstd, const void* dres,
-                  void* dx, float* partial, int rows, int D, int nblk, hipStream_t s) {
+                  void* dx, float* partial, int rows, int D, int nblk, int rpb, int64_t xbs, hipStream_t s) {
     const int nv = (D + 255) / 256;
     dim3 grid(nblk), blk(256);
-#define LN_BWD(NV) hipLaunchKernelGGL((ln_bwd_kernel<T, NV>), grid, blk, 0, s, (const T*)dy, (const T*)x, g, mean, rstd, (const T*)dres, (T*)dx, partial, rows, D)
+#define LN_BWD(NV) hipLaunchKernelGGL((ln_bwd_kernel<T, NV>), grid, blk, 0, s, (const T*)dy, (const T*)x, g, mean, rstd, (const T*)dres, (T*)dx, partial, rows, D, rpb, xbs)
     if (nv <= 1) LN_BWD(1); else if (nv <= 2) LN_BWD(2); else if (nv <= 3) LN_BWD(3); else if (nv <= 4) LN_BWD(4);
     else if (nv <= 8) LN_BWD(8); else LN_BWD(16);
 #undef LN_BWD
@@ -191,16 +194,27 @@ int ln_bwd_launch(const void* dy, const void* x, const float* g, const float* me
 
 }  // namespace
 
-extern "C" int focus_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean,
-                                   float* rstd, int rows, int D, float eps, int dtype, void* stream) {
+static int ln_fwd_any(const void* x, int rpb, int64_t xbs, const float* gamma, const float* beta, void* y, float* mean,
+                      float* rstd, int rows, int D, float eps, int dtype, void* stream) {
     if (!x || !gamma || !beta || !y || !mean || !rstd) return FOCUS_ERR_NULL;
     if (rows <= 0) return FOCUS_OK;
-    if (D <= 0 || (D & 3) || D > MAXV * 256) return FOCUS_ERR_SHAPE;
+    if (D <= 0 || (D & 3) || D > MAXV * 256 || rpb <= 0 || (xbs & 3)) return FOCUS_ERR_SHAPE;
     if (!focus_aligned(x, 8) || !focus_aligned(y, 8) || !focus_aligned(gamma, 16) || !focus_aligned(beta, 16))
         return FOCUS_ERR_ALIGN;
     hipStream_t s = (hipStream_t)stream;
-    return dtype == FOCUS_BF16 ? ln_fwd_launch<bf16_t>(x, gamma, beta, y, mean, rstd, rows, D, eps, s)
-                               : ln_fwd_launch<float>(x, gamma, beta, y, mean, rstd, rows, D, eps, s);
+    return dtype == FOCUS_BF16 ? ln_fwd_launch<bf16_t>(x, gamma, beta, y, mean, rstd, rows, D, eps, rpb, xbs, s)
+                               : ln_fwd_launch<float>(x, gamma, beta, y, mean, rstd, rows, D, eps, rpb, xbs, s);
+}
+
+extern "C" int focus_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean,
+                                   float* rstd, int rows, int D, float eps, int dtype, void* stream) {
+    return ln_fwd_any(x, rows > 0 ? rows : 1, 0, gamma, beta, y, mean, rstd, rows, D, eps, dtype, stream);
+}
+
+extern "C" int focus_layernorm_fwd_blocks(const void* x, int rows_per_block, int64_t block_stride, const float* gamma,
+                                          const float* beta, void* y, float* mean, float* rstd, int rows, int D, float eps,
+                                          int dtype, void* stream) {
+    return ln_fwd_any(x, rows_per_block, block_stride, gamma, beta, y, mean, rstd, rows, D, eps, dtype, stream);
 }
 
 extern "C" int focus_layernorm_bwd_blocks(int rows) {
@@ -208,17 +222,31 @@ extern "C" int focus_layernorm_bwd_blocks(int rows) {
     return b < 1 ? 1 : (b > 512 ? 512 : b);
 }
 
-extern "C" int focus_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean,
-                                   const float* rstd, const void* dres, void* dx, float* dgamma, float* dbeta,
-                                   float* partial, int rows, int D, int dtype, void* stream) {
+static int ln_bwd_any(const void* dy, const void* x, int rpb, int64_t xbs, const float* gamma, const float* mean,
+                      const float* rstd, const void* dres, void* dx, float* dgamma, float* dbeta, float* partial, int rows,
+                      int D, int dtype, void* stream) {
     if (!dy || !x || !gamma || !mean || !rstd || !dx || !dgamma || !dbeta || !partial) return FOCUS_ERR_NULL;
-    if (D <= 0 || (D & 3) || D > MAXV * 256 || rows <= 0) return FOCUS_ERR_SHAPE;
+    if (D <= 0 || (D & 3) || D > MAXV * 256 || rows <= 0 || rpb <= 0 || (xbs & 3)) return FOCUS_ERR_SHAPE;
     hipStream_t s = (hipStream_t)stream;
     const int nblk = focus_layernorm_bwd_blocks(rows);
-    int rc = dtype == FOCUS_BF16 ? ln_bwd_launch<bf16_t>(dy, x, gamma, mean, rstd, dres, dx, partial, rows, D, nblk, s)
-                                 : ln_bwd_launch<float>(dy, x, gamma, mean, rstd, dres, dx, partial, rows, D, nblk, s);
+    int rc = dtype == FOCUS_BF16 ? ln_bwd_launch<bf16_t>(dy, x, gamma, mean, rstd, dres, dx, partial, rows, D, nblk, rpb, xbs, s)
+                                 : ln_bwd_launch<float>(dy, x, gamma, mean, rstd, dres, dx, partial, rows, D, nblk, rpb, xbs, s);
     if (rc) return rc;
     hipLaunchKernelGGL(ln_bwd_finish, dim3((D + 15) / 16, 2), dim3(256), 0, s, partial, dgamma, dbeta, nblk, D);
     FOCUS_CHECK_LAUNCH();
     return FOCUS_OK;
+}
+
+extern "C" int focus_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean,
+                                   const float* rstd, const void* dres, void* dx, float* dgamma, float* dbeta,
+                                   float* partial, int rows, int D, int dtype, void* stream) {
+    return ln_bwd_any(dy, x, rows > 0 ? rows : 1, 0, gamma, mean, rstd, dres, dx, dgamma, dbeta, partial, rows, D, dtype, stream);
+}
+
+extern "C" int focus_layernorm_bwd_blocks_strided(const void* dy, const void* x, int rows_per_block, int64_t block_stride,
+                                                  const float* gamma, const float* mean, const float* rstd, void* dx,
+                                                  float* dgamma, float* dbeta, float* partial, int rows, int D, int dtype,
+                                                  void* stream) {
+    return ln_bwd_any(dy, x, rows_per_block, block_stride, gamma, mean, rstd, nullptr, dx, dgamma, dbeta, partial, rows, D,
+                      dtype, stream);
 }

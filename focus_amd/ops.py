@@ -615,6 +615,77 @@ def unbind_frames(x):
     return _UnbindFramesFn.apply(x)
 
 
+class FrameGrad:
+    """Whole-video gradient buffer shared by the per-frame LayerNorm nodes of one video tensor (see layer_norm_frame)."""
+
+    def __init__(self):
+        self.buf = None
+        self.pending = 0
+        self.frames = 0
+
+
+class _FrameLayerNormFn(torch.autograd.Function):
+    """LayerNorm of frame t of a [B,T,N,D] video tensor, read in place (steve.py:60 normalises the whole video, the
+    slot loop consumes one frame at a time).  Forward: no x[:, t].contiguous() copy.  Backward: every frame's node
+    writes its d(x) rows straight into ONE whole-video buffer (focus_layernorm_bwd_blocks_strided); the node that runs
+    last hands the buffer to autograd, the others return None -- no per-frame copy, no zero-filled whole-video
+    gradients summed by autograd (all T frames must be normalised through the same FrameGrad, which the slot loop does;
+    frames that never ran are zero-filled)."""
+
+    @staticmethod
+    def forward(ctx, video, t, gamma, beta, eps, shared):
+        _need_gpu(video, gamma)
+        assert video.dim() == 4 and video.is_contiguous()
+        B, T, N, D = video.shape
+        rows = B * N
+        y = torch.empty(B, N, D, device=video.device, dtype=video.dtype)
+        mean = torch.empty(rows, device=video.device, dtype=torch.float32)
+        rstd = torch.empty(rows, device=video.device, dtype=torch.float32)
+        _lib.check(_lib.lib().focus_layernorm_fwd_blocks(_p(video, t * N * D), N, T * N * D, _p(gamma), _p(beta), _p(y),
+                                                         _p(mean), _p(rstd), rows, D, eps, _dt(video), _stream()),
+                   "layernorm_fwd_blocks")
+        ctx.save_for_backward(video, gamma, mean, rstd)
+        ctx.t, ctx.shared = t, shared
+        ctx.defer = (gamma, beta) if (_DEFER_ON and gamma.is_leaf and beta.is_leaf) else None
+        shared.pending += 1
+        shared.frames |= 1 << t
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        video, gamma, mean, rstd = ctx.saved_tensors
+        B, T, N, D = video.shape
+        rows, t, sh = B * N, ctx.t, ctx.shared
+        dy = dy.contiguous()
+        if sh.buf is None:
+            sh.buf = torch.empty_like(video)
+            for tt in range(T):
+                if not (sh.frames >> tt) & 1:
+                    sh.buf[:, tt].zero_()
+        L = _lib.lib()
+        nblk = L.focus_layernorm_bwd_blocks(rows)
+        partial = torch.empty(2, nblk, D, device=video.device, dtype=torch.float32)
+        dg = torch.empty(D, device=video.device, dtype=torch.float32)
+        db = torch.empty(D, device=video.device, dtype=torch.float32)
+        _lib.check(L.focus_layernorm_bwd_blocks_strided(_p(dy), _p(video, t * N * D), N, T * N * D, _p(gamma), _p(mean),
+                                                        _p(rstd), _p(sh.buf, t * N * D), _p(dg), _p(db), _p(partial), rows, D,
+                                                        _dt(video), _stream()), "layernorm_bwd_blocks")
+        sh.pending -= 1
+        out = None
+        if sh.pending == 0:
+            out, sh.buf, sh.frames = sh.buf, None, 0
+        if ctx.defer is not None:
+            _defer_vec(ctx.defer[0], dg)
+            _defer_vec(ctx.defer[1], db)
+            dg = db = None
+        return out, None, dg, db, None, None
+
+
+def layer_norm_frame(video, t, gamma, beta, eps, shared):
+    """LayerNorm(video[:, t]) -> [B,N,D]; `shared`: one FrameGrad for all frames of `video`."""
+    return _FrameLayerNormFn.apply(video, t, gamma, beta, eps, shared)
+
+
 def layer_norm(x, gamma, beta, eps):
     return _LayerNormFn.apply(x, gamma, beta, eps)
 

@@ -52,19 +52,19 @@ class SlotAttentionVideo(nn.Module):
         ni, ns, nm = self.norm_inputs, self.norm_slots, self.norm_mlp
         k_scale = Ds ** -0.5
         attns_collect, slots_collect = [], []
-        frames = ops.unbind_frames(inputs) if inputs.requires_grad else [inputs[:, t] for t in range(T)]
         # every parameter below is applied T x num_iterations times: their gradients are formed once, at the end of
         # the backward pass, from the stacked applications (ops.deferred_wgrads)
         with ops.deferred_wgrads():
-            return self._loop(frames, slots, B, T, K, Ds, k_scale)
+            return self._loop(inputs.contiguous(), slots, B, T, K, Ds, k_scale)
 
-    def _loop(self, frames, slots, B, T, K, Ds, k_scale):
+    def _loop(self, inputs, slots, B, T, K, Ds, k_scale):
         ni, ns, nm = self.norm_inputs, self.norm_slots, self.norm_mlp
         attns_collect, slots_collect = [], []
+        video_grad = ops.FrameGrad()                              # one d(inputs) buffer written by all frames' LN nodes
         for t in range(T):
-            # LayerNorm + k/v projections of frame t (per frame instead of whole-video: same values, and the
-            # per-frame gradients need no zero-padded whole-video buffers)
-            x_t = ops.layer_norm(frames[t], ni.weight, ni.bias, ni.eps)
+            # LayerNorm + k/v projections of frame t (per frame instead of whole-video: same values; the frame is read
+            # in place and its gradient rows are written in place: ops.layer_norm_frame)
+            x_t = ops.layer_norm_frame(inputs, t, ni.weight, ni.bias, ni.eps, video_grad)
             k_t = ops.linear(x_t, self.project_k.weight, alpha=k_scale)      # k * Ds^-0.5 in the GEMM epilogue
             v_t = ops.linear(x_t, self.project_v.weight)
             kv_grad = ops.SlotKVGrad()                            # d(k_t), d(v_t) of the iterations summed in-kernel

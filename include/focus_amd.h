@@ -132,6 +132,16 @@ int focus_layernorm_bwd_blocks(int rows);
 int focus_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean,
                         const float* rstd, const void* dres, void* dx, float* dgamma, float* dbeta, float* partial,
                         int rows, int D, int dtype, void* stream);
+/* The same two kernels over ROW BLOCKS: x (and, backward, dx) is a set of blocks of rows_per_block dense rows whose
+ * starts are block_stride elements apart -- frame t of a [B,T,N,D] video tensor read and differentiated in place (pointer
+ * to frame t, rows_per_block = N, block_stride = T*N*D, rows = B*N): no per-frame copies either way (steve.py:60, :68).
+ * y, dy, mean, rstd are dense [rows, D]. */
+int focus_layernorm_fwd_blocks(const void* x, int rows_per_block, int64_t block_stride, const float* gamma,
+                               const float* beta, void* y, float* mean, float* rstd, int rows, int D, float eps, int dtype,
+                               void* stream);
+int focus_layernorm_bwd_blocks_strided(const void* dy, const void* x, int rows_per_block, int64_t block_stride,
+                                       const float* gamma, const float* mean, const float* rstd, void* dx, float* dgamma,
+                                       float* dbeta, float* partial, int rows, int D, int dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Row softmax over segments:  x viewed as [rows, L] with row stride `stride`; in place allowed.
