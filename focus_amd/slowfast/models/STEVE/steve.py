@@ -69,15 +69,17 @@ class SlotAttentionVideo(nn.Module):
             v_t = ops.linear(x_t, self.project_v.weight)
             kv_grad = ops.SlotKVGrad()                            # d(k_t), d(v_t) of the iterations summed in-kernel
             for i in range(self.num_iterations):
-                slots_prev = slots
-                q = ops.linear(ops.layer_norm(slots, ns.weight, ns.bias, ns.eps), self.project_q.weight)
+                # layer_norm_fork: the tensor is used twice (normalised, and as GRU state / residual); the gradient of the
+                # second use is added inside the LayerNorm backward kernel instead of by an autograd accumulation add
+                slots_prev, sn = ops.layer_norm_fork(slots, ns.weight, ns.bias, ns.eps)
+                q = ops.linear(sn, self.project_q.weight)
                 updates, attn_vis = ops.slot_attn_step(k_t, v_t, q, self.epsilon, kv_grad)  # :76-83
                 slots = ops.gru_cell(updates.view(-1, Ds), slots_prev.reshape(-1, Ds), self.gru.weight_ih,
                                      self.gru.weight_hh, self.gru.bias_ih, self.gru.bias_hh).view(B, K, Ds)
                 if i < self.num_iterations - 1:
-                    y = ops.layer_norm(slots, nm.weight, nm.bias, nm.eps)
+                    sr, y = ops.layer_norm_fork(slots, nm.weight, nm.bias, nm.eps)
                     slots = ops.mlp(y, self.mlp[0].weight, self.mlp[0].bias, self.mlp[2].weight, self.mlp[2].bias,
-                                    residual=slots, act=ops.EPI_RELU)
+                                    residual=sr, act=ops.EPI_RELU)
             attns_collect.append(attn_vis)
             slots_collect.append(slots)
             slots = self.predictor(slots)

@@ -72,10 +72,10 @@ class TransformerEncoderBlock(nn.Module):
             input = ops.layer_norm(input, ln.weight, ln.bias, ln.eps)
             input = self.attn(input, input, input, residual=input)
         else:
-            x = ops.layer_norm(input, ln.weight, ln.bias, ln.eps)
+            input, x = ops.layer_norm_fork(input, ln.weight, ln.bias, ln.eps)
             input = self.attn(x, x, x, residual=input)
         fl = self.ffn_layer_norm
-        x = ops.layer_norm(input, fl.weight, fl.bias, fl.eps)
+        input, x = ops.layer_norm_fork(input, fl.weight, fl.bias, fl.eps)   # (residual-path gradient added in the LN backward)
         return _ffn(self.ffn, x, input, self.training)
 
 
