@@ -280,8 +280,9 @@ def bench_job(cfg):
                                "launches_per_step": len(recs) // max(a.steps, 1),
                                "avg_launch_us": round(1e3 * ms / max(len(recs), 1), 2),
                                "kernel_ms_per_step": round(ms / max(a.steps, 1), 3),
-                               "uniform_nt_kernel": {"kernel": "gemm_nt_kernel 128x128 (gemm_mfma.hip): M = 256 motion-stream "
-                                                               "products and other small shapes",
+                               "uniform_nt_kernel": {"kernel": "gemm_nt_kernel 128x128 (gemm_mfma.hip) and gemm_nt_small_kernel "
+                                                               "(gemm_mfma_small.hip): M = 256 motion-stream products and "
+                                                               "other small shapes",
                                                      "launches_per_step": len(other) // max(a.steps, 1),
                                                      "ms_per_step": round(other_ms / max(a.steps, 1), 3)},
                                "weight_grad_kernel": {"kernel": "bf16 TN GEMM (gemm_mfma_tn_ws.hip, gemm_mfma_tn.hip)",

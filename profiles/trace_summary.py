@@ -1,5 +1,5 @@
 """Per-kernel time per step from a rocprofv3 --kernel-trace CSV (the --stats CSV of ROCm 7.2 mis-attributes names).
-usage: python tools/trace_summary.py <dir or *_kernel_trace.csv> <steps incl. warmup> [top]"""
+usage: python profiles/trace_summary.py <dir or *_kernel_trace.csv> <steps incl. warmup> [top]"""
 import collections, csv, glob, os, re, sys
 
 
