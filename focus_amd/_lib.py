@@ -6,6 +6,7 @@ import re
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 HEADER = os.path.join(_HERE, "..", "include", "focus_amd.h")
+DEBUG_HEADER = os.path.join(_HERE, "csrc", "focus_debug.h")     # test-suite probes, not part of the operator ABI
 LIB_PATH = os.path.join(_HERE, "lib", "libfocus_amd.so")
 
 F32, BF16 = 0, 1
@@ -76,7 +77,9 @@ def lib():
         # register with /opt/rocm's runtime while the streams come from torch's: every launch then fails.
         import torch  # noqa: F401
         L = ctypes.CDLL(LIB_PATH)
-        for name, (restype, argtypes) in parse_header().items():
+        decls = dict(parse_header())
+        decls.update(parse_header(DEBUG_HEADER))
+        for name, (restype, argtypes) in decls.items():
             fn = getattr(L, name)          # AttributeError here = header/library mismatch
             fn.restype = restype
             fn.argtypes = argtypes

@@ -2,6 +2,7 @@
 // transposed (zero-padded) operand copies, diagonal gather/scatter, patch im2col, token assembly,
 // label-smoothing cross-entropy, GRU gate math, per-RoI cell max.
 #include "focus_common.h"
+#include "focus_debug.h"
 
 namespace {
 

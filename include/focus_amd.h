@@ -342,11 +342,6 @@ int focus_shadow_refresh(const focus_shadow_item* items, int n_items, int max_ro
 int focus_diag_gather(const void* xt, void* xdiag, int B, int S, int F, int C, int dtype, void* stream);
 int focus_diag_scatter_add(const void* dxdiag, void* dxt, int B, int S, int F, int C, int dtype, void* stream);
 
-/* Hardware probe (bring-up aid, used by tests only): fills an LDS image img[r][c] = 100*r + c (16 rows x 64
- * columns of int16, 128-B rows), issues ONE ds_read_b64_tr_b16 per lane with lane l of each 16-lane group g
- * addressing row 4*g + (l%16)/4, column 4*(l%4), and returns the 4 int16 each lane received: out [64][4]. */
-int focus_debug_tr16_probe(int16_t* out, void* stream);
-
 /* out[b, i] = (x ? x[b, i] : 0) + s[b] * y[b, i]   for b < B, i < per  (per % 8 == 0).
  * Stochastic depth on a residual branch in one pass (common.py:46-60: x + drop_path(y)) and its adjoint (dy = s * dout
  * with x == NULL).  keep == 0: s = scale.  keep > 0: scale holds the U[0,1) draws and s[b] = floor(keep + scale[b]) / keep
