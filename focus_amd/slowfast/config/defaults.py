@@ -144,6 +144,7 @@ def _defaults():
     C.TENSORBOARD = CfgNode(dict(ENABLE=True))
     C.NUM_GPUS = 1
     C.NUM_SHARDS = 1
+    C.SPLIT_QKV_CHECKPOINT = False          # defaults.py:824
     C.SHARD_ID = 0
     C.OUTPUT_DIR = "./tmp"
     C.RNG_SEED = 1
