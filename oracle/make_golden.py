@@ -334,6 +334,54 @@ def main_steve():
     print("wrote steve_forward_small.npz")
 
 
+
+def main_data():
+    """12. Data-side contract: the reference's own datasets/utils.spatial_sampling (train branch and
+    the three test views, with boxes), pack_pathway_output and the ssv2.py:337-346 box hand-off (box_ops), executed from
+    the reference files with numpy's global RNG seeded; frames 5x3x40x56 float32, boxes [5,3,4] xyxy pixels."""
+    from oracle._ref_loader import _load, _ns
+    mods = load_reference(_roi_align_tv)
+    for n in ("slowfast.datasets", "torchvision.transforms", "torchvision.transforms.functional", "cv2", "slowfast.utils.env"):
+        _ns(n)
+    sys.modules["torchvision"].transforms = sys.modules["torchvision.transforms"]
+    sys.modules["slowfast.utils.env"].pathmgr = None
+    for stub in ("rand_augment", "boxes_autoaugment", "random_erasing"):
+        m = _ns("slowfast.datasets." + stub)
+        m.rand_augment_transform = lambda *a, **k: None
+        m.RandomErasing = object
+    _load("slowfast.datasets.transform", "slowfast/datasets/transform.py")
+    du = _load("slowfast.datasets.utils", "slowfast/datasets/utils.py")
+    bo = mods["box_ops"]
+    g = torch.Generator().manual_seed(20264)
+    T, O, H, W = 5, 3, 40, 56
+    frames = torch.rand(T, 3, H, W, generator=g)
+    x0 = torch.rand(T, O, 1, generator=g) * 30
+    y0 = torch.rand(T, O, 1, generator=g) * 20
+    wh = torch.rand(T, O, 2, generator=g) * 24 + 0.5
+    boxes = torch.cat([x0, y0, x0 + wh[..., :1], y0 + wh[..., 1:]], -1).numpy().astype(np.float32)
+    boxes[1, 2] = 0                                                     # an absent object
+    boxes[3, 0] = [10.0, 5.0, 10.8, 30.0]                               # thinner than eps after normalisation
+    out = {"frames": frames.numpy(), "boxes": boxes}
+    cfg = ns(DATA=ns(REVERSE_INPUT_CHANNEL=True), MODEL=ns(ARCH="mformer", SINGLE_PATHWAY_ARCH=["mformer"], MULTI_PATHWAY_ARCH=["slowfast"]))
+    for tag, seed, kw in (("train", 7, dict(spatial_idx=-1, min_scale=36, max_scale=48, crop_size=32)),
+                          ("train_inv", 8, dict(spatial_idx=-1, min_scale=36, max_scale=48, crop_size=32, inverse_uniform_sampling=True)),
+                          ("test0", 9, dict(spatial_idx=0, min_scale=36, max_scale=36, crop_size=32)),
+                          ("test1", 9, dict(spatial_idx=1, min_scale=36, max_scale=36, crop_size=32)),
+                          ("test2", 9, dict(spatial_idx=2, min_scale=36, max_scale=36, crop_size=32))):
+        np.random.seed(seed)
+        f, b = du.spatial_sampling(frames.clone(), boxes=boxes.copy(), random_horizontal_flip=True, **kw)
+        packed = du.pack_pathway_output(cfg, f.permute(1, 0, 2, 3))[0]   # C T H W as the datasets hand it over
+        h, w = packed.shape[-2:]
+        bb = b.copy()
+        bb[..., [0, 2]] = bb[..., [0, 2]] / w                            # ssv2.py:337-346
+        bb[..., [1, 3]] = bb[..., [1, 3]] / h
+        bb = np.clip(bb, 0, 1)
+        ob = bo.zero_empty_boxes(bo.box_xyxy_to_cxcywh(torch.from_numpy(bb)), mode="cxcywh")
+        out.update({tag + ".frames": packed.numpy(), tag + ".boxes_px": b, tag + ".orvit_bboxes": ob.numpy(), tag + ".seed": seed})
+    out["norm"] = du.tensor_normalize((frames * 255).to(torch.uint8).permute(0, 2, 3, 1), [0.45, 0.45, 0.45], [0.225, 0.225, 0.225]).numpy()
+    np.savez(os.path.join(OUT, "data_contract.npz"), **out)
+    print("wrote data_contract.npz")
+
 def _load_losses():
     """The reference's own slowfast/models/losses.py (plain torch + the stubbed logger)."""
     from oracle._ref_loader import _load
@@ -349,10 +397,13 @@ def mods_loss(logits, labels):
 
 
 if __name__ == "__main__":
-    if "--steve-only" in sys.argv:
+    if "--data-only" in sys.argv:
+        main_data()
+    elif "--steve-only" in sys.argv:
         main_steve()
     else:
         if "--r2-only" not in sys.argv:
             main()
         main_r2()
         main_steve()
+        main_data()
