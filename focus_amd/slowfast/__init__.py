@@ -16,6 +16,6 @@ def install_as_slowfast():
                 "models.stem_helper", "models.video_model_builder", "models.losses", "models.optimizer",
                 "models.ORViT", "models.ORViT.orvit", "models.ORViT.utils", "models.ORViT.layout",
                 "models.STEVE", "models.STEVE.steve", "models.STEVE.utils", "models.STEVE.transformer", "models.STEVE.dvae",
-                "datasets", "datasets.utils", "datasets.transform", "utils", "utils.box_ops", "utils.distributed", "utils.misc", "utils.lr_policy", "utils.checkpoint"):
+                "datasets", "datasets.utils", "datasets.transform", "utils", "utils.box_ops", "utils.distributed", "utils.misc", "utils.lr_policy", "utils.checkpoint", "utils.metrics", "utils.meters"):
         sys.modules.setdefault("slowfast." + sub, importlib.import_module(__name__ + "." + sub))
     return pkg

@@ -86,6 +86,45 @@ def slot_train_epoch(train_loader, model, optimizer, scaler, train_meter, cur_ep
     return {"tau": tau, "global_step": global_step}
 
 
+@torch.no_grad()
+def slot_eval_epoch(eval_loader, model, cfg=None):
+    """FG-ARI evaluation of STEVE (tools/steve_eval_net.py:75-132): `eval_loader` yields (video [B,T,C,H,W], true_masks
+    [B,T,S,1,H,W] with segment 0 = background); the slots' attention masks of `model.encode` are scored against the
+    foreground segments over the whole clip (pixels of all frames flattened together).  Returns (mean, std over batches)
+    of 100 x ARI; the ARI itself is computed on the device (utils/metrics.evaluate_ari)."""
+    from .slowfast.utils import metrics
+    model.eval()
+    dev = next(model.parameters()).device
+    scores = []
+    for video, true_masks in eval_loader:
+        video = video.to(dev)
+        _, _, pred_masks = model.encode(video)                                            # [B,T,K,1,H,W]
+        scores.append(100 * metrics.evaluate_ari(true_masks.to(dev).permute(0, 2, 1, 3, 4, 5)[:, 1:].flatten(start_dim=2),
+                                                 pred_masks.permute(0, 2, 1, 3, 4, 5).flatten(start_dim=2)))
+    t = torch.tensor(scores, dtype=torch.float64)
+    return float(t.mean()), float(t.std(unbiased=False)) if len(scores) > 1 else 0.0
+
+
+@torch.no_grad()
+def perform_test(test_loader, model, test_meter, cfg):
+    """Multi-view testing (tools/test_net.py:24-157, single-label branch): every clip of every video goes through the
+    model in eval mode (softmax scores), the meter sums the views per video.  `test_loader` yields
+    (inputs, labels, video_idx, meta) like the reference's loaders."""
+    model.eval()
+    dev = next(model.parameters()).device
+    for inputs, labels, video_idx, meta in test_loader:
+        inputs = [x.to(dev) for x in inputs] if isinstance(inputs, (list, tuple)) else inputs.to(dev)
+        meta = {k: (v.to(dev) if isinstance(v, torch.Tensor) else v) for k, v in meta.items()}
+        preds = model(inputs, meta)
+        if isinstance(preds, tuple):
+            preds = preds[0]
+        if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
+            from .slowfast.utils import distributed as du
+            preds, labels, video_idx = du.all_gather([preds, labels.to(dev), video_idx.to(dev)])
+        test_meter.update_stats(preds, labels, video_idx)
+    return test_meter.finalize_metrics()
+
+
 class GraphedStep:
     """One HIP graph for a launch-bound step (the STEVE slot update issues ~2900 kernels of 3-30 us per step: the host,
     not the GPU, sets its eager time).  `fn` takes no arguments, reads its inputs from tensors that stay in place, and

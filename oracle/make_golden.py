@@ -382,6 +382,36 @@ def main_data():
     np.savez(os.path.join(OUT, "data_contract.npz"), **out)
     print("wrote data_contract.npz")
 
+
+def main_metrics():
+    """13. Evaluation metrics: the reference's own slowfast/utils/metrics.py (scipy comb, per-clip numpy
+    tables) on seeded masks and scores -- FG-ARI incl. a perfect and a single-cluster case, top-k / multitask top-k counts."""
+    from oracle._ref_loader import _load
+    load_reference(_roi_align_tv)
+    mt = _load("slowfast.utils.metrics", "slowfast/utils/metrics.py")
+    g = torch.Generator().manual_seed(20265)
+    B, N0, N1, D = 5, 6, 7, 4 * 16 * 16
+    seg = torch.randint(0, N0, (B, D), generator=g)
+    true = torch.nn.functional.one_hot(seg, N0).permute(0, 2, 1).float()            # [B,N0,D]
+    pred = torch.rand(B, N1, D, generator=g)
+    pred[0] = 0.0
+    pred[0, :N0] = true[0] * 5.0                                                      # clip 0: perfect prediction
+    pred[1] = 0.0
+    pred[1, 3] = 1.0                                                                  # clip 1: everything in one slot
+    pred[2, :N0] += true[2] * 0.6                                                     # clip 2: partially right
+    aris = [mt.evaluate_ari(true[b:b + 1, 1:], pred[b:b + 1]) for b in range(B)]      # foreground segments only
+    scores = torch.randn(64, 23, generator=g)
+    labels = torch.randint(0, 23, (64,), generator=g)
+    s2 = torch.randn(64, 11, generator=g)
+    l2 = torch.randint(0, 11, (64,), generator=g)
+    np.savez(os.path.join(OUT, "metrics.npz"), true=true.numpy().astype(np.uint8), pred=pred.numpy(),
+             ari_each=np.array(aris), ari_fg=mt.evaluate_ari(true[:, 1:], pred), ari_all=mt.evaluate_ari(true, pred),
+             scores=scores.numpy(), labels=labels.numpy(), scores2=s2.numpy(), labels2=l2.numpy(),
+             topk=np.array([float(x) for x in mt.topks_correct(scores, labels, (1, 5))]),
+             topk_acc=np.array([float(x) for x in mt.topk_accuracies(scores, labels, (1, 5))]),
+             multitask=np.array([float(x) for x in mt.multitask_topks_correct((scores, s2), (labels, l2), (1, 5))]))
+    print("wrote metrics.npz")
+
 def _load_losses():
     """The reference's own slowfast/models/losses.py (plain torch + the stubbed logger)."""
     from oracle._ref_loader import _load
@@ -397,7 +427,9 @@ def mods_loss(logits, labels):
 
 
 if __name__ == "__main__":
-    if "--data-only" in sys.argv:
+    if "--metrics-only" in sys.argv:
+        main_metrics()
+    elif "--data-only" in sys.argv:
         main_data()
     elif "--steve-only" in sys.argv:
         main_steve()
@@ -407,3 +439,4 @@ if __name__ == "__main__":
         main_r2()
         main_steve()
         main_data()
+        main_metrics()
