@@ -5,7 +5,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from focus_amd import ops
 
-B, S, F_, heads = 8, 1568, 8, 12
+B, S, F_, heads = int(os.environ.get("B", 8)), 1568, 8, 12
 C = heads * 64
 dev = torch.device("cuda:0")
 g = torch.Generator(device=dev).manual_seed(0)
