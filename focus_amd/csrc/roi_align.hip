@@ -58,7 +58,8 @@ template <typename T>
 __global__ __launch_bounds__(256) void roi_fwd_kernel(const T* __restrict__ feat, int64_t img_stride, int ipb,
                                                       int64_t batch_stride, const float* __restrict__ rois,
                                                       const int32_t* __restrict__ roi_img, T* __restrict__ out, int C,
-                                                      int H, int W, int PH, int PW, float scale, int sr, int aligned) {
+                                                      int H, int W, int PH, int PW, float scale, int sr, int aligned,
+                                                      int relu) {
     const int k = blockIdx.y, ph = blockIdx.x;
     const Geom g = roi_geometry(rois + 4 * k, scale, PH, PW, sr, aligned);
     const int ri = roi_img[k];
@@ -86,6 +87,7 @@ __global__ __launch_bounds__(256) void roi_fwd_kernel(const T* __restrict__ feat
         }
         acc.x = __fdiv_rn(acc.x, g.count); acc.y = __fdiv_rn(acc.y, g.count);
         acc.z = __fdiv_rn(acc.z, g.count); acc.w = __fdiv_rn(acc.w, g.count);
+        if (relu) { acc.x = fmaxf(acc.x, 0.f); acc.y = fmaxf(acc.y, 0.f); acc.z = fmaxf(acc.z, 0.f); acc.w = fmaxf(acc.w, 0.f); }
         st4<T>(out + ((int64_t)k * PH * PW + ph * PW + pw) * C + c, acc);
     }
 }
@@ -146,7 +148,8 @@ __device__ __forceinline__ void locate1(float v, int L, int* low, int* high, flo
 }
 
 template <typename T>
-__global__ __launch_bounds__(1024) void roi_bwd_sep_kernel(const T* __restrict__ dout, const float* __restrict__ rois,
+__global__ __launch_bounds__(1024) void roi_bwd_sep_kernel(const T* __restrict__ dout, const T* __restrict__ relu_out,
+                                                           const float* __restrict__ rois,
                                                            const int32_t* __restrict__ roi_img, T* __restrict__ dfeat,
                                                            int64_t img_stride, int ipb, int64_t batch_stride,
                                                            int C, int H, int W, int K, int PH, int PW, float scale,
@@ -179,8 +182,12 @@ __global__ __launch_bounds__(1024) void roi_bwd_sep_kernel(const T* __restrict__
             const Geom g = roi_geometry(rois + 4 * k, scale, PH, PW, sr, aligned);
             if (g.grid_h <= 0 || g.grid_w <= 0) continue;                  // block-uniform
             __syncthreads();                                               // previous RoI's gst / Ay / Ax are free
-            for (int bin = x; bin < bins; bin += nw)
-                gst[bin * RB_CS + ch] = ld<T>(dout + ((int64_t)k * bins + bin) * C + c0 + ch) / g.count;
+            for (int bin = x; bin < bins; bin += nw) {
+                const int64_t o = ((int64_t)k * bins + bin) * C + c0 + ch;
+                float gv = ld<T>(dout + o) / g.count;
+                if (relu_out && !(ld<T>(relu_out + o) > 0.f)) gv = 0.f;     // fused ReLU: the saved output is the mask
+                gst[bin * RB_CS + ch] = gv;
+            }
             if (threadIdx.x < RB_HMAX * RB_PMAX) { (&Ay[0][0])[threadIdx.x] = 0.f; (&Ax[0][0])[threadIdx.x] = 0.f; }
             __syncthreads();
             // one thread per bin row / bin column: no two threads write the same Ay / Ax entry
@@ -265,7 +272,8 @@ __global__ void roi_indices_kernel(const float* __restrict__ rois, int32_t* __re
 
 extern "C" int focus_roi_align_fwd(const void* feat, int64_t img_stride, int imgs_per_batch, int64_t batch_stride,
                                    const float* rois, const int32_t* roi_img, void* out, int NI, int C, int H, int W,
-                                   int K, int PH, int PW, float scale, int sr, int aligned, int dtype, void* stream) {
+                                   int K, int PH, int PW, float scale, int sr, int aligned, int relu, int dtype,
+                                   void* stream) {
     (void)NI;
     if (!feat || !rois || !roi_img || !out) return FOCUS_ERR_NULL;
     if (K <= 0) return FOCUS_OK;
@@ -275,10 +283,10 @@ extern "C" int focus_roi_align_fwd(const void* feat, int64_t img_stride, int img
     dim3 grid(PH, K);
     if (dtype == FOCUS_BF16)
         hipLaunchKernelGGL((roi_fwd_kernel<bf16_t>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)feat,
-                           img_stride, imgs_per_batch, batch_stride, rois, roi_img, (bf16_t*)out, C, H, W, PH, PW, scale, sr, aligned);
+                           img_stride, imgs_per_batch, batch_stride, rois, roi_img, (bf16_t*)out, C, H, W, PH, PW, scale, sr, aligned, relu);
     else
         hipLaunchKernelGGL((roi_fwd_kernel<float>), grid, dim3(256), 0, (hipStream_t)stream, (const float*)feat,
-                           img_stride, imgs_per_batch, batch_stride, rois, roi_img, (float*)out, C, H, W, PH, PW, scale, sr, aligned);
+                           img_stride, imgs_per_batch, batch_stride, rois, roi_img, (float*)out, C, H, W, PH, PW, scale, sr, aligned, relu);
     FOCUS_CHECK_LAUNCH();
     return FOCUS_OK;
 }
@@ -288,7 +296,7 @@ extern "C" size_t focus_roi_align_bwd_workspace_bytes(int NI, int C, int H, int 
     return (size_t)NI * H * W * C * sizeof(float);
 }
 
-extern "C" int focus_roi_align_bwd(const void* dout, const float* rois, const int32_t* roi_img, void* dfeat,
+extern "C" int focus_roi_align_bwd(const void* dout, const void* relu_out, const float* rois, const int32_t* roi_img, void* dfeat,
                                    int64_t img_stride, int imgs_per_batch, int64_t batch_stride, void* ws,
                                    size_t ws_bytes, int NI, int C, int H, int W, int K, int PH, int PW, float scale,
                                    int sr, int aligned, int dtype, void* stream) {
@@ -296,15 +304,16 @@ extern "C" int focus_roi_align_bwd(const void* dout, const float* rois, const in
     if ((C & 3) || PH <= 0 || PW <= 0 || K > 65535 || NI <= 0 || NI > 65535 || imgs_per_batch <= 0) return FOCUS_ERR_SHAPE;
     const bool dense = img_stride == (int64_t)H * W * C && batch_stride == img_stride * imgs_per_batch;
     if (!dense && !roi_sep_ok(C, H, W, PH, PW)) return FOCUS_ERR_SHAPE;   // the atomic path accumulates into a dense map
+    if (relu_out && !roi_sep_ok(C, H, W, PH, PW)) return FOCUS_ERR_SHAPE; // the fused-ReLU mask is a separable-path feature
     hipStream_t s = (hipStream_t)stream;
     if (roi_sep_ok(C, H, W, PH, PW)) {
         dim3 grid(C / RB_CS, NI), blk(64 * W);
         const size_t lds = (size_t)PH * PW * RB_CS * sizeof(float);
         if (dtype == FOCUS_BF16)
-            hipLaunchKernelGGL((roi_bwd_sep_kernel<bf16_t>), grid, blk, lds, s, (const bf16_t*)dout, rois, roi_img,
+            hipLaunchKernelGGL((roi_bwd_sep_kernel<bf16_t>), grid, blk, lds, s, (const bf16_t*)dout, (const bf16_t*)relu_out, rois, roi_img,
                                (bf16_t*)dfeat, img_stride, imgs_per_batch, batch_stride, C, H, W, K, PH, PW, scale, sr, aligned);
         else
-            hipLaunchKernelGGL((roi_bwd_sep_kernel<float>), grid, blk, lds, s, (const float*)dout, rois, roi_img,
+            hipLaunchKernelGGL((roi_bwd_sep_kernel<float>), grid, blk, lds, s, (const float*)dout, (const float*)relu_out, rois, roi_img,
                                (float*)dfeat, img_stride, imgs_per_batch, batch_stride, C, H, W, K, PH, PW, scale, sr, aligned);
         FOCUS_CHECK_LAUNCH();
         return FOCUS_OK;

@@ -994,7 +994,7 @@ class _RoiAlignFn(torch.autograd.Function):
     + zero-fill out.  rois [K,4] fp32 xyxy pixels."""
 
     @staticmethod
-    def forward(ctx, feat, rois, roi_img, tok_T, H, W, PH, PW, scale, sampling_ratio, aligned):
+    def forward(ctx, feat, rois, roi_img, tok_T, H, W, PH, PW, scale, sampling_ratio, aligned, relu):
         _need_gpu(feat, rois, roi_img)
         feat = feat.contiguous()
         C = feat.shape[-1]
@@ -1009,15 +1009,16 @@ class _RoiAlignFn(torch.autograd.Function):
         K = rois.shape[0]
         out = torch.empty(K, PH * PW, C, device=feat.device, dtype=feat.dtype)
         _lib.check(_lib.lib().focus_roi_align_fwd(_p(feat, off), H * W * C, ipb, bstride, _p(rois), _p(roi_img), _p(out), NI,
-                                                  C, H, W, K, PH, PW, scale, sampling_ratio, int(aligned), _dt(feat),
-                                                  _stream()), "roi_align_fwd")
-        ctx.save_for_backward(rois, roi_img)
+                                                  C, H, W, K, PH, PW, scale, sampling_ratio, int(aligned), int(relu),
+                                                  _dt(feat), _stream()), "roi_align_fwd")
+        ctx.relu = bool(relu)
+        ctx.save_for_backward(rois, roi_img, out if relu else None)
         ctx.args = (NI, C, H, W, K, PH, PW, scale, sampling_ratio, int(aligned), feat.dtype, ipb, bstride, off, feat.shape)
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        rois, roi_img = ctx.saved_tensors
+        rois, roi_img, relu_out = ctx.saved_tensors
         NI, C, H, W, K, PH, PW, scale, sr, al, dt, ipb, bstride, off, shp = ctx.args
         dout = dout.contiguous()
         L = _lib.lib()
@@ -1026,23 +1027,32 @@ class _RoiAlignFn(torch.autograd.Function):
             dfeat[:, 0].zero_()                                   # cls rows: no RoI reads them
         nb = L.focus_roi_align_bwd_workspace_bytes(NI, C, H, W, PH, PW)
         ws = torch.empty(nb // 4, device=dout.device, dtype=torch.float32) if nb else None
-        _lib.check(L.focus_roi_align_bwd(_p(dout), _p(rois), _p(roi_img), _p(dfeat, off), H * W * C, ipb, bstride, _p(ws), nb,
-                                         NI, C, H, W, K, PH, PW, scale, sr, al, _dt(dout), _stream()), "roi_align_bwd")
-        return dfeat, None, None, None, None, None, None, None, None, None, None
+        _lib.check(L.focus_roi_align_bwd(_p(dout), _p(relu_out), _p(rois), _p(roi_img), _p(dfeat, off), H * W * C, ipb, bstride,
+                                         _p(ws), nb, NI, C, H, W, K, PH, PW, scale, sr, al, _dt(dout), _stream()),
+                   "roi_align_bwd")
+        return dfeat, None, None, None, None, None, None, None, None, None, None, None
 
 
 def roi_align_tokens(feat, rois, roi_img, H, W, PH, PW, spatial_scale, sampling_ratio=-1, aligned=True):
-    return _RoiAlignFn.apply(feat, rois, roi_img, 0, H, W, PH, PW, float(spatial_scale), sampling_ratio, aligned)
+    return _RoiAlignFn.apply(feat, rois, roi_img, 0, H, W, PH, PW, float(spatial_scale), sampling_ratio, aligned, False)
 
 
-def roi_align_stream(x, rois, roi_img, T, H, W, PH, PW, spatial_scale, sampling_ratio=-1, aligned=True):
+def roi_align_stream(x, rois, roi_img, T, H, W, PH, PW, spatial_scale, sampling_ratio=-1, aligned=True, relu=False):
     """RoIAlign of the patch tokens of the residual stream x [B, 1+T*H*W, C], read in place (image index = b*T + t).
-    Shapes whose backward needs the dense atomic path (focus_roi_align_bwd_workspace_bytes > 0) take a dense copy."""
+    Shapes whose backward needs the dense atomic path (focus_roi_align_bwd_workspace_bytes > 0) take a dense copy.
+    relu: max(., 0) fused into the forward store and (as a mask from the saved output) into the backward."""
     B, _, C = x.shape
     if _lib.lib().focus_roi_align_bwd_workspace_bytes(B * T, C, H, W, PH, PW):
-        return roi_align_tokens(x[:, 1:].reshape(B * T, H * W, C), rois, roi_img, H, W, PH, PW, spatial_scale,
-                                sampling_ratio, aligned)
-    return _RoiAlignFn.apply(x, rois, roi_img, T, H, W, PH, PW, float(spatial_scale), sampling_ratio, aligned)
+        out = roi_align_tokens(x[:, 1:].reshape(B * T, H * W, C), rois, roi_img, H, W, PH, PW, spatial_scale,
+                               sampling_ratio, aligned)
+        return torch.relu(out) if relu else out
+    return _RoiAlignFn.apply(x, rois, roi_img, T, H, W, PH, PW, float(spatial_scale), sampling_ratio, aligned, relu)
+
+
+def roi_stream_supports_fused(x, T, H, W, PH, PW):
+    """True when roi_align_stream takes the in-place separable path for this shape (then its ReLU is fused too)."""
+    B, _, C = x.shape
+    return _lib.lib().focus_roi_align_bwd_workspace_bytes(B * T, C, H, W, PH, PW) == 0
 
 
 class _OrvitAssembleFn(torch.autograd.Function):

@@ -19,6 +19,7 @@ import os
 # the stream of the LAST gradient hook only, which does not cover gradients produced on another stream.
 _SIDE_STREAMS = {}
 _USE_SIDE_STREAM = os.environ.get("FOCUS_MOTION_SIDE_STREAM", "1") != "0"
+_COMMUTE_PATCH_TO_D = os.environ.get("FOCUS_ORVIT_COMMUTE", "1") != "0"      # patch_to_d[0] before RoIAlign (see forward)
 
 
 def _side_stream(device):
@@ -108,10 +109,19 @@ class ORViT(nn.Module):
             else:
                 motion_emb = self.motion_stream(box_tensors, H, W, dtype=x.dtype)
 
-        # object tokens: RoIAlign (patch tokens read in place from x) -> patch_to_d -> max over the RoI cells (:135-139)
-        crops = self.crop_layer.crop_stream(x, box_tensors, T, H, W)                        # [BS*T*O, HW, d]
+        # object tokens: RoIAlign -> patch_to_d -> max over the RoI cells (:135-139).  patch_to_d's first Linear has no bias,
+        # so it commutes with the bilinear sampling: it is applied ONCE to the T*HW patch tokens of the stream
+        # (O = 4 times fewer rows than the RoI cells), the crops are sampled in dim/2 channels (half the gather bytes, half
+        # the crop tensor, half the RoIAlign backward) with the ReLU fused into the sampling kernels; only the second
+        # Linear runs on the RoI cells.  Same values up to rounding order.
         p2d = self.patch_to_d
-        pre = ops.mlp(crops, p2d[0].weight, None, p2d[2].weight, None, act=ops.EPI_RELU)  # last ReLU commutes with max
+        if _COMMUTE_PATCH_TO_D:
+            z = ops.linear(x, p2d[0].weight)                                                 # [BS, 1+T*HW, d/2]
+            crops = self.crop_layer.crop_stream(z, box_tensors, T, H, W, relu=True)         # [BS*T*O, HW, d/2]
+            pre = ops.linear(crops, p2d[2].weight)                                           # last ReLU commutes with max
+        else:                                                                                # the reference's order (:135-137)
+            crops = self.crop_layer.crop_stream(x, box_tensors, T, H, W)                    # [BS*T*O, HW, d]
+            pre = ops.mlp(crops, p2d[0].weight, None, p2d[2].weight, None, act=ops.EPI_RELU)
         obj = torch.relu(ops.cell_amax(pre)).view(BS, T, O, d)
         box_emb = _relu_pair(self.c_coord_to_feature, box_tensors, x.dtype)
         obj = obj + self.box_categories.to(x.dtype) + box_emb                               # :141-143

@@ -42,11 +42,12 @@ class ObjectsCrops(nn.Module):
         return ops.roi_align_tokens(patch_tokens.reshape(B * T, H * W, C), rois, img, H, W, H, W,
                                     H / self.video_hw[0], self.sampling_ratio, self.aligned)
 
-    def crop_stream(self, x, boxes, T, H, W):
+    def crop_stream(self, x, boxes, T, H, W, relu=False):
         """Same crops from the residual stream x [B, 1+T*H*W, C] itself: the patch tokens are read in place behind the
-        cls row (no slice copy), and the gradient comes back in the stream's shape."""
+        cls row (no slice copy), and the gradient comes back in the stream's shape.  relu: max(., 0) of the crops, fused."""
         rois, img = self.rois(boxes)
-        return ops.roi_align_stream(x, rois, img, T, H, W, H, W, H / self.video_hw[0], self.sampling_ratio, self.aligned)
+        return ops.roi_align_stream(x, rois, img, T, H, W, H, W, H / self.video_hw[0], self.sampling_ratio, self.aligned,
+                                    relu=relu)
 
     def forward(self, features, boxes):
         """Reference signature: features [B,d,T,H,W], boxes [B,T,O,4] -> [B,O,T,d,H,W]."""

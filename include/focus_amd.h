@@ -217,14 +217,18 @@ int focus_traj_time2_bwd(const void* q2, const void* xt, const void* wkT, int64_
  * ----------------------------------------------------------------------------------------------*/
 int focus_roi_align_fwd(const void* feat, int64_t img_stride, int imgs_per_batch, int64_t batch_stride,
                         const float* rois, const int32_t* roi_img, void* out, int NI, int C, int H, int W, int K,
-                        int PH, int PW, float spatial_scale, int sampling_ratio, int aligned, int dtype, void* stream);
+                        int PH, int PW, float spatial_scale, int sampling_ratio, int aligned, int relu, int dtype,
+                        void* stream);
 /* dfeat: image maps addressed like feat, `dtype`, every map fully written (no zero-initialisation needed; rows between
  * the maps -- the cls row of a token buffer -- are not touched).  Maps up to 16x16 with up to
  * 14x14 bins use the separable form dfeat = sum_rois Ay . dout . Ax^T (no atomics, accumulators in registers); other
  * shapes go through fp32 atomics into `ws` (focus_roi_align_bwd_workspace_bytes, 0 for the separable path) + a cast
- * and need the dense addressing (FOCUS_ERR_SHAPE otherwise). */
+ * and need the dense addressing (FOCUS_ERR_SHAPE otherwise).
+ * relu != 0 (forward): out = max(RoIAlign, 0) -- the ReLU that follows when patch_to_d's first Linear is applied BEFORE
+ * sampling (it has no bias, so it commutes with the bilinear sampling: SURVEY a10); relu_out (backward, may be NULL,
+ * separable path only): that saved output, used as the ReLU mask on dout. */
 size_t focus_roi_align_bwd_workspace_bytes(int NI, int C, int H, int W, int PH, int PW);
-int focus_roi_align_bwd(const void* dout, const float* rois, const int32_t* roi_img, void* dfeat, int64_t img_stride,
+int focus_roi_align_bwd(const void* dout, const void* relu_out, const float* rois, const int32_t* roi_img, void* dfeat, int64_t img_stride,
                         int imgs_per_batch, int64_t batch_stride, void* ws, size_t ws_bytes, int NI, int C, int H, int W, int K, int PH, int PW, float spatial_scale,
                         int sampling_ratio, int aligned, int dtype, void* stream);
 /* Debug/parity export of the integer side: grid [K,2], nbr [K,PH,PW,4] (int32). */
