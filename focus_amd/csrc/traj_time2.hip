@@ -72,17 +72,34 @@ __device__ __forceinline__ void lds_barrier() {
     asm volatile("" ::: "memory");
 }
 
-// Which (channel chunk, query range) a workgroup owns: 256 workgroups of 512 threads, one per CU; id -> (chunk id % nchunk,
-// range id / nchunk), 256 / nchunk ranges, the remainder of the ids idle.  (Placing the nchunk owners of a range on one
-// XCD so that they share its q2 / dl / dout reads in one L2 leaves 8 of an XCD's 32 CUs idle for 12 chunks: measured
-// 35.6 vs 35.2 ms per bench step, so the owners are spread.)
+// Which (channel chunk, query range) a workgroup owns: 256 workgroups of 512 threads, one per CU.  Every owner of a range
+// reads that range's q2 (and, backward, its attn2 / dl / dout), and an XCD's L2 only shares those reads among the owners
+// it hosts: spread over all 8 XCDs the logits kernel fetched 332 MB against 173 algorithmic, the dx kernel 237 against 46
+// (profiles/r02_pmc_hbm_traffic.txt).  The nchunk owners are therefore dealt out in groups of g (the largest divisor of
+// nchunk <= 8: 6 for 12 chunks) that sit on ONE XCD -- workgroup ids go to the XCDs round-robin (id % 8), so XCD x holds
+// ids x, x + 8, ...: its 32 slots = floor(32 / g) groups -- and the nchunk / g groups of a range land on neighbouring
+// XCDs: a range is fetched by 2 XCDs instead of 8.  (All 12 owners on one XCD would idle 8 of its 32 CUs: measured
+// slower.)  12 chunks: 40 groups = 20 ranges, 16 of the 256 workgroups idle.  FOCUS_T2_SPREAD=1: id -> (id % nchunk,
+// id / nchunk), the owners of a range on all XCDs (kept for A/B).
 struct Owner { int cc, range, nranges; };
-__device__ __forceinline__ Owner owner_of_block(int nchunk) {
-    const int id = blockIdx.x;
+__device__ __forceinline__ Owner owner_of_block(int nchunk, int spread) {
     Owner o;
-    o.nranges = gridDim.x / nchunk;
-    o.cc = id % nchunk;
-    o.range = id < o.nranges * nchunk ? id / nchunk : -1;
+    const int id = blockIdx.x;
+    if (spread) {
+        o.nranges = gridDim.x / nchunk;
+        o.cc = id % nchunk;
+        o.range = id < o.nranges * nchunk ? id / nchunk : -1;
+        return o;
+    }
+    int g = 1;
+    for (int d = 2; d <= 8; ++d)
+        if (nchunk % d == 0) g = d;
+    const int xcd = id & 7, j = id >> 3, per_xcd = gridDim.x >> 3;
+    const int gpx = per_xcd / g, parts = nchunk / g;
+    const int gi = xcd + 8 * (j / g);                              // group index; groups parts*r .. parts*r + parts-1 = range r
+    o.nranges = 8 * gpx / parts;
+    o.cc = (gi % parts) * g + j % g;
+    o.range = (j < gpx * g && gi < o.nranges * parts) ? gi / parts : -1;
     return o;
 }
 
@@ -186,12 +203,12 @@ __device__ __forceinline__ void compute_u_tile(const WFrag<UPW>& wf, const QFrag
 template <int FT, int UPW>
 __global__ __launch_bounds__(512) void time2_logits_kernel(const bf16_t* __restrict__ q2, const bf16_t* __restrict__ xt,
                                                            const bf16_t* __restrict__ wkT, int64_t ldw,
-                                                           float* __restrict__ slab, int rows, int heads, float scale) {
+                                                           float* __restrict__ slab, int rows, int heads, float scale, int spread) {
     constexpr int QPF = 16 / FT;           // queries per A fragment (rows = (query, frame))
     constexpr int NFR = FT > 8 ? FT / 8 : 1;   // fragments per wave: a tile has FT fragments (F = 4: waves 4..7 have none)
     constexpr int NHW = NHeads<UPW>::value;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const Owner own = owner_of_block(heads);
+    const Owner own = owner_of_block(heads, spread);
     if (own.range < 0) return;
     const int C = heads * CH, cc = own.cc;
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -314,6 +331,182 @@ __global__ __launch_bounds__(512) void time2_logits_kernel(const bf16_t* __restr
     // the ring loads of the tiles past the end are still in flight and hipcc does not know: drain them before anything
     // below may reuse their destination registers (an address register overwritten by a late load faults)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+// ------------------------------------------------------------------------------------------------
+// forward 1/3, LDS-staged operands.  The kernel above loads q2 / x~ straight into MFMA operand layout: a 16-byte-per-lane
+// load then touches 16 rows x 64 B, and the L1/TA serves that pattern at ~16 B/clk/CU from L2 against ~32 B/clk/CU for
+// row-contiguous loads (tools/probe/ta_pattern_probe.hip: 32 vs 64 GB/s per CU) -- with 48 KB per tile that rate, not HBM
+// and not the matrix pipe, set the tile time (1.6 us per tile whether or not any MFMA ran).  Here every thread loads
+// row-contiguous 16-byte pieces (q2: whole rows, each element ONCE instead of once per head group; x~: 128-byte chunk
+// rows), two tiles ahead in registers (inline-asm loads, counted waits), stores them to padded LDS images and the
+// fragments are read back with ds_read_b128 (pitches + 16 B: conflict-free for the 16-lane groups of both reads).
+// Per tile: A  fragments of x~(t), U(t), q2(t+1) -> registers | barrier | W  registers (tile t+2) -> the stage x~(t) left
+//           | C  issue loads of tile t+4 | B  U(t+1), contraction(t), store | barrier.
+// LDS: 2 U buffers + 2 stages of (q2 tile, x~ tile): 139 KB for 12 heads, F = 8; larger shapes take the direct kernel.
+// ------------------------------------------------------------------------------------------------
+constexpr int XP = CH * 2 + 16;                                    // x~ chunk row pitch in LDS
+__host__ __device__ __forceinline__ int q_pitch(int heads) { return heads * CH * 2 + 16; }
+__host__ __device__ __forceinline__ size_t time2_lds_staged(int heads, int F) {
+    return (size_t)2 * TQ * fwd_urow(heads) + (size_t)2 * TQ * q_pitch(heads) + (size_t)2 * TQ * F * XP;
+}
+
+template <int FT, int UPW>
+__global__ __launch_bounds__(512) void time2_logits_lds_kernel(const bf16_t* __restrict__ q2, const bf16_t* __restrict__ xt,
+                                                               const bf16_t* __restrict__ wkT, int64_t ldw,
+                                                               float* __restrict__ slab, int rows, int heads, float scale, int spread) {
+    constexpr int QPF = 16 / FT, NFR = FT > 8 ? FT / 8 : 1, NHW = NHeads<UPW>::value;
+    constexpr int XROWS = TQ * FT;                                 // (query, frame) rows of a tile
+    constexpr int NXP = XROWS * 8 / 512 > 0 ? XROWS * 8 / 512 : 1; // 16-byte x~ pieces per thread
+    constexpr int NQP = 4;                                         // 16-byte q2 pieces per thread (16 rows x C/8 <= 2048)
+    constexpr int LG = NQP + NXP;                                  // loads per thread and tile (fixed: counted waits)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const Owner own = owner_of_block(heads, spread);
+    if (own.range < 0) return;
+    const int C = heads * CH, cc = own.cc;
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int urow = fwd_urow(heads), QP = q_pitch(heads);
+    char* sUb = smem;
+    char* sQb = smem + 2 * TQ * urow;
+    char* sXb = sQb + 2 * TQ * QP;
+    const int ntiles = (rows + TQ - 1) / TQ;
+    const int t_begin = (int)((int64_t)ntiles * own.range / own.nranges), t_end = (int)((int64_t)ntiles * (own.range + 1) / own.nranges);
+    const int niter = t_end - t_begin;
+    if (niter <= 0) return;
+    WFrag<UPW> wf;
+    load_w_frags<UPW>(wf, wkT, ldw, cc, heads, w, lane);
+    const int col = lane & 15, kg = lane >> 4;
+    const int hl = col < heads ? col : heads - 1, hfirst = (w * UPW) >> 1;
+    // this thread's staging pieces (fixed for the whole launch)
+    const int qpr = C / 8, nqp = TQ * qpr;                         // 16-byte pieces per q2 row / per q2 tile
+    int qrow[NQP], qcol[NQP], qlds[NQP];
+#pragma unroll
+    for (int i = 0; i < NQP; ++i) {
+        const int p = tid + 512 * i, pc = min(p, nqp - 1);
+        qrow[i] = pc / qpr;
+        qcol[i] = (pc - qrow[i] * qpr) * 8;
+        qlds[i] = p < nqp ? qrow[i] * QP + qcol[i] * 2 : -1;
+    }
+    int xq[NXP], xoff[NXP], xlds[NXP];
+#pragma unroll
+    for (int i = 0; i < NXP; ++i) {
+        const int p = tid + 512 * i, pc = min(p, XROWS * 8 - 1), r = pc >> 3, c16 = pc & 7;
+        xq[i] = r / FT;
+        xoff[i] = (r % FT) * C + cc * CH + c16 * 8;
+        xlds[i] = p < XROWS * 8 ? r * XP + c16 * 16 : -1;
+    }
+    struct Pre { bf16x8 q[NQP]; bf16x8 x[NXP]; };
+    auto issue = [&](Pre& pr, int t) __attribute__((always_inline)) {
+        const int row0 = t * TQ;
+#pragma unroll
+        for (int i = 0; i < NQP; ++i) gload16_asm(pr.q[i], q2 + (int64_t)min(row0 + qrow[i], rows - 1) * C + qcol[i]);
+#pragma unroll
+        for (int i = 0; i < NXP; ++i) gload16_asm(pr.x[i], xt + (int64_t)min(row0 + xq[i], rows - 1) * FT * C + xoff[i]);
+    };
+    auto pin_pre = [&](Pre& pr) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < NQP; ++i) pin(pr.q[i]);
+#pragma unroll
+        for (int i = 0; i < NXP; ++i) pin(pr.x[i]);
+    };
+    auto stash = [&](const Pre& pr, int stage) __attribute__((always_inline)) {
+        char* sq = sQb + stage * (TQ * QP);
+        char* sx = sXb + stage * (XROWS * XP);
+#pragma unroll
+        for (int i = 0; i < NQP; ++i)
+            if (qlds[i] >= 0) *reinterpret_cast<bf16x8*>(sq + qlds[i]) = pr.q[i];
+#pragma unroll
+        for (int i = 0; i < NXP; ++i)
+            if (xlds[i] >= 0) *reinterpret_cast<bf16x8*>(sx + xlds[i]) = pr.x[i];
+    };
+    auto read_q = [&](QFrag<NHW>& qf, int stage) __attribute__((always_inline)) {
+        const char* sq = sQb + stage * (TQ * QP) + col * QP;
+#pragma unroll
+        for (int i = 0; i < NHW; ++i) {
+            const int h = min(hfirst + i, heads - 1);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) qf.v[i][ks] = *reinterpret_cast<const bf16x8*>(sq + (h * CH + 32 * ks + 8 * kg) * 2);
+        }
+    };
+    Pre pre[2];
+    // prologue: tiles 0, 1 -> LDS stages 0, 1; tiles 2, 3 -> registers; U(0)
+    issue(pre[0], t_begin);
+    issue(pre[1], t_begin + 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    pin_pre(pre[0]); pin_pre(pre[1]);
+    stash(pre[0], 0);
+    stash(pre[1], 1);
+    asm volatile("" ::: "memory");
+    pin_pre(pre[0]); pin_pre(pre[1]);
+    issue(pre[0], t_begin + 2);
+    issue(pre[1], t_begin + 3);
+    lds_barrier();
+    {
+        QFrag<NHW> qf;
+        read_q(qf, 0);
+        compute_u_tile<UPW, false>(wf, qf, sUb, urow, heads, w, lane);
+    }
+    lds_barrier();
+    for (int itb = 0; itb < niter; itb += 2) {
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const int it = itb + k;
+        if (it >= niter) break;
+        const int t = t_begin + it, row0 = t * TQ;
+        // A: this tile's x~ fragments and U rows, the next tile's q2 fragments -> registers
+        const char* sx = sXb + k * (XROWS * XP);
+        const char* sU = sUb + k * (TQ * urow);
+        bf16x8 xf[NFR][2], ub[NFR][QPF][2];
+#pragma unroll
+        for (int i = 0; i < NFR; ++i) {
+            const int fi = min(w + 8 * i, FT - 1);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) xf[i][ks] = *reinterpret_cast<const bf16x8*>(sx + (16 * fi + col) * XP + (32 * ks + 8 * kg) * 2);
+#pragma unroll
+            for (int j = 0; j < QPF; ++j)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks)
+                    ub[i][j][ks] = *reinterpret_cast<const bf16x8*>(sU + (QPF * fi + j) * urow + hl * FWD_HP + (32 * ks + 8 * kg) * 2);
+        }
+        QFrag<NHW> qf;
+        read_q(qf, k ^ 1);
+        lds_barrier();                                           // every wave has what it needs of stage k
+        // W: tile it + 2 (loaded two iterations ago) -> stage k;  C: its register slot re-issued for tile it + 4
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LG) : "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        pin_pre(pre[k]);
+        stash(pre[k], k);
+        asm volatile("" ::: "memory");
+        pin_pre(pre[k]);
+        issue(pre[k], t + 4);
+        // B: U of the next tile, contraction of this one
+        if (it + 1 < niter) compute_u_tile<UPW, false>(wf, qf, sUb + (k ^ 1) * (TQ * urow), urow, heads, w, lane);
+#pragma unroll
+        for (int i = 0; i < NFR; ++i) {
+            f32x4 acc[QPF];
+#pragma unroll
+            for (int j = 0; j < QPF; ++j) {
+                acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks)
+                    acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[i][ks], ub[i][j][ks], acc[j], 0, 0, 0);
+            }
+            f32x4 v = acc[0];
+#pragma unroll
+            for (int j = 1; j < QPF; ++j)
+                if ((4 * kg) / FT == j) v = acc[j];
+            const int fi = w + 8 * i;
+            const int jq = (4 * kg) / FT, f0 = (4 * kg) % FT;
+            const int row = row0 + QPF * fi + jq;
+            if (fi < FT && row < rows && col < heads) {
+                float4 o = make_float4(v[0] * scale, v[1] * scale, v[2] * scale, v[3] * scale);
+                *reinterpret_cast<float4*>(slab + (((int64_t)cc * rows + row) * heads + col) * FT + f0) = o;
+            }
+        }
+        lds_barrier();                                           // U(t+1) and stage k (tile it + 2) are complete
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // late ring loads: see time2_logits_kernel
 }
 
 // forward 2/3: sum the chunk slabs, softmax over the frames -> attn2 [row][h][F]
@@ -462,13 +655,13 @@ template <int FT, int UPW>
 __global__ __launch_bounds__(512) void time2_dx_kernel(const bf16_t* __restrict__ q2, const bf16_t* __restrict__ wkT, int64_t ldw,
                                                        const float* __restrict__ attn2, const bf16_t* __restrict__ dl,
                                                        const bf16_t* __restrict__ dout, int64_t dobs,
-                                                       bf16_t* __restrict__ dxt, int rows, int S, int heads) {
+                                                       bf16_t* __restrict__ dxt, int rows, int S, int heads, int spread) {
     constexpr int QPF = 16 / FT;           // queries per column tile (columns = (query, frame))
     constexpr int NNT = FT > 8 ? FT / 8 : 1;   // column tiles per wave: a tile of 16 queries has FT of them
     constexpr int KS = QPF > 2 ? QPF / 2 : 1;  // k steps: K = QPF queries x 16 heads (F = 16: the upper 16 slots are zero)
     constexpr int NHW = NHeads<UPW>::value;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const Owner own = owner_of_block(heads);
+    const Owner own = owner_of_block(heads, spread);
     if (own.range < 0) return;
     const int C = heads * CH, cc = own.cc;
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -607,6 +800,201 @@ __global__ __launch_bounds__(512) void time2_dx_kernel(const bf16_t* __restrict_
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // late ring loads: see time2_logits_kernel
 }
 
+// backward 2/2 with the q2 tile staged through LDS (see time2_logits_lds_kernel: the four fragment-layout q2 loads per wave
+// were 32 of the 64 KB a tile pulled through the L1/TA at the 16 B/clk rate of that pattern).  q2 rows are loaded
+// row-contiguous two tiles ahead, stored to a padded LDS image and read back as fragments; the small per-column operands
+// (dl, a, dout) keep their direct loads, two tiles ahead.  Issue order per tile: q pieces (tile + 4), then the column
+// operands (tile + 2): the counted waits below follow from it.
+template <int FT, int UPW>
+__global__ __launch_bounds__(512) void time2_dx_lds_kernel(const bf16_t* __restrict__ q2, const bf16_t* __restrict__ wkT, int64_t ldw,
+                                                           const float* __restrict__ attn2, const bf16_t* __restrict__ dl,
+                                                           const bf16_t* __restrict__ dout, int64_t dobs,
+                                                           bf16_t* __restrict__ dxt, int rows, int S, int heads, int spread) {
+    constexpr int QPF = 16 / FT, NNT = FT > 8 ? FT / 8 : 1, KS = QPF > 2 ? QPF / 2 : 1, NHW = NHeads<UPW>::value;
+    constexpr int NQP = 4, NX = NNT * 4;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const Owner own = owner_of_block(heads, spread);
+    if (own.range < 0) return;
+    const int C = heads * CH, cc = own.cc, QP = q_pitch(heads);
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    char* sQb = smem + 2 * TQ * BWD_UROW;
+    const int ntiles = (rows + TQ - 1) / TQ;
+    const int t_begin = (int)((int64_t)ntiles * own.range / own.nranges), t_end = (int)((int64_t)ntiles * (own.range + 1) / own.nranges);
+    const int niter = t_end - t_begin;
+    if (niter <= 0) return;
+    WFrag<UPW> wf;
+    load_w_frags<UPW>(wf, wkT, ldw, cc, heads, w, lane);
+    for (int e = tid; e < 2 * TQ * BWD_UROW / 16; e += 512)         // head rows >= heads stay zero
+        reinterpret_cast<uint4*>(smem)[e] = make_uint4(0, 0, 0, 0);
+    const int col = lane & 15, kg = lane >> 4, hfirst = (w * UPW) >> 1;
+    const int j = col / FT, f = col % FT;
+    const int hb = QPF >= 2 ? 8 * (kg >> 1) : 8 * (kg & 1);
+    const int tq = (lane & 15) >> 2, tp = lane & 3;
+    const int qpr = C / 8, nqp = TQ * qpr;
+    int qrow[NQP], qcol[NQP], qlds[NQP];
+#pragma unroll
+    for (int i = 0; i < NQP; ++i) {
+        const int p = tid + 512 * i, pc = min(p, nqp - 1);
+        qrow[i] = pc / qpr;
+        qcol[i] = (pc - qrow[i] * qpr) * 8;
+        qlds[i] = p < nqp ? qrow[i] * QP + qcol[i] * 2 : -1;
+    }
+    struct PreQ { bf16x8 q[NQP]; };
+    struct DFrag { bf16x8 dl[NNT]; float a[NNT]; bf16x8 dout[NNT][2]; };
+    auto issue_q = [&](PreQ& pr, int t) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < NQP; ++i) gload16_asm(pr.q[i], q2 + (int64_t)min(t * TQ + qrow[i], rows - 1) * C + qcol[i]);
+    };
+    auto pin_pq = [&](PreQ& pr) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < NQP; ++i) pin(pr.q[i]);
+    };
+    auto stash_q = [&](const PreQ& pr, int stage) __attribute__((always_inline)) {
+        char* sq = sQb + stage * (TQ * QP);
+#pragma unroll
+        for (int i = 0; i < NQP; ++i)
+            if (qlds[i] >= 0) *reinterpret_cast<bf16x8*>(sq + qlds[i]) = pr.q[i];
+    };
+    auto read_q = [&](QFrag<NHW>& qf, int stage) __attribute__((always_inline)) {
+        const char* sq = sQb + stage * (TQ * QP) + col * QP;
+#pragma unroll
+        for (int i = 0; i < NHW; ++i) {
+            const int h = min(hfirst + i, heads - 1);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) qf.v[i][ks] = *reinterpret_cast<const bf16x8*>(sq + (h * CH + 32 * ks + 8 * kg) * 2);
+        }
+    };
+    auto load_d = [&](DFrag& x, int t) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < NNT; ++i) {
+            const int nt = min(w + 8 * i, FT - 1);
+            const int row = min(t * TQ + QPF * nt + j, rows - 1);
+            const int b = row / S;
+            gload16_asm(x.dl[i], dl + ((int64_t)row * FT + f) * MAXH + hb);
+            gload4_asm(x.a[i], attn2 + ((int64_t)row * heads + cc) * FT + f);
+            const bf16_t* dp = dout + b * dobs + (int64_t)(row - b * S) * C + cc * CH + 16 * kg;
+            gload16_asm(x.dout[i][0], dp);
+            gload16_asm(x.dout[i][1], dp + 8);
+        }
+    };
+    auto pin_d = [&](DFrag& x) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < NNT; ++i) { pin(x.dl[i]); pin(x.a[i]); pin(x.dout[i][0]); pin(x.dout[i][1]); }
+    };
+    PreQ pq[2];
+    DFrag dr[2];
+    // prologue: q2 tiles 0, 1 -> LDS; then, in the steady-state issue order of iterations -2 and -1: q(2) d(0) q(3) d(1)
+    issue_q(pq[0], t_begin);
+    issue_q(pq[1], t_begin + 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    pin_pq(pq[0]); pin_pq(pq[1]);
+    stash_q(pq[0], 0);
+    stash_q(pq[1], 1);
+    asm volatile("" ::: "memory");
+    pin_pq(pq[0]); pin_pq(pq[1]);
+    issue_q(pq[0], t_begin + 2);
+    load_d(dr[0], t_begin);
+    issue_q(pq[1], t_begin + 3);
+    load_d(dr[1], t_begin + 1);
+    lds_barrier();                                                // zero fill and q2 stages visible
+    {
+        QFrag<NHW> qf;
+        read_q(qf, 0);
+        compute_u_tile<UPW, true>(wf, qf, smem, 0, heads, w, lane);
+    }
+    lds_barrier();
+    for (int itb = 0; itb < niter; itb += 2) {
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const int it = itb + k;
+        if (it >= niter) break;
+        const int t = t_begin + it, row0 = t * TQ;
+        const char* sU = smem + k * (TQ * BWD_UROW);
+        // A: U^T of this tile (gathered h-major) and the next tile's q2 fragments -> registers
+        TrFrag af[NNT][KS][4];
+#pragma unroll
+        for (int i = 0; i < NNT; ++i) {
+            const int nt = min(w + 8 * i, FT - 1);
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const int jp = QPF >= 2 ? (kg & 1) + 2 * ks : 0;
+                const int sa = QPF * nt + jp;
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) {
+                    af[i][ks][mt].t[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(sU + bwd_off(sa, hb + tq, 4 * tp + mt)));
+                    af[i][ks][mt].t[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(sU + bwd_off(sa, hb + 4 + tq, 4 * tp + mt)));
+                }
+            }
+        }
+        QFrag<NHW> qf;
+        read_q(qf, k ^ 1);
+        lds_barrier();                                           // every wave has what it needs of q2 stage k^1 ... and of
+                                                                 // stage k (read one iteration ago): stage k may be rewritten
+        // W / C: q2 tile it + 2 -> stage k, its registers re-issued for tile it + 4
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NQP + 2 * NX) : "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        pin_pq(pq[k]);
+        stash_q(pq[k], k);
+        asm volatile("" ::: "memory");
+        pin_pq(pq[k]);
+        issue_q(pq[k], t + 4);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NQP + NX) : "memory");   // the column operands of this tile
+        __builtin_amdgcn_sched_barrier(0);
+        pin_d(dr[k]);
+        // B: U of the next tile, dx~ of this one
+        if (it + 1 < niter) compute_u_tile<UPW, true>(wf, qf, smem + (k ^ 1) * (TQ * BWD_UROW), 0, heads, w, lane);
+        uint4 o[NNT][2];
+#pragma unroll
+        for (int i = 0; i < NNT; ++i) {
+            f32x4 acc[4];
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) acc[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const int jp = QPF >= 2 ? (kg & 1) + 2 * ks : 0;
+                const bool keep = QPF >= 2 ? jp == j : kg < 2;
+                bf16x8 bfr = dr[k].dl[i];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) bfr[e] = keep ? bfr[e] : (__bf16)0.f;
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt)
+                    acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i][ks][mt].v, bfr, acc[mt], 0, 0, 0);
+            }
+            float dv[16], v[16];
+            unpack8(*reinterpret_cast<const uint4*>(&dr[k].dout[i][0]), dv);
+            unpack8(*reinterpret_cast<const uint4*>(&dr[k].dout[i][1]), dv + 8);
+            const float av = dr[k].a[i];
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[4 * mt + r] = fmaf(av, dv[4 * mt + r], acc[mt][r]);
+            o[i][0] = pack8(v);
+            o[i][1] = pack8(v + 8);
+        }
+        asm volatile("" ::: "memory");
+        pin_d(dr[k]);
+        load_d(dr[k], t + 2);
+#pragma unroll
+        for (int i = 0; i < NNT; ++i) {
+            const int nt = w + 8 * i;
+            const int row = row0 + QPF * nt + j;
+            if (nt < FT && row < rows) {
+                uint4* dp = reinterpret_cast<uint4*>(dxt + ((int64_t)row * FT + f) * C + cc * CH + 16 * kg);
+                dp[0] = o[i][0];
+                dp[1] = o[i][1];
+            }
+        }
+        lds_barrier();                                           // U(t+1) and q2 stage k (tile it + 2) are complete
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // late ring loads: see time2_logits_kernel
+}
+
+int spread_mode() {
+    static const int v = getenv("FOCUS_T2_SPREAD") ? atoi(getenv("FOCUS_T2_SPREAD")) : 0;
+    return v;
+}
+
 size_t time2_lds_fwd(int heads) { return (size_t)2 * TQ * fwd_urow(heads); }
 size_t time2_lds_bwd() { return (size_t)2 * TQ * BWD_UROW; }
 
@@ -638,13 +1026,20 @@ extern "C" int focus_traj_time2_fwd(const void* q2, const void* xt, const void* 
     if (ws_bytes < focus_traj_time2_workspace_bytes(B, S, F, heads, d)) return FOCUS_ERR_WORKSPACE;
     hipStream_t s = (hipStream_t)stream;
     const int nchunk = C / CH;
-    const size_t lds = time2_lds_fwd(heads);
     const float scale = 1.f / sqrtf((float)d);
     const int upw = (2 * heads + 7) / 8;                          // weight units per wave (see WFrag)
+    static const bool staged_on = !(getenv("FOCUS_T2_LDS") && atoi(getenv("FOCUS_T2_LDS")) == 0);
+    const bool staged = staged_on && F <= 8 && time2_lds_staged(heads, F) <= 160 * 1024;
+    const size_t lds = staged ? time2_lds_staged(heads, F) : time2_lds_fwd(heads);
 #define TL(FT, UPW) do { \
+        if (staged) { \
+            static bool once_s = (hipFuncSetAttribute((const void*)time2_logits_lds_kernel<FT, UPW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess); \
+            (void)once_s; \
+            hipLaunchKernelGGL((time2_logits_lds_kernel<FT, UPW>), dim3(256), dim3(512), lds, s, (const bf16_t*)q2, (const bf16_t*)xt, (const bf16_t*)wkT, ldw, (float*)ws, (int)rows, heads, scale, spread_mode()); \
+            break; } \
         static bool once = (hipFuncSetAttribute((const void*)time2_logits_kernel<FT, UPW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess); \
         (void)once; \
-        hipLaunchKernelGGL((time2_logits_kernel<FT, UPW>), dim3(256), dim3(512), lds, s, (const bf16_t*)q2, (const bf16_t*)xt, (const bf16_t*)wkT, ldw, (float*)ws, (int)rows, heads, scale); } while (0)
+        hipLaunchKernelGGL((time2_logits_kernel<FT, UPW>), dim3(256), dim3(512), lds, s, (const bf16_t*)q2, (const bf16_t*)xt, (const bf16_t*)wkT, ldw, (float*)ws, (int)rows, heads, scale, spread_mode()); } while (0)
 #define TLU(FT) do { if (upw == 1) TL(FT, 1); else if (upw == 2) TL(FT, 2); else if (upw == 3) TL(FT, 3); else TL(FT, 4); } while (0)
     if (F == 8) TLU(8); else if (F == 4) TLU(4); else TLU(16);
 #undef TLU
@@ -687,12 +1082,22 @@ extern "C" int focus_traj_time2_bwd(const void* q2, const void* xt, const void* 
 #undef TD
         FOCUS_CHECK_LAUNCH();
     }
-    const size_t lds = time2_lds_bwd();
     const int upw = (2 * heads + 7) / 8;
+    static const bool staged_on = !(getenv("FOCUS_T2_LDS") && atoi(getenv("FOCUS_T2_LDS")) == 0);
+    const size_t lds_staged = time2_lds_bwd() + (size_t)2 * TQ * q_pitch(heads);
+    // (13..16 heads with F = 4 or 16: the staged variant would spill, and a spilled ring register is stored before its
+    // inline-asm load lands -> those shapes keep the direct kernel)
+    const bool staged = staged_on && lds_staged <= 160 * 1024 && !(upw == 4 && F != 8);
+    const size_t lds = staged ? lds_staged : time2_lds_bwd();
 #define TB(FT, UPW) do { \
+        if (staged) { \
+            static bool once_s = (hipFuncSetAttribute((const void*)time2_dx_lds_kernel<FT, UPW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess); \
+            (void)once_s; \
+            hipLaunchKernelGGL((time2_dx_lds_kernel<FT, UPW>), dim3(256), dim3(512), lds, s, (const bf16_t*)q2, (const bf16_t*)wkT, ldw, attn2, (const bf16_t*)dl, (const bf16_t*)dout, dout_bstride, (bf16_t*)dxt, (int)rows, S, heads, spread_mode()); \
+            break; } \
         static bool once = (hipFuncSetAttribute((const void*)time2_dx_kernel<FT, UPW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess); \
         (void)once; \
-        hipLaunchKernelGGL((time2_dx_kernel<FT, UPW>), dim3(256), dim3(512), lds, s, (const bf16_t*)q2, (const bf16_t*)wkT, ldw, attn2, (const bf16_t*)dl, (const bf16_t*)dout, dout_bstride, (bf16_t*)dxt, (int)rows, S, heads); } while (0)
+        hipLaunchKernelGGL((time2_dx_kernel<FT, UPW>), dim3(256), dim3(512), lds, s, (const bf16_t*)q2, (const bf16_t*)wkT, ldw, attn2, (const bf16_t*)dl, (const bf16_t*)dout, dout_bstride, (bf16_t*)dxt, (int)rows, S, heads, spread_mode()); } while (0)
 #define TBU(FT) do { if (upw == 1) TB(FT, 1); else if (upw == 2) TB(FT, 2); else if (upw == 3) TB(FT, 3); else TB(FT, 4); } while (0)
     if (F == 8) TBU(8); else if (F == 4) TBU(4); else TBU(16);
 #undef TBU
