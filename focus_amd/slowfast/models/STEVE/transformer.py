@@ -48,12 +48,39 @@ class MultiHeadAttention(nn.Module):
         return ops.linear(a, self.proj_o.weight, residual=residual)
 
 
+def _norm(ln, x):
+    return ops.layer_norm(x, ln.weight, ln.bias, ln.eps)
+
+
+def _make_ffn(d_model, gain, dropout):
+    """The feed-forward member of both block kinds: indices 0 / 2 hold the Linear layers, 3 the dropout."""
+    return nn.Sequential(linear(d_model, 4 * d_model, weight_init="kaiming"), nn.ReLU(),
+                         linear(4 * d_model, d_model, gain=gain), nn.Dropout(dropout))
+
+
 def _ffn(seq, x, residual, training):
-    """Linear -> ReLU -> Linear -> Dropout (+ residual)."""
-    p = seq[3].p
-    if training and p > 0.0:
-        return residual + seq[3](ops.mlp(x, seq[0].weight, seq[0].bias, seq[2].weight, seq[2].bias, act=ops.EPI_RELU))
-    return ops.mlp(x, seq[0].weight, seq[0].bias, seq[2].weight, seq[2].bias, residual=residual, act=ops.EPI_RELU)
+    """Linear -> ReLU -> Linear -> Dropout (+ residual): one fused op, the residual in the second GEMM's epilogue."""
+    up, down, drop = seq[0], seq[2], seq[3]
+    if training and drop.p > 0.0:
+        return residual + drop(ops.mlp(x, up.weight, up.bias, down.weight, down.bias, act=ops.EPI_RELU))
+    return ops.mlp(x, up.weight, up.bias, down.weight, down.bias, residual=residual, act=ops.EPI_RELU)
+
+
+class _BlockStack(nn.Module):
+    """`blocks` (the first one flagged is_first) followed by a closing LayerNorm: the shape both transformers share.
+    `branches` is the number of residual branches per block; the output projections are scaled by
+    (branches * num_blocks) ** -0.5 (transformer.py:101, :175)."""
+
+    def __init__(self, num_blocks, d_model, branches, make_block):
+        super().__init__()
+        gain = (branches * num_blocks) ** (-0.5) if num_blocks > 0 else 1.0
+        self.blocks = nn.ModuleList([make_block(gain, i == 0) for i in range(num_blocks)])
+        self.layer_norm = nn.LayerNorm(d_model)
+
+    def forward(self, input, *context):
+        for block in self.blocks:
+            input = block(input, *context)
+        return _norm(self.layer_norm, input)
 
 
 class TransformerEncoderBlock(nn.Module):
@@ -63,13 +90,12 @@ class TransformerEncoderBlock(nn.Module):
         self.attn_layer_norm = nn.LayerNorm(d_model)
         self.attn = MultiHeadAttention(d_model, num_heads, dropout, gain)
         self.ffn_layer_norm = nn.LayerNorm(d_model)
-        self.ffn = nn.Sequential(linear(d_model, 4 * d_model, weight_init="kaiming"), nn.ReLU(),
-                                 linear(4 * d_model, d_model, gain=gain), nn.Dropout(dropout))
+        self.ffn = _make_ffn(d_model, gain, dropout)
 
     def forward(self, input):
         ln = self.attn_layer_norm
         if self.is_first:       # the residual stream itself is normalised (:75-78)
-            input = ops.layer_norm(input, ln.weight, ln.bias, ln.eps)
+            input = _norm(ln, input)
             input = self.attn(input, input, input, residual=input)
         else:
             input, x = ops.layer_norm_fork(input, ln.weight, ln.bias, ln.eps)
@@ -79,24 +105,12 @@ class TransformerEncoderBlock(nn.Module):
         return _ffn(self.ffn, x, input, self.training)
 
 
-class TransformerEncoder(nn.Module):
-    def __init__(self, num_blocks, d_model, num_heads, dropout=0.0):
-        super().__init__()
-        if num_blocks > 0:
-            gain = (2 * num_blocks) ** (-0.5)
-            self.blocks = nn.ModuleList(
-                [TransformerEncoderBlock(d_model, num_heads, dropout, gain, is_first=True)] +
-                [TransformerEncoderBlock(d_model, num_heads, dropout, gain, is_first=False)
-                 for _ in range(num_blocks - 1)])
-        else:
-            self.blocks = nn.ModuleList()
-        self.layer_norm = nn.LayerNorm(d_model)
+class TransformerEncoder(_BlockStack):
+    """transformer.py:96-114 (two residual branches per block)."""
 
-    def forward(self, input):
-        for block in self.blocks:
-            input = block(input)
-        ln = self.layer_norm
-        return ops.layer_norm(input, ln.weight, ln.bias, ln.eps)
+    def __init__(self, num_blocks, d_model, num_heads, dropout=0.0):
+        super().__init__(num_blocks, d_model, 2,
+                         lambda gain, first: TransformerEncoderBlock(d_model, num_heads, dropout, gain, is_first=first))
 
 
 class TransformerDecoderBlock(nn.Module):
@@ -113,44 +127,26 @@ class TransformerDecoderBlock(nn.Module):
         self.encoder_decoder_attn_layer_norm = nn.LayerNorm(d_model)
         self.encoder_decoder_attn = MultiHeadAttention(d_model, num_heads, dropout, gain)
         self.ffn_layer_norm = nn.LayerNorm(d_model)
-        self.ffn = nn.Sequential(linear(d_model, 4 * d_model, weight_init="kaiming"), nn.ReLU(),
-                                 linear(4 * d_model, d_model, gain=gain), nn.Dropout(dropout))
+        self.ffn = _make_ffn(d_model, gain, dropout)
 
     def forward(self, input, encoder_output):
         T = input.shape[1]
         ln = self.self_attn_layer_norm
         mask = self.self_attn_mask[:T, :T]
         if self.is_first:
-            input = ops.layer_norm(input, ln.weight, ln.bias, ln.eps)
+            input = _norm(ln, input)
             input = self.self_attn(input, input, input, mask, residual=input)
         else:
-            x = ops.layer_norm(input, ln.weight, ln.bias, ln.eps)
+            x = _norm(ln, input)
             input = self.self_attn(x, x, x, mask, residual=input)
-        el = self.encoder_decoder_attn_layer_norm
-        x = ops.layer_norm(input, el.weight, el.bias, el.eps)
+        x = _norm(self.encoder_decoder_attn_layer_norm, input)
         input = self.encoder_decoder_attn(x, encoder_output, encoder_output, residual=input)
-        fl = self.ffn_layer_norm
-        x = ops.layer_norm(input, fl.weight, fl.bias, fl.eps)
-        return _ffn(self.ffn, x, input, self.training)
+        return _ffn(self.ffn, _norm(self.ffn_layer_norm, input), input, self.training)
 
 
-class TransformerDecoder(nn.Module):
-    """transformer.py:169-193."""
+class TransformerDecoder(_BlockStack):
+    """transformer.py:169-193 (three residual branches per block); forward(input, encoder_output)."""
 
     def __init__(self, num_blocks, max_len, d_model, num_heads, dropout=0.0):
-        super().__init__()
-        if num_blocks > 0:
-            gain = (3 * num_blocks) ** (-0.5)
-            self.blocks = nn.ModuleList(
-                [TransformerDecoderBlock(max_len, d_model, num_heads, dropout, gain, is_first=True)] +
-                [TransformerDecoderBlock(max_len, d_model, num_heads, dropout, gain, is_first=False)
-                 for _ in range(num_blocks - 1)])
-        else:
-            self.blocks = nn.ModuleList()
-        self.layer_norm = nn.LayerNorm(d_model)
-
-    def forward(self, input, encoder_output):
-        for block in self.blocks:
-            input = block(input, encoder_output)
-        ln = self.layer_norm
-        return ops.layer_norm(input, ln.weight, ln.bias, ln.eps)
+        super().__init__(num_blocks, d_model, 3, lambda gain, first: TransformerDecoderBlock(
+            max_len, d_model, num_heads, dropout, gain, is_first=first))

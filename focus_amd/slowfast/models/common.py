@@ -27,20 +27,25 @@ class Mlp(nn.Module):
                        act=ops.EPI_GELU)
 
 
-def drop_path(x, drop_prob: float = 0.0, training: bool = False):
-    """Stochastic depth per sample (common.py:46-60)."""
-    if drop_prob == 0.0 or not training:
-        return x
-    keep = 1 - drop_prob
-    mask = keep + torch.rand((x.shape[0],) + (1,) * (x.ndim - 1), dtype=x.dtype, device=x.device)
-    mask.floor_()
-    return x.div(keep) * mask
-
-
 class DropPath(nn.Module):
+    """Stochastic depth (common.py:46-70): a whole sample's residual branch is zeroed with probability drop_prob and the
+    survivors are rescaled by 1 / keep.  The blocks of the hot path do not call this module -- they read `drop_prob`
+    and fold the draw into the residual add (ops.residual_drop_path, one kernel); forward() is the standalone form
+    for any other caller, using the reference's draw (floor(keep + U[0,1)) per sample, one torch.rand of shape
+    [B, 1, ...])."""
+
     def __init__(self, drop_prob=None):
         super().__init__()
         self.drop_prob = drop_prob
 
     def forward(self, x):
-        return drop_path(x, self.drop_prob, self.training)
+        return drop_path(x, self.drop_prob or 0.0, self.training)
+
+
+def drop_path(x, drop_prob: float = 0.0, training: bool = False):
+    if not training or drop_prob == 0.0:
+        return x
+    keep = 1 - drop_prob
+    per_sample = [x.shape[0]] + [1] * (x.dim() - 1)
+    survives = torch.rand(per_sample, dtype=x.dtype, device=x.device).add_(keep).floor_()
+    return x.div(keep) * survives
