@@ -5,6 +5,7 @@
 // per-chunk partials and applies the 1/sum_n normalisation.  HBM-bound: 2*N*D*esize read per (b,t,iter).
 #include "focus_common.h"
 #include <cstdlib>
+#include <utility>
 
 namespace {
 
@@ -276,120 +277,342 @@ __device__ __forceinline__ sbf16x8 slot_frag(const bf16_t* base, int slot, int K
     return f.v;
 }
 
-template <int KS>   // KS = D / 32
+// ---- rank-1 sums over the rows on the matrix pipe ----
+// updates[slot][c] = sum_rows ae[row][slot] v[row][c]   (forward)      dq[slot][c] = sum_rows dl[row][slot] k[row][c]   (backward)
+// are products with the ROW as the reduction index.  As VALU rank-1 updates they cost 80 wave instructions per row
+// (64 FMA + the LDS broadcasts of the 16 scalars, 48 of 64 lanes active at D = 192): 17 us of issue per SIMD at
+// B = 32, N = 4096 against 12.5 us of HBM time -- the forward launch measured 31.9 us, the backward 40.2.  Here:
+//   * phase 1 runs "swapped" (A = the 16 rows of k / v, B = the slot matrix), so a lane ends with slot (lane & 15) of
+//     rows 4g .. 4g+3: the softmax over the slots is a 16-lane DPP reduction, and the lane's values of two consecutive
+//     16-row tiles ARE the A fragment of a 32-row reduction step, with reduction slot j of lane group g standing for row
+//     16 (j >> 2) + 4 g + (j & 3) of the step;
+//   * the other operand (v or k rows, channel on the lane, the same row order) is gathered from a wave-private LDS
+//     image of the 32 rows by ds_read_b64_tr_b16; row pitch 2 D + 32 bytes = 8 * odd dwords: the 8 rows one 32-lane
+//     half touches sit on 8 different 8-bank groups, conflict-free;
+//   * 2 * D / 16 MFMAs per 32 rows replace 2560 VALU instructions.  The image is filled by 16-byte row-contiguous loads
+//     (the 32 rows are one contiguous 64 D-byte run of HBM); no workgroup barrier until the final 4-wave combine, whose
+//     buffer reuses the wave's own image.
+typedef __attribute__((ext_vector_type(4))) short ss16x4;
+typedef __attribute__((address_space(3))) ss16x4 lds_ss16x4;
+union STrFrag { sbf16x8 v; ss16x4 t[2]; };
+
+template <int KS> struct SlotImg {
+    static constexpr int D = KS * 32;
+    static constexpr int PITCH = 2 * D + 32;              // bytes per image row
+    static constexpr int BYTES = 32 * PITCH;              // one wave's image: 32 rows (>= 16 x (D + 1) floats of the combine)
+    static constexpr int CPR = D / 8;                     // 16-byte chunks per row
+    static constexpr int NLD = 2 * KS;                    // chunks per lane
+};
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float x) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xf, 0xf, true));
+}
+// all-reduce over the 16 lanes of a DPP row: mirror (i <-> 15-i), half mirror (i <-> 7-i), quad xor 1, quad xor 2
+__device__ __forceinline__ float row16_max(float x) {
+    x = fmaxf(x, dpp_f<0x140>(x)); x = fmaxf(x, dpp_f<0x141>(x)); x = fmaxf(x, dpp_f<0xB1>(x)); return fmaxf(x, dpp_f<0x4E>(x));
+}
+__device__ __forceinline__ float row16_sum(float x) {
+    x += dpp_f<0x140>(x); x += dpp_f<0x141>(x); x += dpp_f<0xB1>(x); return x + dpp_f<0x4E>(x);
+}
+
+// ---- loads issued by hand (cdna_hip_programming.md 5.7 form (iii)) ----
+// Left to the compiler, every group of loads sinks to its first use and the step becomes three exposed HBM round trips
+// with 6-12 KB in flight per wave (25 us per launch); __builtin_amdgcn_sched_barrier does not help, the loads are
+// sunk before the machine scheduler runs.  Here a step's loads are issued together, in the order they are needed, and
+// each consumer waits with a counted s_waitcnt: vmcnt(number of HAND-ISSUED loads younger than the one needed).  The
+// count ignores the stores (and, backward, nothing else reads through the compiler inside the step): loads return in
+// order, so "at most Y operations outstanding" with Y younger loads can only hold once the awaited load is back --
+// extra outstanding operations only make the wait longer.  The next step's loads are issued before this step's MFMA
+// phase, into the registers phase 1 and the LDS copy have just released.
+typedef __attribute__((ext_vector_type(4))) uint32_t su32x4;   // (a true vector type: HIP's uint4 struct is no asm register operand)
+template <int OFF>
+__device__ __forceinline__ void sload16(su32x4& dst, const void* p) {
+    asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(dst) : "v"(p), "n"(OFF) : "memory");
+}
+template <int OFF>
+__device__ __forceinline__ void sload2(uint32_t& dst, const void* p) {
+    asm volatile("global_load_ushort %0, %1, off offset:%2" : "=v"(dst) : "v"(p), "n"(OFF) : "memory");
+}
+template <int N> __device__ __forceinline__ void swait() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+__device__ __forceinline__ void spin(su32x4& v) { asm volatile("" : "+v"(v)); }
+__device__ __forceinline__ void spin(uint32_t& v) { asm volatile("" : "+v"(v)); }
+
+// the KS operand fragments of one 16-row tile: lane (row t16, d-group g) reads 16 bytes of every 64-byte k step
+// HAND = false (row counts with a ragged last workgroup): the same loads through the compiler, which then also does
+// the waiting.  The clamped per-chunk addresses raise the register pressure, and under pressure the compiler parks
+// values in AGPRs -- a copy of a register whose hand-issued load is still in flight copies garbage (seen in the D = 256
+// instance: v_accvgpr_write of the destination right after the global_load).  tests/test_asm_load_lint.py checks that no
+// kernel with hand-issued loads contains such copies or scratch.
+template <int KS, bool HAND, int... J>
+__device__ __forceinline__ void slot_issue_frags(su32x4 (&f)[KS], const bf16_t* row, std::integer_sequence<int, J...>) {
+    if constexpr (HAND) (sload16<J * 64>(f[J], row), ...);
+    else ((f[J] = *reinterpret_cast<const su32x4*>(row + J * 32)), ...);
+}
+template <int KS, bool HAND, int... J>
+__device__ __forceinline__ void slot_pin_frags(su32x4 (&f)[KS], std::integer_sequence<int, J...>) {
+    if constexpr (HAND) (spin(f[J]), ...);
+}
+template <bool HAND, int N> __device__ __forceinline__ void slot_wait() { if constexpr (HAND) swait<N>(); }
+__device__ __forceinline__ sbf16x8 as_frag(const su32x4& u) { return __builtin_bit_cast(sbf16x8, u); }
+
+// rows n_first .. n_first+31 of a [N][D] matrix, 16 bytes per lane and load: chunk lane + 64 u of the 64 D-byte run.
+// FULL (all 32 rows exist): hand-issued, one base address per 4 loads and immediate offsets; else compiler loads with
+// every chunk's row clamped to N-1 (the weights of those rows are zero, the data only has to be finite).
+template <int KS, bool FULL, int... U>
+__device__ __forceinline__ void slot_issue_rows(su32x4 (&r)[2 * KS], const bf16_t* base, int n_first, int N, int lane,
+                                                std::integer_sequence<int, U...>) {
+    using I = SlotImg<KS>;
+    if constexpr (FULL) {
+        const char* p = reinterpret_cast<const char*>(base + (int64_t)n_first * I::D) + lane * 16;
+        (sload16<(U & 3) * 1024>(r[U], p + (U >> 2) * 4096), ...);
+    } else {
+        auto one = [&](su32x4& dst, int u) __attribute__((always_inline)) {
+            const int i = lane + 64 * u, row = i / I::CPR, ch = i - row * I::CPR;
+            dst = *reinterpret_cast<const su32x4*>(base + (int64_t)min(n_first + row, N - 1) * I::D + ch * 8);
+        };
+        (one(r[U], U), ...);
+    }
+}
+template <int KS, bool HAND, int... U>
+__device__ __forceinline__ void slot_store_rows(char* img, su32x4 (&r)[2 * KS], int lane, std::integer_sequence<int, U...>) {
+    using I = SlotImg<KS>;
+    if constexpr (HAND) (spin(r[U]), ...);
+#pragma unroll
+    for (int u = 0; u < I::NLD; ++u) {
+        const int i = lane + 64 * u, row = i / I::CPR, ch = i - row * I::CPR;
+        *reinterpret_cast<su32x4*>(img + row * I::PITCH + ch * 16) = r[u];
+    }
+}
+// acc[ct][r] += sum over the 32 rows of a[row][slot 4g + r] * img[row][16 ct + (lane & 15)]
+template <int KS>
+__device__ __forceinline__ void slot_rank_mfma(sf32x4 (&acc)[2 * KS], const char* img, sbf16x8 a, int lane) {
+    using I = SlotImg<KS>;
+    const int i = lane & 15, g = lane >> 4;
+    const char* p0 = img + (4 * g + (i >> 2)) * I::PITCH + (i & 3) * 8;
+#pragma unroll
+    for (int ct = 0; ct < 2 * KS; ++ct) {
+        STrFrag f;
+        f.t[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ss16x4*)(p0 + ct * 32));
+        f.t[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ss16x4*)(p0 + 16 * I::PITCH + ct * 32));
+        acc[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, f.v, acc[ct], 0, 0, 0);
+    }
+}
+// the 4 waves' [16 slots][D (+1)] accumulators meet in LDS (each wave writes into its own image), summed into partial
+template <int KS, int EXTRA>
+__device__ __forceinline__ void slot_combine(char* smem, const sf32x4 (&acc)[2 * KS], float extra, float* out, int K) {
+    using I = SlotImg<KS>;
+    constexpr int LD = I::D + EXTRA;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, t16 = lane & 15, g = lane >> 4;
+    float* mine = reinterpret_cast<float*>(smem + w * I::BYTES);
+#pragma unroll
+    for (int ct = 0; ct < 2 * KS; ++ct)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) mine[(4 * g + r) * LD + 16 * ct + t16] = acc[ct][r];
+    if (EXTRA && g == 0) mine[t16 * LD + I::D] = extra;
+    __syncthreads();
+    for (int e = threadIdx.x; e < K * LD; e += 256) {
+        float t = 0.f;
+#pragma unroll
+        for (int ww = 0; ww < 4; ++ww) t += reinterpret_cast<const float*>(smem + ww * I::BYTES)[e];
+        out[e] = t;
+    }
+}
+
+template <int KS, bool FULL>   // KS = D / 32; FULL: N is a multiple of the 256 rows of a workgroup
 __global__ __launch_bounds__(256) void slot_fwd_mfma_kernel(const bf16_t* __restrict__ kt, const bf16_t* __restrict__ vt,
                                                             int64_t kv_bs, const bf16_t* __restrict__ q,
                                                             bf16_t* __restrict__ attn, int64_t attn_bs,
                                                             float* __restrict__ partial, int N, int K, float eps) {
+    using I = SlotImg<KS>;
     constexpr int D = KS * 32;
-    __shared__ __attribute__((aligned(16))) float sA[4][64][16];          // (attn + eps) per (row, slot), 0 for padding
-    __shared__ float red[4][16][D + 1];
+    constexpr auto SK = std::make_integer_sequence<int, KS>{};
+    constexpr auto SV = std::make_integer_sequence<int, 2 * KS>{};
+    __shared__ __attribute__((aligned(16))) char smem[4 * I::BYTES];
     const int b = blockIdx.y, chunk = blockIdx.x, nchunk = gridDim.x;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int t16 = lane & 15, g = lane >> 4;
     const int n0 = chunk * MROWS + w * 64;
     const bf16_t* kb = kt + (int64_t)b * kv_bs;
     const bf16_t* vb = vt + (int64_t)b * kv_bs;
+    char* img = smem + w * I::BYTES;
+    su32x4 kf[2][KS], vr[2 * KS];
+    auto issue = [&](int step) __attribute__((always_inline)) {
+#pragma unroll
+        for (int half = 0; half < 2; ++half)
+            slot_issue_frags<KS, FULL>(kf[half], kb + (int64_t)min(n0 + step * 32 + half * 16 + t16, N - 1) * D + g * 8, SK);
+        slot_issue_rows<KS, FULL>(vr, vb, n0 + step * 32, N, lane, SV);
+    };
+    issue(0);
     sbf16x8 qf[KS];
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) qf[ks] = slot_frag(q + (int64_t)b * K * D, t16, K, D, ks, g);
-    // ---- phase 1: logits and softmax over slots, 16 rows per MFMA tile ----
+    sf32x4 U[2 * KS];
 #pragma unroll
-    for (int tb = 0; tb < 4; ++tb) {
-        const int n = n0 + tb * 16 + t16;
-        const bf16_t* row = kb + (int64_t)min(n, N - 1) * D;
-        sf32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        SPk8 kf[KS];
+    for (int ct = 0; ct < 2 * KS; ++ct) U[ct] = (sf32x4){0.f, 0.f, 0.f, 0.f};
+    float cs = 0.f;                                             // sum over this lane's rows of (attn + eps)[row][slot t16]
+    const bool slot_ok = t16 < K;
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) kf[ks].u = *reinterpret_cast<const uint4*>(row + ks * 32 + g * 8);
+    for (int step = 0; step < 2; ++step) {
+        SPk8 af;
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf[ks], kf[ks].v, acc, 0, 0, 0);
-        // acc[r] = logit[slot 4g + r][row t16 of this tile]
-        float m = -INFINITY;
+        for (int half = 0; half < 2; ++half) {
+            const int nt = n0 + step * 32 + half * 16;          // first row of the 16-row tile
+            if (half == 0) slot_wait<FULL, 3 * KS>(); else slot_wait<FULL, 2 * KS>();
+            slot_pin_frags<KS, FULL>(kf[half], SK);
+            sf32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { if (4 * g + r >= K) acc[r] = -INFINITY; m = fmaxf(m, acc[r]); }
-        m = fmaxf(m, __shfl_xor(m, 16, 64));
-        m = fmaxf(m, __shfl_xor(m, 32, 64));
-        float e[4], den = 0.f;
+            for (int ks = 0; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag(kf[half][ks]), qf[ks], acc, 0, 0, 0);
+            // acc[r] = logit[row nt + 4g + r][slot t16]: softmax over the 16 lanes of the DPP row
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { e[r] = __expf(acc[r] - m); den += e[r]; }
-        den += __shfl_xor(den, 16, 64);
-        den += __shfl_xor(den, 32, 64);
-        const float inv = 1.f / den;
-        const bool valid = n < N;
-        float4 ae;
-        float a[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            a[r] = e[r] * inv;
-            if (valid && 4 * g + r < K) attn[(int64_t)b * attn_bs + (int64_t)n * K + 4 * g + r] = f32_to_bf16(a[r]);
-        }
-        ae.x = valid && 4 * g + 0 < K ? a[0] + eps : 0.f;
-        ae.y = valid && 4 * g + 1 < K ? a[1] + eps : 0.f;
-        ae.z = valid && 4 * g + 2 < K ? a[2] + eps : 0.f;
-        ae.w = valid && 4 * g + 3 < K ? a[3] + eps : 0.f;
-        *reinterpret_cast<float4*>(&sA[w][tb * 16 + t16][4 * g]) = ae;
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // the table is wave-private
-    // ---- phase 2: U[k][c] += ae[row][k] * v[row][c]; lane = 4 channels ----
-    constexpr int NL = D / 4;                                // active lanes
-    float U[16][4], cs[16];
-#pragma unroll
-    for (int k = 0; k < 16; ++k) { cs[k] = 0.f; U[k][0] = U[k][1] = U[k][2] = U[k][3] = 0.f; }
-    const bool lact = lane < NL;
-    for (int t0 = 0; t0 < 64; t0 += 8) {
-        uint2 vr[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int n = min(n0 + t0 + u, N - 1);
-            vr[u] = lact ? *reinterpret_cast<const uint2*>(vb + (int64_t)n * D + lane * 4) : make_uint2(0, 0);
-        }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const float v0 = __uint_as_float(vr[u].x << 16), v1 = __uint_as_float(vr[u].x & 0xffff0000u);
-            const float v2 = __uint_as_float(vr[u].y << 16), v3 = __uint_as_float(vr[u].y & 0xffff0000u);
-            const float4* ar = reinterpret_cast<const float4*>(&sA[w][t0 + u][0]);
-            float aw[16];
-#pragma unroll
-            for (int c4 = 0; c4 < 4; ++c4) {
-                const float4 x = ar[c4];
-                aw[c4 * 4 + 0] = x.x; aw[c4 * 4 + 1] = x.y; aw[c4 * 4 + 2] = x.z; aw[c4 * 4 + 3] = x.w;
-            }
-#pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                cs[k] += aw[k];
-                U[k][0] = fmaf(aw[k], v0, U[k][0]); U[k][1] = fmaf(aw[k], v1, U[k][1]);
-                U[k][2] = fmaf(aw[k], v2, U[k][2]); U[k][3] = fmaf(aw[k], v3, U[k][3]);
+            for (int r = 0; r < 4; ++r) {
+                const float x = slot_ok ? acc[r] : -INFINITY;
+                const float m = row16_max(x);
+                const float e = __expf(x - m);
+                const float a = e / row16_sum(e);
+                const int n = nt + 4 * g + r;
+                const bool ok = slot_ok && n < N;
+                if (ok) attn[(int64_t)b * attn_bs + (int64_t)n * K + t16] = f32_to_bf16(a);
+                const float ae = ok ? a + eps : 0.f;
+                cs += ae;
+                af.e[4 * half + r] = f32_to_bf16(ae);
             }
         }
+        slot_wait<FULL, 0>();
+        slot_store_rows<KS, FULL>(img, vr, lane, SV);            // (LDS is in order per wave: the previous step's reads are done)
+        if (step == 0) issue(1);
+        slot_rank_mfma<KS>(U, img, af.v, lane);
     }
-    // ---- combine the 4 waves: partial[b][chunk][k][0..D-1], column sum at [..][D] ----
-#pragma unroll
-    for (int k = 0; k < 16; ++k) {
-        if (lact) { red[w][k][lane * 4 + 0] = U[k][0]; red[w][k][lane * 4 + 1] = U[k][1]; red[w][k][lane * 4 + 2] = U[k][2]; red[w][k][lane * 4 + 3] = U[k][3]; }
-        if (lane == 0) red[w][k][D] = cs[k];
-    }
-    __syncthreads();
-    float* out = partial + ((int64_t)b * nchunk + chunk) * K * (D + 1);
-    for (int i = threadIdx.x; i < K * (D + 1); i += 256) {
-        const int k = i / (D + 1), e = i - k * (D + 1);
-        out[i] = red[0][k][e] + red[1][k][e] + red[2][k][e] + red[3][k][e];
-    }
+    cs += __shfl_xor(cs, 16, 64);
+    cs += __shfl_xor(cs, 32, 64);
+    slot_combine<KS, 1>(smem, U, cs, partial + ((int64_t)b * nchunk + chunk) * K * (D + 1), K);
 }
 
-// DEFER: the d(k_t), d(v_t) part is left to slot_kv_grad_kernel (once per frame, for all iterations): this launch only
-// writes its rows of w = (attn + eps) / colsum and d(logits) to wl [B,N,32] bf16 (slots 0..15 | 16..31) and forms dq.
-template <int KS, bool DEFER>
+// Deferred backward of one corrector iteration: d(k_t), d(v_t) are left to slot_kv_grad_kernel (once per frame, for all
+// iterations); this launch writes its rows of w = (attn + eps) / colsum and d(logits) to wl [B,N,32] bf16 (slots
+// 0..15 | 16..31) and forms dq = sum_rows dlogits[row][slot] k[row][:] with the row-sum scheme above.
+template <int KS, bool FULL, bool HAS_DA>
+__global__ __launch_bounds__(256) void slot_bwd_defer_kernel(const bf16_t* __restrict__ kt, const bf16_t* __restrict__ vt,
+                                                             int64_t kv_bs, const bf16_t* __restrict__ attn, int64_t attn_bs,
+                                                             const float* __restrict__ colsum, const bf16_t* __restrict__ upd,
+                                                             const bf16_t* __restrict__ dupd, const bf16_t* __restrict__ dattn,
+                                                             bf16_t* __restrict__ wl, float* __restrict__ partial, int N, int K,
+                                                             float eps) {
+    using I = SlotImg<KS>;
+    constexpr int D = KS * 32;
+    constexpr int NA = HAS_DA ? 8 : 4;                          // scalar loads per tile (attn, d attn of the lane's 4 rows)
+    constexpr auto SK = std::make_integer_sequence<int, KS>{};
+    constexpr auto SV = std::make_integer_sequence<int, 2 * KS>{};
+    __shared__ __attribute__((aligned(16))) char smem[4 * I::BYTES];
+    __shared__ float sr[16], scs[16];
+    const int b = blockIdx.y, chunk = blockIdx.x, nchunk = gridDim.x;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int t16 = lane & 15, g = lane >> 4;
+    const int n0 = chunk * MROWS + w * 64;
+    const bf16_t* kb = kt + (int64_t)b * kv_bs;
+    const bf16_t* vb = vt + (int64_t)b * kv_bs;
+    const bf16_t* dub = dupd + (int64_t)b * K * D;
+    char* img = smem + w * I::BYTES;
+    su32x4 vf[2][KS], kr[2 * KS];
+    uint32_t at[2][4], da[2][4];
+    const int tk = min(t16, K - 1);
+    auto issue = [&](int step) __attribute__((always_inline)) {
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const int nt = n0 + step * 32 + half * 16;
+            slot_issue_frags<KS, FULL>(vf[half], vb + (int64_t)min(nt + t16, N - 1) * D + g * 8, SK);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int64_t o = (int64_t)b * attn_bs + (int64_t)min(nt + 4 * g + r, N - 1) * K + tk;
+                if constexpr (FULL) {
+                    sload2<0>(at[half][r], attn + o);
+                    if (HAS_DA) sload2<0>(da[half][r], dattn + o);
+                } else {
+                    at[half][r] = attn[o];
+                    if (HAS_DA) da[half][r] = dattn[o];
+                }
+            }
+        }
+        slot_issue_rows<KS, FULL>(kr, kb, n0 + step * 32, N, lane, SV);
+    };
+    issue(0);
+    // r[k] = dupd[k,:] . upd[k,:]  (one wave per slot, round robin), colsum.  (These loads go through the compiler, whose
+    // waits drain the step-0 loads above with them: one exposed round trip for the prologue and step 0 together.)
+    if (threadIdx.x < 16) { sr[threadIdx.x] = 0.f; scs[threadIdx.x] = 1.f; }
+    __syncthreads();
+    for (int k = w; k < K; k += 4) {
+        float p = 0.f;
+        for (int e = lane; e < D; e += 64) p += bf16_to_f32(dub[k * D + e]) * bf16_to_f32(upd[((int64_t)b * K + k) * D + e]);
+        p = wave_sum(p);
+        if (lane == 0) { sr[k] = p; scs[k] = colsum[b * K + k]; }
+    }
+    __syncthreads();
+    const float my_r = sr[t16], my_inv = 1.f / scs[t16];
+    sbf16x8 df[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) df[ks] = slot_frag(dub, t16, K, D, ks, g);
+    sf32x4 dQ[2 * KS];
+#pragma unroll
+    for (int ct = 0; ct < 2 * KS; ++ct) dQ[ct] = (sf32x4){0.f, 0.f, 0.f, 0.f};
+    const bool slot_ok = t16 < K;
+#pragma unroll
+    for (int step = 0; step < 2; ++step) {
+        SPk8 lf;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const int nt = n0 + step * 32 + half * 16;
+            if (half == 0) slot_wait<FULL, 3 * KS + NA>(); else slot_wait<FULL, 2 * KS>();
+            slot_pin_frags<KS, FULL>(vf[half], SK);
+            if constexpr (FULL) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { spin(at[half][r]); if (HAS_DA) spin(da[half][r]); }
+            }
+            sf32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag(vf[half][ks]), df[ks], acc, 0, 0, 0);
+            // acc[r] = dupd[slot t16] . v[row nt + 4g + r]: softmax backward over the 16 lanes of the DPP row
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int n = nt + 4 * g + r;
+                const bool ok = slot_ok && n < N;
+                float av = 0.f, dav = 0.f;
+                if (ok) {
+                    av = __uint_as_float(at[half][r] << 16);
+                    dav = (acc[r] - my_r) * my_inv;
+                    if (HAS_DA) dav += __uint_as_float(da[half][r] << 16);
+                }
+                const float dot = row16_sum(av * dav);
+                const bf16_t wv = f32_to_bf16(ok ? (av + eps) * my_inv : 0.f);
+                const bf16_t lv = f32_to_bf16(ok ? av * (dav - dot) : 0.f);
+                if (n < N) {
+                    bf16_t* o = wl + ((int64_t)b * N + n) * 32 + t16;
+                    o[0] = wv;
+                    o[16] = lv;
+                }
+                lf.e[4 * half + r] = lv;
+            }
+        }
+        slot_wait<FULL, 0>();
+        slot_store_rows<KS, FULL>(img, kr, lane, SV);
+        if (step == 0) issue(1);
+        slot_rank_mfma<KS>(dQ, img, lf.v, lane);
+    }
+    slot_combine<KS, 0>(smem, dQ, 0.f, partial + ((int64_t)b * nchunk + chunk) * K * D, K);
+}
+
+// Non-deferred backward (more than 4 iterations per frame, or the deferral switched off): d(k_t), d(v_t) are written (or
+// accumulated) by this launch, dq included; the rank-1 updates of this variant stay on the VALU.
+template <int KS>
 __global__ __launch_bounds__(256) void slot_bwd_mfma_kernel(const bf16_t* __restrict__ kt, const bf16_t* __restrict__ vt,
                                                             int64_t kv_bs, const bf16_t* __restrict__ q,
                                                             const bf16_t* __restrict__ attn, int64_t attn_bs,
                                                             const float* __restrict__ colsum, const bf16_t* __restrict__ upd,
                                                             const bf16_t* __restrict__ dupd, const bf16_t* __restrict__ dattn,
                                                             bf16_t* __restrict__ dkt, bf16_t* __restrict__ dvt, int accumulate,
-                                                            bf16_t* __restrict__ wl, float* __restrict__ partial, int N, int K,
+                                                            float* __restrict__ partial, int N, int K,
                                                             float eps) {
     constexpr int D = KS * 32;
-    __shared__ __attribute__((aligned(16))) float sW[DEFER ? 1 : 4][DEFER ? 1 : 64][16];   // (attn + eps) / colsum per (row, slot)
+    __shared__ __attribute__((aligned(16))) float sW[4][64][16];   // (attn + eps) / colsum per (row, slot)
     __shared__ __attribute__((aligned(16))) float sL[4][64][16];          // d logits per (row, slot)
     __shared__ float sr[16], scs[16];
     __shared__ float red[4][16][D];
@@ -450,20 +673,7 @@ __global__ __launch_bounds__(256) void slot_bwd_mfma_kernel(const bf16_t* __rest
         }
         wg.x = wv[0]; wg.y = wv[1]; wg.z = wv[2]; wg.w = wv[3];
         dl.x = lv[0]; dl.y = lv[1]; dl.z = lv[2]; dl.w = lv[3];
-        if (DEFER) {
-            if (valid) {
-                bf16_t* o = wl + ((int64_t)b * N + n) * 32 + 4 * g;
-                uint2 pw, pl;
-                pw.x = (uint32_t)f32_to_bf16(wv[0]) | ((uint32_t)f32_to_bf16(wv[1]) << 16);
-                pw.y = (uint32_t)f32_to_bf16(wv[2]) | ((uint32_t)f32_to_bf16(wv[3]) << 16);
-                pl.x = (uint32_t)f32_to_bf16(lv[0]) | ((uint32_t)f32_to_bf16(lv[1]) << 16);
-                pl.y = (uint32_t)f32_to_bf16(lv[2]) | ((uint32_t)f32_to_bf16(lv[3]) << 16);
-                *reinterpret_cast<uint2*>(o) = pw;
-                *reinterpret_cast<uint2*>(o + 16) = pl;
-            }
-        } else {
-            *reinterpret_cast<float4*>(&sW[w][tb * 16 + t16][4 * g]) = wg;
-        }
+        *reinterpret_cast<float4*>(&sW[w][tb * 16 + t16][4 * g]) = wg;
         *reinterpret_cast<float4*>(&sL[w][tb * 16 + t16][4 * g]) = dl;
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -476,8 +686,8 @@ __global__ __launch_bounds__(256) void slot_bwd_mfma_kernel(const bf16_t* __rest
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             const bool ok = lact && k < K;
-            sq[k][c] = ok && !DEFER ? bf16_to_f32(qb[k * D + lane * 4 + c]) : 0.f;
-            sd[k][c] = ok && !DEFER ? bf16_to_f32(dub[k * D + lane * 4 + c]) : 0.f;
+            sq[k][c] = ok ? bf16_to_f32(qb[k * D + lane * 4 + c]) : 0.f;
+            sd[k][c] = ok ? bf16_to_f32(dub[k * D + lane * 4 + c]) : 0.f;
             dQ[k][c] = 0.f;
         }
     }
@@ -493,29 +703,25 @@ __global__ __launch_bounds__(256) void slot_bwd_mfma_kernel(const bf16_t* __rest
             const int n = n0 + t0 + u;
             const float k0 = __uint_as_float(kr[u].x << 16), k1 = __uint_as_float(kr[u].x & 0xffff0000u);
             const float k2 = __uint_as_float(kr[u].y << 16), k3 = __uint_as_float(kr[u].y & 0xffff0000u);
-            const float4* wr = reinterpret_cast<const float4*>(&sW[DEFER ? 0 : w][DEFER ? 0 : t0 + u][0]);
+            const float4* wr = reinterpret_cast<const float4*>(&sW[w][t0 + u][0]);
             const float4* lr = reinterpret_cast<const float4*>(&sL[w][t0 + u][0]);
             float ww[16], ll[16];
 #pragma unroll
             for (int c4 = 0; c4 < 4; ++c4) {
                 const float4 y = lr[c4];
                 ll[c4 * 4 + 0] = y.x; ll[c4 * 4 + 1] = y.y; ll[c4 * 4 + 2] = y.z; ll[c4 * 4 + 3] = y.w;
-                if (!DEFER) {
-                    const float4 x = wr[c4];
-                    ww[c4 * 4 + 0] = x.x; ww[c4 * 4 + 1] = x.y; ww[c4 * 4 + 2] = x.z; ww[c4 * 4 + 3] = x.w;
-                }
+                const float4 x = wr[c4];
+                ww[c4 * 4 + 0] = x.x; ww[c4 * 4 + 1] = x.y; ww[c4 * 4 + 2] = x.z; ww[c4 * 4 + 3] = x.w;
             }
             float dv[4] = {0.f, 0.f, 0.f, 0.f}, dk[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int k = 0; k < 16; ++k) {
-                if (!DEFER) {
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) { dv[c] = fmaf(ww[k], sd[k][c], dv[c]); dk[c] = fmaf(ll[k], sq[k][c], dk[c]); }
-                }
+                for (int c = 0; c < 4; ++c) { dv[c] = fmaf(ww[k], sd[k][c], dv[c]); dk[c] = fmaf(ll[k], sq[k][c], dk[c]); }
                 dQ[k][0] = fmaf(ll[k], k0, dQ[k][0]); dQ[k][1] = fmaf(ll[k], k1, dQ[k][1]);
                 dQ[k][2] = fmaf(ll[k], k2, dQ[k][2]); dQ[k][3] = fmaf(ll[k], k3, dQ[k][3]);
             }
-            if (!DEFER && lact && n < N) {
+            if (lact && n < N) {
                 const int64_t ro = (int64_t)b * kv_bs + (int64_t)n * D + lane * 4;
                 if (accumulate) {
                     const uint2 ok = *reinterpret_cast<const uint2*>(dkt + ro), ov = *reinterpret_cast<const uint2*>(dvt + ro);
@@ -669,9 +875,11 @@ extern "C" int focus_slot_attn_fwd(const void* k_t, const void* v_t, int64_t kv_
     hipStream_t s = (hipStream_t)stream;
     if (slot_mfma_ok(k_t, v_t, q, kv_bs, K, D, dtype)) {
         dim3 gm(nchunks_mfma(N), B);
-#define SFM(KS) hipLaunchKernelGGL((slot_fwd_mfma_kernel<KS>), gm, dim3(256), 0, s, (const bf16_t*)k_t, (const bf16_t*)v_t, kv_bs, (const bf16_t*)q, (bf16_t*)attn_vis, attn_bs, (float*)partial, N, K, eps)
+#define SFM_(KS, FULL) hipLaunchKernelGGL((slot_fwd_mfma_kernel<KS, FULL>), gm, dim3(256), 0, s, (const bf16_t*)k_t, (const bf16_t*)v_t, kv_bs, (const bf16_t*)q, (bf16_t*)attn_vis, attn_bs, (float*)partial, N, K, eps)
+#define SFM(KS) do { if (N % MROWS == 0) SFM_(KS, true); else SFM_(KS, false); } while (0)
         if (D == 64) SFM(2); else if (D == 128) SFM(4); else if (D == 192) SFM(6); else SFM(8);
 #undef SFM
+#undef SFM_
         FOCUS_CHECK_LAUNCH();
         hipLaunchKernelGGL((slot_fwd_finish<bf16_t>), dim3(K, B), dim3(256), 0, s, (const float*)partial, (bf16_t*)upd, colsum,
                            nchunks_mfma(N), K, D);
@@ -719,11 +927,15 @@ extern "C" int focus_slot_attn_bwd(const void* k_t, const void* v_t, int64_t kv_
     if (wl && !(slot_mfma_ok(k_t, v_t, q, kv_bs, K, D, dtype) && focus_aligned(wl, 16))) return FOCUS_ERR_ALIGN;
     if (slot_mfma_ok(k_t, v_t, q, kv_bs, K, D, dtype) && (wl || (focus_aligned(dk_t, 8) && focus_aligned(dv_t, 8)))) {
         dim3 gm(nchunks_mfma(N), B);
+#define SBD(KS, FULL, DA) hipLaunchKernelGGL((slot_bwd_defer_kernel<KS, FULL, DA>), gm, dim3(256), 0, s, (const bf16_t*)k_t, (const bf16_t*)v_t, kv_bs, (const bf16_t*)attn_vis, attn_bs, colsum, (const bf16_t*)upd, (const bf16_t*)dupd, (const bf16_t*)dattn_vis, (bf16_t*)wl, (float*)partial, N, K, eps)
 #define SBM(KS) do { \
-        if (wl) hipLaunchKernelGGL((slot_bwd_mfma_kernel<KS, true>), gm, dim3(256), 0, s, (const bf16_t*)k_t, (const bf16_t*)v_t, kv_bs, (const bf16_t*)q, (const bf16_t*)attn_vis, attn_bs, colsum, (const bf16_t*)upd, (const bf16_t*)dupd, (const bf16_t*)dattn_vis, (bf16_t*)nullptr, (bf16_t*)nullptr, 0, (bf16_t*)wl, (float*)partial, N, K, eps); \
-        else hipLaunchKernelGGL((slot_bwd_mfma_kernel<KS, false>), gm, dim3(256), 0, s, (const bf16_t*)k_t, (const bf16_t*)v_t, kv_bs, (const bf16_t*)q, (const bf16_t*)attn_vis, attn_bs, colsum, (const bf16_t*)upd, (const bf16_t*)dupd, (const bf16_t*)dattn_vis, (bf16_t*)dk_t, (bf16_t*)dv_t, accumulate, (bf16_t*)nullptr, (float*)partial, N, K, eps); } while (0)
+        if (wl) { \
+            if (N % MROWS == 0) { if (dattn_vis) SBD(KS, true, true); else SBD(KS, true, false); } \
+            else { if (dattn_vis) SBD(KS, false, true); else SBD(KS, false, false); } } \
+        else hipLaunchKernelGGL((slot_bwd_mfma_kernel<KS>), gm, dim3(256), 0, s, (const bf16_t*)k_t, (const bf16_t*)v_t, kv_bs, (const bf16_t*)q, (const bf16_t*)attn_vis, attn_bs, colsum, (const bf16_t*)upd, (const bf16_t*)dupd, (const bf16_t*)dattn_vis, (bf16_t*)dk_t, (bf16_t*)dv_t, accumulate, (float*)partial, N, K, eps); } while (0)
         if (D == 64) SBM(2); else if (D == 128) SBM(4); else if (D == 192) SBM(6); else SBM(8);
 #undef SBM
+#undef SBD
         FOCUS_CHECK_LAUNCH();
         hipLaunchKernelGGL((slot_bwd_finish<bf16_t>), dim3(K, B), dim3(256), 0, s, (const float*)partial, (bf16_t*)dq,
                            nchunks_mfma(N), K, D);

@@ -1086,11 +1086,12 @@ extern "C" int focus_traj_time2_bwd(const void* q2, const void* xt, const void* 
     static const bool staged_on = !(getenv("FOCUS_T2_LDS") && atoi(getenv("FOCUS_T2_LDS")) == 0);
     const size_t lds_staged = time2_lds_bwd() + (size_t)2 * TQ * q_pitch(heads);
     // (13..16 heads with F = 4 or 16: the staged variant would spill, and a spilled ring register is stored before its
-    // inline-asm load lands -> those shapes keep the direct kernel)
+    // inline-asm load lands -> those shapes keep the direct kernel and the staged one is not even instantiated: the
+    // build's lint of hand-issued loads, focus_amd/build.py lint_hand_loads, refuses such a kernel)
     const bool staged = staged_on && lds_staged <= 160 * 1024 && !(upw == 4 && F != 8);
     const size_t lds = staged ? lds_staged : time2_lds_bwd();
 #define TB(FT, UPW) do { \
-        if (staged) { \
+        if constexpr (!((UPW) == 4 && (FT) != 8)) if (staged) { \
             static bool once_s = (hipFuncSetAttribute((const void*)time2_dx_lds_kernel<FT, UPW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess); \
             (void)once_s; \
             hipLaunchKernelGGL((time2_dx_lds_kernel<FT, UPW>), dim3(256), dim3(512), lds, s, (const bf16_t*)q2, (const bf16_t*)wkT, ldw, attn2, (const bf16_t*)dl, (const bf16_t*)dout, dout_bstride, (bf16_t*)dxt, (int)rows, S, heads, spread_mode()); \
