@@ -1,6 +1,8 @@
 // layernorm.hip -- LayerNorm forward/backward, one wave (64 lanes) per row, 4-wide vector access.
 // HBM-bound: fwd reads x once and writes y once (2*D*esize B/row); bwd reads dy,x once, writes dx once.
 #include "focus_common.h"
+#include <algorithm>
+#include <cstdlib>
 
 namespace {
 
@@ -166,6 +168,213 @@ __global__ __launch_bounds__(256) void ln_bwd_finish(const float* __restrict__ p
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// bf16, D % 8 == 0, D <= 1024: 16 bytes per lane and a SUB-WAVE per row.  The kernels above give a row a whole wave and
+// 8 bytes per lane: at D = 192 (the STEVE tokens, 131072 rows per frame) 48 lanes issue 8-byte loads -- 46 / 80 us per
+// call forward / backward against 12.5 / 19 us of HBM time.  Here a row takes LPR = 8, 16, 32 or 64 lanes (the smallest
+// with LPR * 8 * NV >= D), a wave holds 64 / LPR rows per pass and keeps UN passes in flight; the row reductions are
+// log2(LPR) xor-shuffle steps.  D = 768 (ORViT tokens) runs as LPR = 64, NV = 2.
+// ------------------------------------------------------------------------------------------------
+template <int LPR>
+__device__ __forceinline__ float sub_sum(float v) {
+#pragma unroll
+    for (int o = LPR / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ void unpack8(const uint4& u, float (&f)[8]) {
+    f[0] = __uint_as_float(u.x << 16); f[1] = __uint_as_float(u.x & 0xffff0000u);
+    f[2] = __uint_as_float(u.y << 16); f[3] = __uint_as_float(u.y & 0xffff0000u);
+    f[4] = __uint_as_float(u.z << 16); f[5] = __uint_as_float(u.z & 0xffff0000u);
+    f[6] = __uint_as_float(u.w << 16); f[7] = __uint_as_float(u.w & 0xffff0000u);
+}
+__device__ __forceinline__ uint4 pack8(const float (&f)[8]) {
+    uint4 o;
+    o.x = (uint32_t)f32_to_bf16(f[0]) | ((uint32_t)f32_to_bf16(f[1]) << 16);
+    o.y = (uint32_t)f32_to_bf16(f[2]) | ((uint32_t)f32_to_bf16(f[3]) << 16);
+    o.z = (uint32_t)f32_to_bf16(f[4]) | ((uint32_t)f32_to_bf16(f[5]) << 16);
+    o.w = (uint32_t)f32_to_bf16(f[6]) | ((uint32_t)f32_to_bf16(f[7]) << 16);
+    return o;
+}
+__device__ __forceinline__ void load8f(const float* p, float (&f)[8]) {
+    const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+    f[0] = a.x; f[1] = a.y; f[2] = a.z; f[3] = a.w; f[4] = b.x; f[5] = b.y; f[6] = b.z; f[7] = b.w;
+}
+
+template <int LPR, int NV>
+__global__ __launch_bounds__(256) void ln_fwd_v16_kernel(const bf16_t* __restrict__ x, const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta, bf16_t* __restrict__ y,
+                                                         float* __restrict__ mean, float* __restrict__ rstd, int rows, int D,
+                                                         float eps, int rpb, int64_t xbs) {
+    constexpr int RPW = 64 / LPR, UN = NV == 1 ? 4 : 2;
+    const int lane = threadIdx.x & 63, sub = lane / LPR, sl = lane % LPR;
+    float g[NV][8], bt[NV][8];
+    bool act[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = (i * LPR + sl) * 8;
+        act[i] = c < D;
+        if (act[i]) { load8f(gamma + c, g[i]); load8f(beta + c, bt[i]); }
+    }
+    const int wave = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
+    const float invD = 1.f / (float)D;
+    for (int r0 = wave * (RPW * UN); r0 < rows; r0 += nwaves * (RPW * UN)) {
+        uint4 v[UN][NV];
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const int row = min(r0 + u * RPW + sub, rows - 1);
+            const bf16_t* xr = x + (int64_t)(row / rpb) * xbs + (int64_t)(row % rpb) * D;
+#pragma unroll
+            for (int i = 0; i < NV; ++i)
+                v[u][i] = act[i] ? *reinterpret_cast<const uint4*>(xr + (i * LPR + sl) * 8) : make_uint4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const int row = r0 + u * RPW + sub;
+            float f[NV][8], s = 0.f;
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                unpack8(v[u][i], f[i]);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) s += f[i][e];
+            }
+            const float mu = sub_sum<LPR>(s) * invD;
+            float q = 0.f;
+#pragma unroll
+            for (int i = 0; i < NV; ++i)
+                if (act[i]) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { f[i][e] -= mu; q += f[i][e] * f[i][e]; }
+                }
+            const float rs = rsqrtf(sub_sum<LPR>(q) * invD + eps);
+            if (row < rows) {
+                if (sl == 0) { mean[row] = mu; rstd[row] = rs; }
+                bf16_t* yr = y + (int64_t)row * D;
+#pragma unroll
+                for (int i = 0; i < NV; ++i)
+                    if (act[i]) {
+                        float o[8];
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) o[e] = f[i][e] * rs * g[i][e] + bt[i][e];
+                        *reinterpret_cast<uint4*>(yr + (i * LPR + sl) * 8) = pack8(o);
+                    }
+            }
+        }
+    }
+}
+
+// Backward: per-lane partial dgamma/dbeta over every row the lane's sub-wave visits, combined across the workgroup's
+// 4 * (64 / LPR) sub-waves through LDS into partial[0|1][blk][D] (ln_bwd_finish sums the blocks).
+template <int LPR, int NV>
+__global__ __launch_bounds__(256) void ln_bwd_v16_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x,
+                                                         const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                         const float* __restrict__ rstd, const bf16_t* __restrict__ dres,
+                                                         bf16_t* __restrict__ dx, float* __restrict__ partial, int rows, int D,
+                                                         int rpb, int64_t xbs) {
+    constexpr int RPW = 64 / LPR, UN = NV == 1 ? 4 : 2, NSUB = 4 * RPW;
+    extern __shared__ float red[];                                // [2][NSUB][D]
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, sub = lane / LPR, sl = lane % LPR;
+    float g[NV][8], dg[NV][8], db[NV][8];
+    bool act[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = (i * LPR + sl) * 8;
+        act[i] = c < D;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { g[i][e] = 0.f; dg[i][e] = 0.f; db[i][e] = 0.f; }
+        if (act[i]) load8f(gamma + c, g[i]);
+    }
+    const int wave = blockIdx.x * 4 + w, nwaves = gridDim.x * 4;
+    const float invD = 1.f / (float)D;
+    for (int r0 = wave * (RPW * UN); r0 < rows; r0 += nwaves * (RPW * UN)) {
+        uint4 xv[UN][NV], dv[UN][NV];
+        float mu[UN], rs[UN];
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const int row = min(r0 + u * RPW + sub, rows - 1);
+            const bf16_t* xr = x + (int64_t)(row / rpb) * xbs + (int64_t)(row % rpb) * D;
+            const bf16_t* dr = dy + (int64_t)row * D;
+            mu[u] = mean[row]; rs[u] = rstd[row];
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const int c = (i * LPR + sl) * 8;
+                xv[u][i] = act[i] ? *reinterpret_cast<const uint4*>(xr + c) : make_uint4(0, 0, 0, 0);
+                dv[u][i] = act[i] ? *reinterpret_cast<const uint4*>(dr + c) : make_uint4(0, 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const int row = r0 + u * RPW + sub;
+            const bool valid = row < rows;
+            float xh[NV][8], gd[NV][8], s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                float d[8];
+                unpack8(xv[u][i], xh[i]);
+                unpack8(dv[u][i], d);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    xh[i][e] = act[i] ? (xh[i][e] - mu[u]) * rs[u] : 0.f;
+                    gd[i][e] = d[e] * g[i][e];
+                    s1 += gd[i][e];
+                    s2 += gd[i][e] * xh[i][e];
+                    if (valid) { dg[i][e] += d[e] * xh[i][e]; db[i][e] += d[e]; }
+                }
+            }
+            const float m1 = sub_sum<LPR>(s1) * invD, m2 = sub_sum<LPR>(s2) * invD;
+            if (valid) {
+                bf16_t* dxr = dx + (int64_t)(row / rpb) * xbs + (int64_t)(row % rpb) * D;
+#pragma unroll
+                for (int i = 0; i < NV; ++i)
+                    if (act[i]) {
+                        const int c = (i * LPR + sl) * 8;
+                        float o[8];
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) o[e] = rs[u] * (gd[i][e] - m1 - xh[i][e] * m2);
+                        if (dres) {          // gradient arriving on the residual path around this LayerNorm
+                            float r[8];
+                            unpack8(*reinterpret_cast<const uint4*>(dres + (int64_t)row * D + c), r);
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) o[e] += r[e];
+                        }
+                        *reinterpret_cast<uint4*>(dxr + c) = pack8(o);
+                    }
+            }
+        }
+    }
+    float* rg = red + (size_t)(w * RPW + sub) * D;
+    float* rb = red + (size_t)(NSUB + w * RPW + sub) * D;
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+        if (act[i]) {
+            const int c = (i * LPR + sl) * 8;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { rg[c + e] = dg[i][e]; rb[c + e] = db[i][e]; }
+        }
+    __syncthreads();
+    for (int c = threadIdx.x; c < 2 * D; c += 256) {
+        const int which = c >= D, col = which ? c - D : c;
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < NSUB; ++k) t += red[(size_t)(which * NSUB + k) * D + col];
+        partial[(int64_t)(which * gridDim.x + blockIdx.x) * D + col] = t;
+    }
+}
+
+// (rows < 4096 -- the per-slot LayerNorms of STEVE, 352 rows -- stay with the wave-per-row kernels: a launch that small
+// is a fixed few microseconds either way and the sub-wave kernels' wider LDS combine measured 1 us slower there)
+inline bool ln_v16_ok(const void* a, const void* b, const void* c, const void* d, int rows, int D, int64_t xbs, int dtype) {
+    static const bool enabled = !(getenv("FOCUS_LN_V16") && atoi(getenv("FOCUS_LN_V16")) == 0);
+    return enabled && rows >= 4096 && dtype == FOCUS_BF16 && (D & 7) == 0 && D <= 1024 && (xbs & 7) == 0 && focus_aligned(a, 16) &&
+           focus_aligned(b, 16) && (!c || focus_aligned(c, 16)) && (!d || focus_aligned(d, 16));
+}
+
+#define LN_V16_DISPATCH(CALL)                                        \
+    do {                                                             \
+        if (D <= 64) CALL(8, 1); else if (D <= 128) CALL(16, 1);     \
+        else if (D <= 256) CALL(32, 1); else if (D <= 512) CALL(64, 1); \
+        else CALL(64, 2);                                            \
+    } while (0)
+
 template <typename T>
 int ln_fwd_launch(const void* x, const float* g, const float* b, void* y, float* mean, float* rstd, int rows, int D,
                   float eps, int rpb, int64_t xbs, hipStream_t s) {
@@ -202,6 +411,16 @@ static int ln_fwd_any(const void* x, int rpb, int64_t xbs, const float* gamma, c
     if (!focus_aligned(x, 8) || !focus_aligned(y, 8) || !focus_aligned(gamma, 16) || !focus_aligned(beta, 16))
         return FOCUS_ERR_ALIGN;
     hipStream_t s = (hipStream_t)stream;
+    if (ln_v16_ok(x, y, gamma, beta, rows, D, xbs, dtype)) {
+#define LNF(LPR, NV) do { \
+        constexpr int per_blk = 4 * (64 / LPR) * (NV == 1 ? 4 : 2); \
+        const int grid = (int)std::min<int64_t>(((int64_t)rows + per_blk - 1) / per_blk, 4096); \
+        hipLaunchKernelGGL((ln_fwd_v16_kernel<LPR, NV>), dim3(grid), dim3(256), 0, s, (const bf16_t*)x, gamma, beta, (bf16_t*)y, mean, rstd, rows, D, eps, rpb, xbs); } while (0)
+        LN_V16_DISPATCH(LNF);
+#undef LNF
+        FOCUS_CHECK_LAUNCH();
+        return FOCUS_OK;
+    }
     return dtype == FOCUS_BF16 ? ln_fwd_launch<bf16_t>(x, gamma, beta, y, mean, rstd, rows, D, eps, rpb, xbs, s)
                                : ln_fwd_launch<float>(x, gamma, beta, y, mean, rstd, rows, D, eps, rpb, xbs, s);
 }
@@ -229,6 +448,17 @@ static int ln_bwd_any(const void* dy, const void* x, int rpb, int64_t xbs, const
     if (D <= 0 || (D & 3) || D > MAXV * 256 || rows <= 0 || rpb <= 0 || (xbs & 3)) return FOCUS_ERR_SHAPE;
     hipStream_t s = (hipStream_t)stream;
     const int nblk = focus_layernorm_bwd_blocks(rows);
+    if (ln_v16_ok(dy, x, dx, dres, rows, D, xbs, dtype) && focus_aligned(gamma, 16)) {
+#define LNB(LPR, NV) do { \
+        const size_t lds = (size_t)2 * 4 * (64 / LPR) * D * sizeof(float); \
+        hipLaunchKernelGGL((ln_bwd_v16_kernel<LPR, NV>), dim3(nblk), dim3(256), lds, s, (const bf16_t*)dy, (const bf16_t*)x, gamma, mean, rstd, (const bf16_t*)dres, (bf16_t*)dx, partial, rows, D, rpb, xbs); } while (0)
+        LN_V16_DISPATCH(LNB);
+#undef LNB
+        FOCUS_CHECK_LAUNCH();
+        hipLaunchKernelGGL(ln_bwd_finish, dim3((D + 15) / 16, 2), dim3(256), 0, s, partial, dgamma, dbeta, nblk, D);
+        FOCUS_CHECK_LAUNCH();
+        return FOCUS_OK;
+    }
     int rc = dtype == FOCUS_BF16 ? ln_bwd_launch<bf16_t>(dy, x, gamma, mean, rstd, dres, dx, partial, rows, D, nblk, rpb, xbs, s)
                                  : ln_bwd_launch<float>(dy, x, gamma, mean, rstd, dres, dx, partial, rows, D, nblk, rpb, xbs, s);
     if (rc) return rc;

@@ -334,6 +334,9 @@ template <int OFF>
 __device__ __forceinline__ void sload2(uint32_t& dst, const void* p) {
     asm volatile("global_load_ushort %0, %1, off offset:%2" : "=v"(dst) : "v"(p), "n"(OFF) : "memory");
 }
+__device__ __forceinline__ void sload4(uint32_t& dst, const void* p) {
+    asm volatile("global_load_dword %0, %1, off" : "=v"(dst) : "v"(p) : "memory");
+}
 template <int N> __device__ __forceinline__ void swait() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 __device__ __forceinline__ void spin(su32x4& v) { asm volatile("" : "+v"(v)); }
 __device__ __forceinline__ void spin(uint32_t& v) { asm volatile("" : "+v"(v)); }
@@ -436,17 +439,24 @@ __global__ __launch_bounds__(256) void slot_fwd_mfma_kernel(const bf16_t* __rest
     const bf16_t* kb = kt + (int64_t)b * kv_bs;
     const bf16_t* vb = vt + (int64_t)b * kv_bs;
     char* img = smem + w * I::BYTES;
-    su32x4 kf[2][KS], vr[2 * KS];
-    auto issue = [&](int step) __attribute__((always_inline)) {
+    // DEEP (D <= 192): the NEXT step's k fragments are requested before this step's phase 1 starts (48 more registers in
+    // flight), its v rows as soon as this step's are in LDS: HBM never idles behind the softmax arithmetic.
+    constexpr bool DEEP = FULL && KS <= 6;
+    su32x4 kf[2][2][KS], vr[2 * KS];                            // kf[step parity][tile][k step]
+    auto issue_k = [&](int step) __attribute__((always_inline)) {
 #pragma unroll
         for (int half = 0; half < 2; ++half)
-            slot_issue_frags<KS, FULL>(kf[half], kb + (int64_t)min(n0 + step * 32 + half * 16 + t16, N - 1) * D + g * 8, SK);
-        slot_issue_rows<KS, FULL>(vr, vb, n0 + step * 32, N, lane, SV);
+            slot_issue_frags<KS, FULL>(kf[DEEP ? step : 0][half], kb + (int64_t)min(n0 + step * 32 + half * 16 + t16, N - 1) * D + g * 8, SK);
     };
-    issue(0);
+    auto issue_v = [&](int step) __attribute__((always_inline)) { slot_issue_rows<KS, FULL>(vr, vb, n0 + step * 32, N, lane, SV); };
+    // the slot matrix first: it is older than everything below, so it is back when the first tile's wait returns (a
+    // compiler-issued load here would make the compiler wait for ITS count, i.e. drain every prefetch)
+    su32x4 qu[KS];
+    slot_issue_frags<KS, FULL>(qu, q + ((int64_t)b * K + min(t16, K - 1)) * D + g * 8, SK);
+    issue_k(0);
+    issue_v(0);
+    if (DEEP) issue_k(1);
     sbf16x8 qf[KS];
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) qf[ks] = slot_frag(q + (int64_t)b * K * D, t16, K, D, ks, g);
     sf32x4 U[2 * KS];
 #pragma unroll
     for (int ct = 0; ct < 2 * KS; ++ct) U[ct] = (sf32x4){0.f, 0.f, 0.f, 0.f};
@@ -454,22 +464,32 @@ __global__ __launch_bounds__(256) void slot_fwd_mfma_kernel(const bf16_t* __rest
     const bool slot_ok = t16 < K;
 #pragma unroll
     for (int step = 0; step < 2; ++step) {
+        // hand-issued loads younger than the one awaited (see the note on counting above)
+        constexpr int AFTER_V = DEEP ? 2 * KS : 0;               // step 0 only: the next step's k fragments
+        const int later = (DEEP && step == 0) ? AFTER_V : 0;
         SPk8 af;
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
             const int nt = n0 + step * 32 + half * 16;          // first row of the 16-row tile
-            if (half == 0) slot_wait<FULL, 3 * KS>(); else slot_wait<FULL, 2 * KS>();
-            slot_pin_frags<KS, FULL>(kf[half], SK);
+            if (half == 0) { if (later) slot_wait<FULL, 3 * KS + AFTER_V>(); else slot_wait<FULL, 3 * KS>(); }
+            else { if (later) slot_wait<FULL, 2 * KS + AFTER_V>(); else slot_wait<FULL, 2 * KS>(); }
+            su32x4 (&kt16)[KS] = kf[DEEP ? step : 0][half];
+            slot_pin_frags<KS, FULL>(kt16, SK);
+            if (step == 0 && half == 0) {
+                slot_pin_frags<KS, FULL>(qu, SK);
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) qf[ks] = as_frag(t16 < K ? qu[ks] : (su32x4){0u, 0u, 0u, 0u});
+            }
             sf32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag(kf[half][ks]), qf[ks], acc, 0, 0, 0);
+            for (int ks = 0; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag(kt16[ks]), qf[ks], acc, 0, 0, 0);
             // acc[r] = logit[row nt + 4g + r][slot t16]: softmax over the 16 lanes of the DPP row
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float x = slot_ok ? acc[r] : -INFINITY;
                 const float m = row16_max(x);
                 const float e = __expf(x - m);
-                const float a = e / row16_sum(e);
+                const float a = e * __builtin_amdgcn_rcpf(row16_sum(e));
                 const int n = nt + 4 * g + r;
                 const bool ok = slot_ok && n < N;
                 if (ok) attn[(int64_t)b * attn_bs + (int64_t)n * K + t16] = f32_to_bf16(a);
@@ -478,9 +498,12 @@ __global__ __launch_bounds__(256) void slot_fwd_mfma_kernel(const bf16_t* __rest
                 af.e[4 * half + r] = f32_to_bf16(ae);
             }
         }
-        slot_wait<FULL, 0>();
+        if (later) slot_wait<FULL, AFTER_V>(); else slot_wait<FULL, 0>();
         slot_store_rows<KS, FULL>(img, vr, lane, SV);            // (LDS is in order per wave: the previous step's reads are done)
-        if (step == 0) issue(1);
+        if (step == 0) {
+            if (!DEEP) issue_k(1);
+            issue_v(1);
+        }
         slot_rank_mfma<KS>(U, img, af.v, lane);
     }
     cs += __shfl_xor(cs, 16, 64);
@@ -504,18 +527,23 @@ __global__ __launch_bounds__(256) void slot_bwd_defer_kernel(const bf16_t* __res
     constexpr auto SK = std::make_integer_sequence<int, KS>{};
     constexpr auto SV = std::make_integer_sequence<int, 2 * KS>{};
     __shared__ __attribute__((aligned(16))) char smem[4 * I::BYTES];
-    __shared__ float sr[16], scs[16];
     const int b = blockIdx.y, chunk = blockIdx.x, nchunk = gridDim.x;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int t16 = lane & 15, g = lane >> 4;
     const int n0 = chunk * MROWS + w * 64;
     const bf16_t* kb = kt + (int64_t)b * kv_bs;
     const bf16_t* vb = vt + (int64_t)b * kv_bs;
-    const bf16_t* dub = dupd + (int64_t)b * K * D;
     char* img = smem + w * I::BYTES;
+    const int tk = min(t16, K - 1);
+    // The slot-side operands first (older than every row load: back when the first tile's wait returns; through the
+    // compiler they would drain the prefetches): d(updates) and updates as fragments of slot t16, 1 / colsum[t16].
+    su32x4 du[KS], uu[KS];
+    uint32_t csu;
+    slot_issue_frags<KS, FULL>(du, dupd + ((int64_t)b * K + tk) * D + g * 8, SK);
+    slot_issue_frags<KS, FULL>(uu, upd + ((int64_t)b * K + tk) * D + g * 8, SK);
+    if constexpr (FULL) sload4(csu, colsum + b * K + tk); else csu = __float_as_uint(colsum[b * K + tk]);
     su32x4 vf[2][KS], kr[2 * KS];
     uint32_t at[2][4], da[2][4];
-    const int tk = min(t16, K - 1);
     auto issue = [&](int step) __attribute__((always_inline)) {
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
@@ -536,21 +564,8 @@ __global__ __launch_bounds__(256) void slot_bwd_defer_kernel(const bf16_t* __res
         slot_issue_rows<KS, FULL>(kr, kb, n0 + step * 32, N, lane, SV);
     };
     issue(0);
-    // r[k] = dupd[k,:] . upd[k,:]  (one wave per slot, round robin), colsum.  (These loads go through the compiler, whose
-    // waits drain the step-0 loads above with them: one exposed round trip for the prologue and step 0 together.)
-    if (threadIdx.x < 16) { sr[threadIdx.x] = 0.f; scs[threadIdx.x] = 1.f; }
-    __syncthreads();
-    for (int k = w; k < K; k += 4) {
-        float p = 0.f;
-        for (int e = lane; e < D; e += 64) p += bf16_to_f32(dub[k * D + e]) * bf16_to_f32(upd[((int64_t)b * K + k) * D + e]);
-        p = wave_sum(p);
-        if (lane == 0) { sr[k] = p; scs[k] = colsum[b * K + k]; }
-    }
-    __syncthreads();
-    const float my_r = sr[t16], my_inv = 1.f / scs[t16];
     sbf16x8 df[KS];
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) df[ks] = slot_frag(dub, t16, K, D, ks, g);
+    float my_r = 0.f, my_inv = 1.f;
     sf32x4 dQ[2 * KS];
 #pragma unroll
     for (int ct = 0; ct < 2 * KS; ++ct) dQ[ct] = (sf32x4){0.f, 0.f, 0.f, 0.f};
@@ -566,6 +581,24 @@ __global__ __launch_bounds__(256) void slot_bwd_defer_kernel(const bf16_t* __res
             if constexpr (FULL) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) { spin(at[half][r]); if (HAS_DA) spin(da[half][r]); }
+            }
+            if (step == 0 && half == 0) {
+                // r[k] = d(updates)[k] . updates[k] = the diagonal of a 16 x 16 product of the two fragment sets: lane (k, g)
+                // takes it from lane (k, k >> 2), register k & 3
+                slot_pin_frags<KS, FULL>(du, SK);
+                slot_pin_frags<KS, FULL>(uu, SK);
+                if constexpr (FULL) spin(csu);
+                sf32x4 pr = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    df[ks] = as_frag(slot_ok ? du[ks] : (su32x4){0u, 0u, 0u, 0u});
+                    pr = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag(uu[ks]), df[ks], pr, 0, 0, 0);
+                }
+                const int rr = t16 & 3;
+                const float lo = (rr & 1) ? pr[1] : pr[0], hi = (rr & 1) ? pr[3] : pr[2];
+                const float diag = (rr & 2) ? hi : lo;
+                my_r = __shfl(diag, (t16 >> 2) * 16 + t16, 64);   // (valid in the source lanes g == t16 >> 2, which is what is read)
+                my_inv = 1.f / __uint_as_float(csu);
             }
             sf32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll

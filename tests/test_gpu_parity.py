@@ -108,7 +108,10 @@ def test_linear_and_mlp(oracle, dtype, shape):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("rows,D", [(37, 64), (1569, 768), (3, 192), (50, 12)])
+@pytest.mark.parametrize("rows,D", [(37, 64), (1569, 768), (3, 192), (50, 12),
+                                    # >= 4096 rows in bf16: the sub-wave 16-byte kernels (8 / 16 / 32 / 64 lanes per row,
+                                    # one and two chunks per lane, ragged last pass and a half-empty last chunk)
+                                    (4100, 192), (4097, 768), (5003, 64), (4099, 128), (4096, 520), (4101, 328)])
 def test_layernorm(oracle, dtype, rows, D):
     from focus_amd import ops
     g = torch.Generator().manual_seed(1)
@@ -677,11 +680,11 @@ def test_cell_amax_vectorised():
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-def test_layer_norm_fork_adds_residual_gradient(dtype):
+@pytest.mark.parametrize("rows,D", [(333, 192), (4107, 192), (4098, 768)])
+def test_layer_norm_fork_adds_residual_gradient(dtype, rows, D):
     """layer_norm_fork returns (x, LN(x)); the gradient arriving on the x output is added inside the LN backward."""
     from focus_amd import ops
     g = torch.Generator().manual_seed(4)
-    rows, D = 333, 192
     x = torch.randn(rows, D, generator=g)
     w, b = torch.randn(D, generator=g), torch.randn(D, generator=g)
     c1, c2 = torch.randn(rows, D, generator=g), torch.randn(rows, D, generator=g)
