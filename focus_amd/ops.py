@@ -423,6 +423,53 @@ def linear(x, w, b=None, residual=None, alpha=1.0):
     return _LinearFn.apply(x, w, b, residual, float(alpha))
 
 
+class _LinearKVFn(torch.autograd.Function):
+    """Two bias-free Linears of the same input (STEVE's k / v projections of a frame, steve.py:62-63).  Forward is the
+    two GEMMs; the backward forms d(input) = alpha dk.Wk + dv.Wv with the second product's epilogue adding the first
+    (autograd would write both [rows, Din] products and add them in a third pass: 150 MB of traffic per frame)."""
+
+    @staticmethod
+    def forward(ctx, x, wk, wv, alpha_k):
+        _need_gpu(x, wk, wv)
+        shp = x.shape
+        x2 = x.reshape(-1, shp[-1])
+        if not x2.is_contiguous():
+            x2 = x2.contiguous()
+        k = mm_nt(x2, shadow(wk, x.dtype), alpha=alpha_k)
+        v = mm_nt(x2, shadow(wv, x.dtype))
+        ctx.save_for_backward(x2, wk, wv)
+        ctx.shp, ctx.alpha = shp, alpha_k
+        return k.reshape(*shp[:-1], wk.shape[0]), v.reshape(*shp[:-1], wv.shape[0])
+
+    @staticmethod
+    def backward(ctx, dk, dv):
+        x2, wk, wv = ctx.saved_tensors
+        dk2, dv2 = dk.reshape(-1, wk.shape[0]), dv.reshape(-1, wv.shape[0])
+        dk2 = dk2 if dk2.is_contiguous() else dk2.contiguous()
+        dv2 = dv2 if dv2.is_contiguous() else dv2.contiguous()
+        dwk = dwv = dx = None
+        if ctx.needs_input_grad[1]:
+            dwk = linear_wgrad(dk2, x2, False)[0]
+            if ctx.alpha != 1.0:
+                dwk = dwk * ctx.alpha
+        if ctx.needs_input_grad[2]:
+            dwv = linear_wgrad(dv2, x2, False)[0]
+        if ctx.needs_input_grad[0]:
+            dt = dk2.dtype
+            if dt == torch.bfloat16 and wk.shape[0] % 64 == 0 and wv.shape[0] % 64 == 0:
+                dx = mm_nt(dk2, shadow(wk, dt, transposed=True), alpha=ctx.alpha)
+                mm_nt(dv2, shadow(wv, dt, transposed=True), residual=dx, out=dx)   # (each element: read, add, write by one lane)
+            else:
+                dx = _dx_from(dk2, wk, dt, alpha=ctx.alpha) + _dx_from(dv2, wv, dt)
+            dx = dx.reshape(ctx.shp)
+        return dx, dwk, dwv, None
+
+
+def linear_kv(x, wk, wv, alpha_k=1.0):
+    """(alpha_k * x.wk^T, x.wv^T): two bias-free Linears of one input with a fused d(input)."""
+    return _LinearKVFn.apply(x, wk, wv, float(alpha_k))
+
+
 class _MlpFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w1, b1, w2, b2, residual, act):

@@ -65,8 +65,8 @@ class SlotAttentionVideo(nn.Module):
             # LayerNorm + k/v projections of frame t (per frame instead of whole-video: same values; the frame is read
             # in place and its gradient rows are written in place: ops.layer_norm_frame)
             x_t = ops.layer_norm_frame(inputs, t, ni.weight, ni.bias, ni.eps, video_grad)
-            k_t = ops.linear(x_t, self.project_k.weight, alpha=k_scale)      # k * Ds^-0.5 in the GEMM epilogue
-            v_t = ops.linear(x_t, self.project_v.weight)
+            # k * Ds^-0.5 in the GEMM epilogue; one node for both projections: d(x_t) = dk.Wk + dv.Wv in one pass
+            k_t, v_t = ops.linear_kv(x_t, self.project_k.weight, self.project_v.weight, alpha_k=k_scale)
             kv_grad = ops.SlotKVGrad()                            # d(k_t), d(v_t) of the iterations summed in-kernel
             for i in range(self.num_iterations):
                 # layer_norm_fork: the tensor is used twice (normalised, and as GRU state / residual); the gradient of the
