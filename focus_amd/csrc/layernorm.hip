@@ -444,7 +444,9 @@ extern "C" int focus_layernorm_bwd_blocks(int rows) {
 static int ln_bwd_any(const void* dy, const void* x, int rpb, int64_t xbs, const float* gamma, const float* mean,
                       const float* rstd, const void* dres, void* dx, float* dgamma, float* dbeta, float* partial, int rows,
                       int D, int dtype, void* stream) {
-    if (!dy || !x || !gamma || !mean || !rstd || !dx || !dgamma || !dbeta || !partial) return FOCUS_ERR_NULL;
+    if (!dy || !x || !gamma || !mean || !rstd || !dx || !partial) return FOCUS_ERR_NULL;
+    if (!dgamma != !dbeta) return FOCUS_ERR_NULL;                   // both, or neither: the caller sums `partial` itself
+    const bool finish = dgamma != nullptr;
     if (D <= 0 || (D & 3) || D > MAXV * 256 || rows <= 0 || rpb <= 0 || (xbs & 3)) return FOCUS_ERR_SHAPE;
     hipStream_t s = (hipStream_t)stream;
     const int nblk = focus_layernorm_bwd_blocks(rows);
@@ -455,15 +457,19 @@ static int ln_bwd_any(const void* dy, const void* x, int rpb, int64_t xbs, const
         LN_V16_DISPATCH(LNB);
 #undef LNB
         FOCUS_CHECK_LAUNCH();
-        hipLaunchKernelGGL(ln_bwd_finish, dim3((D + 15) / 16, 2), dim3(256), 0, s, partial, dgamma, dbeta, nblk, D);
-        FOCUS_CHECK_LAUNCH();
+        if (finish) {
+            hipLaunchKernelGGL(ln_bwd_finish, dim3((D + 15) / 16, 2), dim3(256), 0, s, partial, dgamma, dbeta, nblk, D);
+            FOCUS_CHECK_LAUNCH();
+        }
         return FOCUS_OK;
     }
     int rc = dtype == FOCUS_BF16 ? ln_bwd_launch<bf16_t>(dy, x, gamma, mean, rstd, dres, dx, partial, rows, D, nblk, rpb, xbs, s)
                                  : ln_bwd_launch<float>(dy, x, gamma, mean, rstd, dres, dx, partial, rows, D, nblk, rpb, xbs, s);
     if (rc) return rc;
-    hipLaunchKernelGGL(ln_bwd_finish, dim3((D + 15) / 16, 2), dim3(256), 0, s, partial, dgamma, dbeta, nblk, D);
-    FOCUS_CHECK_LAUNCH();
+    if (finish) {
+        hipLaunchKernelGGL(ln_bwd_finish, dim3((D + 15) / 16, 2), dim3(256), 0, s, partial, dgamma, dbeta, nblk, D);
+        FOCUS_CHECK_LAUNCH();
+    }
     return FOCUS_OK;
 }
 

@@ -93,6 +93,10 @@ __global__ __launch_bounds__(256) void slot_fwd_kernel(const T* __restrict__ kt,
     }
 }
 
+// (An in-launch finish -- the workgroup that publishes a batch element's last partial reduces all 16, the "split-K in one
+// launch" ticket protocol -- was measured and dropped: with agent-scope release fences every one of the 512 workgroups
+// writes the L2 back, 22 -> 68 us per launch; with write-through (sc1) partial stores and no fences the single reducing
+// workgroup reads its 135 KB through dependent sc1 round trips, 22 -> 51 us.  The separate launch below costs 6 us.)
 // grid (K, B), 256 threads = 64 channel lanes x 4 chunk lanes: reduce the partials over the chunks, normalise.  (With 64
 // threads walking the chunks one after the other the launch was a chain of dependent L2 round trips: 16.6 us for 16
 // chunks; here every thread's loads are independent and the four chunk lanes meet in LDS.)
@@ -811,8 +815,10 @@ __global__ __launch_bounds__(256) void slot_kv_grad_kernel(const KvGradArgs a, i
     // stacked transposed slot matrices: img[m][d][i*16 + k] = (m ? dupd_i : q_i)[b][k][d], zero for k >= K or i >= iters
     // (one 16-byte read of 8 channels of a slot row -> 8 two-byte LDS writes; a workgroup keeps the image for KVSUB
     // row blocks, so the transpose is amortised over 512 rows)
+    // (the stacked slot is the fastest index over the lanes: a wave's 64 two-byte writes of one j land in one image row,
+    // two lanes per dword; with the channel group fastest all 64 lanes hit one bank, 288 dwords apart)
     for (int e = tid; e < 2 * 64 * (D / 8); e += 256) {
-        const int m = e / (64 * (D / 8)), r = e - m * 64 * (D / 8), sl = r / (D / 8), d8 = r - sl * (D / 8);
+        const int sl = e & 63, rest = e >> 6, d8 = rest % (D / 8), m = rest / (D / 8);
         const int i = sl >> 4, k = sl & 15;
         SPk8 v;
         v.u = make_uint4(0, 0, 0, 0);

@@ -302,6 +302,7 @@ _DEFER_ON = False
 _DEFER_MAX_ROWS = 8192            # applications larger than this keep the immediate path (their GEMMs are efficient)
 _deferred_lin = {}                # id(w) -> [w, b, alpha, [dy...], [x...]]
 _deferred_vec = {}                # id(p) -> [p, [g...]]
+_deferred_ln = {}                 # id(gamma) -> [gamma, beta, [partial [2, nblk, D] ...]]
 _flush_queued = False
 
 
@@ -336,6 +337,15 @@ def _defer_linear(w, b, alpha, dy2, x2):
     _queue_flush()
 
 
+def _defer_ln(gamma, beta, partial):
+    """partial [2, nblk, D]: block partial sums of one LayerNorm application (focus_layernorm_bwd without its finish)."""
+    e = _deferred_ln.get(id(gamma))
+    if e is None:
+        e = _deferred_ln[id(gamma)] = [gamma, beta, []]
+    e[2].append(partial)
+    _queue_flush()
+
+
 def _defer_vec(p, g):
     e = _deferred_vec.get(id(p))
     if e is None:
@@ -355,9 +365,10 @@ def _acc_grad(p, g):
 def _flush_deferred():
     global _flush_queued
     _flush_queued = False
-    lin, vec = list(_deferred_lin.values()), list(_deferred_vec.values())
+    lin, vec, lns = list(_deferred_lin.values()), list(_deferred_vec.values()), list(_deferred_ln.values())
     _deferred_lin.clear()
     _deferred_vec.clear()
+    _deferred_ln.clear()
     with torch.no_grad():
         for w, b, alpha, dys, xs in lin:
             dy = dys[0] if len(dys) == 1 else torch.cat(dys, 0)
@@ -370,6 +381,10 @@ def _flush_deferred():
                 _acc_grad(b, db)
         for p, gs in vec:
             _acc_grad(p, gs[0] if len(gs) == 1 else torch.stack(gs, 0).sum(0))
+        for gamma, beta, parts in lns:
+            both = (parts[0] if len(parts) == 1 else torch.cat(parts, 1)).sum(1)          # [2, D]
+            _acc_grad(gamma, both[0])
+            _acc_grad(beta, both[1])
 
 
 # --------------------------------------------------------------------------------------------------
@@ -599,14 +614,17 @@ def _ln_backward(ctx, dy, dres):
     nblk = L.focus_layernorm_bwd_blocks(rows)
     partial = torch.empty(2, nblk, D, device=x2.device, dtype=torch.float32)
     dx = torch.empty_like(x2)
+    if ctx.defer is not None:
+        # recurrent module: this application only leaves its block partials; every application's partials are summed in
+        # one pass at the end of the backward (no per-application finish launch)
+        _lib.check(L.focus_layernorm_bwd(_p(dy2), _p(x2), _p(gamma), _p(mean), _p(rstd), _p(r2) if r2 is not None else None,
+                                         _p(dx), None, None, _p(partial), rows, D, _dt(x2), _stream()), "layernorm_bwd")
+        _defer_ln(ctx.defer[0], ctx.defer[1], partial)
+        return dx.reshape(ctx.shp), None, None
     dg = torch.empty(D, device=x2.device, dtype=torch.float32)
     db = torch.empty(D, device=x2.device, dtype=torch.float32)
     _lib.check(L.focus_layernorm_bwd(_p(dy2), _p(x2), _p(gamma), _p(mean), _p(rstd), _p(r2) if r2 is not None else None,
                                      _p(dx), _p(dg), _p(db), _p(partial), rows, D, _dt(x2), _stream()), "layernorm_bwd")
-    if ctx.defer is not None:          # recurrent module: the per-application affine gradients are summed once at the end
-        _defer_vec(ctx.defer[0], dg)
-        _defer_vec(ctx.defer[1], db)
-        return dx.reshape(ctx.shp), None, None
     return dx.reshape(ctx.shp), dg, db
 
 

@@ -127,7 +127,9 @@ int focus_layernorm_fwd(const void* x, const float* gamma, const float* beta, vo
 /* dgamma/dbeta are written (not accumulated); `partial` is a [2, nblk, D] fp32 scratch with
  * nblk = focus_layernorm_bwd_blocks(rows).  dres (may be NULL): gradient arriving on the residual path around a
  * pre-norm block (x -> x + f(LN(x)), attention.py:116-126); it is added into dx in the same pass, replacing the
- * separate accumulation autograd would do. */
+ * separate accumulation autograd would do.  dgamma == dbeta == NULL: only `partial` is written -- partial[0] holds nblk row
+ * vectors whose sum is dgamma, partial[1] likewise dbeta -- for a caller that applies the same LayerNorm many times and
+ * reduces all applications' partials in one pass at the end (STEVE's slot loop: 213 applications per step). */
 int focus_layernorm_bwd_blocks(int rows);
 int focus_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean,
                         const float* rstd, const void* dres, void* dx, float* dgamma, float* dbeta, float* partial,
