@@ -806,7 +806,7 @@ constexpr int KVSUB = 1;                          // row blocks of 256 per workg
 
 template <int KS>
 __global__ __launch_bounds__(256) void slot_kv_grad_kernel(const KvGradArgs a, int iters, bf16_t* __restrict__ dkt,
-                                                           bf16_t* __restrict__ dvt, int64_t kv_bs, int N, int K) {
+                                                           bf16_t* __restrict__ dvt, int64_t kv_bs, int64_t kv_ld, int N, int K) {
     constexpr int D = KS * 32;
     extern __shared__ __attribute__((aligned(16))) char smem[];   // [2][D][SROW]: Q^T stack, dU^T stack
     const int b = blockIdx.y, chunk = blockIdx.x;
@@ -878,7 +878,7 @@ __global__ __launch_bounds__(256) void slot_kv_grad_kernel(const KvGradArgs a, i
             }
             const int n = n0 + tb * 16 + t16;                     // lane (row n, g): channels dt*32 + 8 g .. + 7
             if (n < N) {
-                const int64_t ro = (int64_t)b * kv_bs + (int64_t)n * D + dt * 32 + 8 * g;
+                const int64_t ro = (int64_t)b * kv_bs + (int64_t)n * kv_ld + dt * 32 + 8 * g;
                 uint4 o1, o2;
                 o1.x = (uint32_t)f32_to_bf16(ck[0][0]) | ((uint32_t)f32_to_bf16(ck[0][1]) << 16);
                 o1.y = (uint32_t)f32_to_bf16(ck[0][2]) | ((uint32_t)f32_to_bf16(ck[0][3]) << 16);
@@ -1036,10 +1036,11 @@ extern "C" int focus_slot_kv_grad_ok(int K, int D, int dtype, int iters) {
 
 extern "C" int focus_slot_kv_grad(const void* wl0, const void* wl1, const void* wl2, const void* wl3, const void* q0,
                                   const void* q1, const void* q2, const void* q3, const void* du0, const void* du1,
-                                  const void* du2, const void* du3, int iters, void* dk_t, void* dv_t, int64_t kv_bs, int B,
-                                  int N, int K, int D, int dtype, void* stream) {
+                                  const void* du2, const void* du3, int iters, void* dk_t, void* dv_t, int64_t kv_bs,
+                                  int64_t kv_ld, int B, int N, int K, int D, int dtype, void* stream) {
     if (!dk_t || !dv_t) return FOCUS_ERR_NULL;
-    if (B <= 0 || N <= 0 || B > 65535 || !focus_slot_kv_grad_ok(K, D, dtype, iters) || (kv_bs & 3)) return FOCUS_ERR_SHAPE;
+    if (B <= 0 || N <= 0 || B > 65535 || !focus_slot_kv_grad_ok(K, D, dtype, iters) || (kv_bs & 7) || kv_ld < D || (kv_ld & 7))
+        return FOCUS_ERR_SHAPE;
     KvGradArgs a;
     const void* wl[4] = {wl0, wl1, wl2, wl3};
     const void* q[4] = {q0, q1, q2, q3};
@@ -1056,7 +1057,7 @@ extern "C" int focus_slot_kv_grad(const void* wl0, const void* wl1, const void* 
 #define SKV(KS) do { \
         static bool once = (hipFuncSetAttribute((const void*)slot_kv_grad_kernel<KS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess); \
         (void)once; \
-        hipLaunchKernelGGL((slot_kv_grad_kernel<KS>), grid, dim3(256), lds, s, a, iters, (bf16_t*)dk_t, (bf16_t*)dv_t, kv_bs, N, K); } while (0)
+        hipLaunchKernelGGL((slot_kv_grad_kernel<KS>), grid, dim3(256), lds, s, a, iters, (bf16_t*)dk_t, (bf16_t*)dv_t, kv_bs, kv_ld, N, K); } while (0)
     if (D == 64) SKV(2); else if (D == 128) SKV(4); else if (D == 192) SKV(6); else SKV(8);
 #undef SKV
     FOCUS_CHECK_LAUNCH();

@@ -259,6 +259,7 @@ def drop_caches():
     """Forget every bf16 weight shadow (frees their memory when a model is dropped between workloads)."""
     _shadow_cache.clear()
     _shadow_tables.clear()
+    _stacked.clear()
 
 
 def shadow(w, dtype, transposed=False):
@@ -459,25 +460,55 @@ class _LinearKVFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dk, dv):
         x2, wk, wv = ctx.saved_tensors
-        dk2, dv2 = dk.reshape(-1, wk.shape[0]), dv.reshape(-1, wv.shape[0])
+        Dk, Dv = wk.shape[0], wv.shape[0]
+        dk2, dv2 = dk.reshape(-1, Dk), dv.reshape(-1, Dv)
+        dt = dk2.dtype
+        need_x, need_wk, need_wv = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.needs_input_grad[2]
+        if (Dk == Dv and dt == torch.bfloat16 and Dk % 64 == 0 and dk2.stride() == (2 * Dk, 1) == dv2.stride()
+                and dv2.data_ptr() == dk2.data_ptr() + Dk * dk2.element_size()):
+            # the two gradients are the halves of one [rows, 2D] matrix (ops.slot_attn_step's deferred k/v gradient):
+            # d(input) = [dk|dv] . [alpha Wk; Wv] and d[Wk; Wv] = [dk|dv]^T . x, each ONE product that reads [dk|dv] once
+            dkv = torch.as_strided(dk2, (dk2.shape[0], 2 * Dk), (2 * Dk, 1))
+            dx = dwk = dwv = None
+            if need_x:
+                dx = mm_nt(dkv, _stacked_wT(wk, wv, ctx.alpha, dt)).reshape(ctx.shp)
+            if need_wk or need_wv:
+                dw = linear_wgrad(dkv, x2, False)[0]
+                dwk = dw[:Dk] * ctx.alpha if ctx.alpha != 1.0 else dw[:Dk]
+                dwv = dw[Dk:]
+            return dx, dwk if need_wk else None, dwv if need_wv else None, None
         dk2 = dk2 if dk2.is_contiguous() else dk2.contiguous()
         dv2 = dv2 if dv2.is_contiguous() else dv2.contiguous()
         dwk = dwv = dx = None
-        if ctx.needs_input_grad[1]:
+        if need_wk:
             dwk = linear_wgrad(dk2, x2, False)[0]
             if ctx.alpha != 1.0:
                 dwk = dwk * ctx.alpha
-        if ctx.needs_input_grad[2]:
+        if need_wv:
             dwv = linear_wgrad(dv2, x2, False)[0]
-        if ctx.needs_input_grad[0]:
-            dt = dk2.dtype
-            if dt == torch.bfloat16 and wk.shape[0] % 64 == 0 and wv.shape[0] % 64 == 0:
+        if need_x:
+            if dt == torch.bfloat16 and Dk % 64 == 0 and Dv % 64 == 0:
                 dx = mm_nt(dk2, shadow(wk, dt, transposed=True), alpha=ctx.alpha)
                 mm_nt(dv2, shadow(wv, dt, transposed=True), residual=dx, out=dx)   # (each element: read, add, write by one lane)
             else:
                 dx = _dx_from(dk2, wk, dt, alpha=ctx.alpha) + _dx_from(dv2, wv, dt)
             dx = dx.reshape(ctx.shp)
         return dx, dwk, dwv, None
+
+
+_stacked = {}
+
+
+def _stacked_wT(wk, wv, alpha, dtype):
+    """[alpha Wk; Wv]^T as an NT-GEMM B operand [Din, 2D] in `dtype`.  Cached like the bf16 weight shadows it is built
+    from: rebuilt when a weight's version, storage or the shadow generation (optimizer post-step hook) changes."""
+    key = (id(wk), id(wv), dtype)
+    stamp = (wk._version, wk.data_ptr(), wv._version, wv.data_ptr(), alpha, _shadow_gen)
+    e = _stacked.get(key)
+    if e is None or e[0] != stamp:
+        t = torch.cat([shadow(wk, dtype, transposed=True) * alpha, shadow(wv, dtype, transposed=True)], dim=1).contiguous()
+        e = _stacked[key] = (stamp, t)
+    return e[1]
 
 
 def linear_kv(x, wk, wv, alpha_k=1.0):
@@ -1403,10 +1434,12 @@ class _SlotAttnFn(torch.autograd.Function):
             if acc.pending > 0:
                 return None, None, dq, None, None
             it = acc.items + [(None, None, None)] * (4 - len(acc.items))
-            dk, dv = torch.empty_like(k_t), torch.empty_like(v_t)
+            # one [B,N,2D] matrix [dk | dv]: the projections' backward (linear_kv) then runs one product per gradient
+            dkv = torch.empty(B, N, 2 * D, device=k_t.device, dtype=k_t.dtype)
+            dk, dv = dkv[..., :D], dkv[..., D:]
             _lib.check(L.focus_slot_kv_grad(*[_p(e[0]) for e in it], *[_p(e[1]) for e in it], *[_p(e[2]) for e in it],
-                                            len(acc.items), _p(dk), _p(dv), N * D, B, N, K, D, _dt(k_t), _stream()),
-                       "slot_kv_grad")
+                                            len(acc.items), _p(dk), _p(dv), N * 2 * D, 2 * D, B, N, K, D, _dt(k_t),
+                                            _stream()), "slot_kv_grad")
             acc.items = []
             acc.total = 0
             return dk, dv, dq, None, None

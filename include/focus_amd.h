@@ -296,12 +296,14 @@ int focus_slot_attn_bwd(const void* k_t, const void* v_t, int64_t kv_bstride, co
                         size_t partial_bytes, int B, int N, int K, int D, float eps, int dtype, void* wl, void* stream);
 /* d(k_t), d(v_t) of one frame for all `iters` (<= 4) corrector iterations that read it (steve.py:68-83), from the wl rows
  * of their backward launches and their q / dupd [B,K,D]:  dk = sum_i dlogits_i . q_i,  dv = sum_i w_i . dupd_i  (two MFMA
- * products with the iterations stacked along the reduction).  bf16, K <= 16, D in {64,128,192,256}. */
+ * products with the iterations stacked along the reduction).  bf16, K <= 16, D in {64,128,192,256}.  dk_t / dv_t rows are
+ * kv_ld elements apart (>= D): with dv_t = dk_t + D and kv_ld = 2 D the two gradients form one [B,N,2D] matrix [dk | dv],
+ * which lets the projections' backward run as one product each (d(input) = [dk|dv].[Wk;Wv], d[Wk;Wv] = [dk|dv]^T.x). */
 int focus_slot_kv_grad_ok(int K, int D, int dtype, int iters);
 int focus_slot_kv_grad(const void* wl0, const void* wl1, const void* wl2, const void* wl3, const void* q0, const void* q1,
                        const void* q2, const void* q3, const void* du0, const void* du1, const void* du2, const void* du3,
-                       int iters, void* dk_t, void* dv_t, int64_t kv_bstride, int B, int N, int K, int D, int dtype,
-                       void* stream);
+                       int iters, void* dk_t, void* dv_t, int64_t kv_bstride, int64_t kv_ld, int B, int N, int K, int D,
+                       int dtype, void* stream);
 
 /* nn.GRUCell gate math (STEVE/utils.py:107-118): gi, gh [R,3D] (bias already added), h [R,D] -> hn. */
 int focus_gru_gates_fwd(const void* gi, const void* gh, const void* h, void* hn, int R, int D, int dtype,

@@ -66,7 +66,7 @@ def main():
 
     def kvg():
         _lib.check(L.focus_slot_kv_grad(_p(wls[0]), _p(wls[1]), _p(wls[2]), None, _p(q), _p(q), _p(q), None, _p(dupd),
-                                        _p(dupd), _p(dupd), None, 3, _p(dk), _p(dv), N * D, B, N, K, D, _dt(q), _stream()),
+                                        _p(dupd), _p(dupd), None, 3, _p(dk), _p(dv), N * D, D, B, N, K, D, _dt(q), _stream()),
                    "kv_grad")
 
     fwd()
