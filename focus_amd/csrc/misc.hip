@@ -181,26 +181,41 @@ __global__ __launch_bounds__(256) void xent_ls_kernel(const float* __restrict__ 
 
 // ---- GRU gates --------------------------------------------------------------------------------------
 __device__ __forceinline__ float sigm(float x) { return 1.f / (1.f + expf(-x)); }
+// b_ih / b_hh (fp32 [3D], both or neither): the gate pre-activations arrive WITHOUT their biases (the two Linear products
+// of the cell run as one batched bias-free launch); they are added here and the biased values written back, so that
+// gi / gh hold what the backward kernel expects.
 template <typename T>
-__global__ void gru_fwd_kernel(const T* __restrict__ gi, const T* __restrict__ gh, const T* __restrict__ h,
-                               T* __restrict__ hn, int R, int D) {
+__global__ void gru_fwd_kernel(T* __restrict__ gi, T* __restrict__ gh, const T* __restrict__ h, T* __restrict__ hn,
+                               const float* __restrict__ b_ih, const float* __restrict__ b_hh, int R, int D) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (int64_t)R * D) return;
     const int64_t r = i / D;
     const int c = (int)(i % D);
-    const T* a = gi + r * 3 * D;
-    const T* b = gh + r * 3 * D;
-    const float rg = sigm(ld<T>(a + c) + ld<T>(b + c));
-    const float zg = sigm(ld<T>(a + D + c) + ld<T>(b + D + c));
-    const float ng = tanhf(ld<T>(a + 2 * D + c) + rg * ld<T>(b + 2 * D + c));
+    T* a = gi + r * 3 * D;
+    T* b = gh + r * 3 * D;
+    float ar = ld<T>(a + c), az = ld<T>(a + D + c), an = ld<T>(a + 2 * D + c);
+    float br = ld<T>(b + c), bz = ld<T>(b + D + c), bn = ld<T>(b + 2 * D + c);
+    if (b_ih) {
+        ar += b_ih[c]; az += b_ih[D + c]; an += b_ih[2 * D + c];
+        br += b_hh[c]; bz += b_hh[D + c]; bn += b_hh[2 * D + c];
+        st<T>(a + c, ar); st<T>(a + D + c, az); st<T>(a + 2 * D + c, an);
+        st<T>(b + c, br); st<T>(b + D + c, bz); st<T>(b + 2 * D + c, bn);
+        // the backward recomputes the gates from the STORED values: use them here too (bf16 storage rounds)
+        ar = ld<T>(a + c); az = ld<T>(a + D + c); an = ld<T>(a + 2 * D + c);
+        br = ld<T>(b + c); bz = ld<T>(b + D + c); bn = ld<T>(b + 2 * D + c);
+    }
+    const float rg = sigm(ar + br);
+    const float zg = sigm(az + bz);
+    const float ng = tanhf(an + rg * bn);
     st<T>(hn + i, (1.f - zg) * ng + zg * ld<T>(h + i));
 }
 template <typename T>
 __global__ void gru_bwd_kernel(const T* __restrict__ gi, const T* __restrict__ gh, const T* __restrict__ h,
                                const T* __restrict__ dhn, T* __restrict__ dgi, T* __restrict__ dgh,
-                               T* __restrict__ dh, int R, int D) {
+                               T* __restrict__ dh, T* __restrict__ zero_out, int R, int D) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (int64_t)R * D) return;
+    if (zero_out) st<T>(zero_out + i, 0.f);
     const int64_t r = i / D;
     const int c = (int)(i % D);
     const T* a = gi + r * 3 * D;
@@ -481,20 +496,20 @@ extern "C" int focus_xent_ls(const float* logits, const int64_t* target, float* 
     return FOCUS_OK;
 }
 
-extern "C" int focus_gru_gates_fwd(const void* gi, const void* gh, const void* h, void* hn, int R, int D, int dtype,
-                                   void* stream) {
-    if (!gi || !gh || !h || !hn) return FOCUS_ERR_NULL;
+extern "C" int focus_gru_gates_fwd(void* gi, void* gh, const void* h, void* hn, const float* b_ih, const float* b_hh, int R,
+                                   int D, int dtype, void* stream) {
+    if (!gi || !gh || !h || !hn || (!b_ih != !b_hh)) return FOCUS_ERR_NULL;
     DISPATCH_T(dtype, hipLaunchKernelGGL((gru_fwd_kernel<T>), dim3(nblk((int64_t)R * D, 256)), dim3(256), 0,
-                                         (hipStream_t)stream, (const T*)gi, (const T*)gh, (const T*)h, (T*)hn, R, D));
+                                         (hipStream_t)stream, (T*)gi, (T*)gh, (const T*)h, (T*)hn, b_ih, b_hh, R, D));
     FOCUS_CHECK_LAUNCH();
     return FOCUS_OK;
 }
 extern "C" int focus_gru_gates_bwd(const void* gi, const void* gh, const void* h, const void* dhn, void* dgi,
-                                   void* dgh, void* dh, int R, int D, int dtype, void* stream) {
+                                   void* dgh, void* dh, void* zero_out, int R, int D, int dtype, void* stream) {
     if (!gi || !gh || !h || !dhn || !dgi || !dgh || !dh) return FOCUS_ERR_NULL;
     DISPATCH_T(dtype, hipLaunchKernelGGL((gru_bwd_kernel<T>), dim3(nblk((int64_t)R * D, 256)), dim3(256), 0,
                                          (hipStream_t)stream, (const T*)gi, (const T*)gh, (const T*)h, (const T*)dhn,
-                                         (T*)dgi, (T*)dgh, (T*)dh, R, D));
+                                         (T*)dgi, (T*)dgh, (T*)dh, (T*)zero_out, R, D));
     FOCUS_CHECK_LAUNCH();
     return FOCUS_OK;
 }

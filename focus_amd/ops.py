@@ -1474,7 +1474,8 @@ class _GruGatesFn(torch.autograd.Function):
         gi, gh, h = gi.contiguous(), gh.contiguous(), h.contiguous()
         R, D = h.shape
         hn = torch.empty_like(h)
-        _lib.check(_lib.lib().focus_gru_gates_fwd(_p(gi), _p(gh), _p(h), _p(hn), R, D, _dt(h), _stream()), "gru_fwd")
+        _lib.check(_lib.lib().focus_gru_gates_fwd(_p(gi), _p(gh), _p(h), _p(hn), None, None, R, D, _dt(h), _stream()),
+                   "gru_fwd")
         ctx.save_for_backward(gi, gh, h)
         return hn
 
@@ -1484,11 +1485,70 @@ class _GruGatesFn(torch.autograd.Function):
         R, D = h.shape
         dhn = dhn.contiguous()
         dgi, dgh, dh = torch.empty_like(gi), torch.empty_like(gh), torch.empty_like(h)
-        _lib.check(_lib.lib().focus_gru_gates_bwd(_p(gi), _p(gh), _p(h), _p(dhn), _p(dgi), _p(dgh), _p(dh), R, D,
+        _lib.check(_lib.lib().focus_gru_gates_bwd(_p(gi), _p(gh), _p(h), _p(dhn), _p(dgi), _p(dgh), _p(dh), None, R, D,
                                                   _dt(h), _stream()), "gru_bwd")
         return dgi, dgh, dh
 
 
+def _stacked_pair(wa, wb, dtype, transposed):
+    """The bf16 shadows of two equally shaped weights as one [2, ...] tensor (the B operands of a batch-2 product);
+    cached like the shadows themselves (version, storage, shadow generation)."""
+    key = (id(wa), id(wb), dtype, transposed)
+    stamp = (wa._version, wa.data_ptr(), wb._version, wb.data_ptr(), _shadow_gen)
+    e = _stacked.get(key)
+    if e is None or e[0] != stamp:
+        t = torch.stack([shadow(wa, dtype, transposed=transposed), shadow(wb, dtype, transposed=transposed)], 0).contiguous()
+        e = _stacked[key] = (stamp, t)
+    return e[1]
+
+
+class _GruCellFn(torch.autograd.Function):
+    """nn.GRUCell (STEVE/utils.py:107-118) with its two Linear products as ONE batch-2 launch each way: forward
+    [gi | gh] = [x | h] . [W_ih | W_hh]^T (the operands of the two halves are separate tensors: the batch stride of A is
+    simply their distance), backward [dx | dh] = [dgi | dgh] . [W_ih | W_hh] + [0 | dhn z].  The gate kernel adds the
+    biases.  Per application: 2 launches forward, 2 backward (5 and 7 before, with autograd's accumulation add)."""
+
+    @staticmethod
+    def forward(ctx, x, h, w_ih, w_hh, b_ih, b_hh):
+        R, D = h.shape
+        G = 3 * D
+        g = torch.empty(2, R, G, device=x.device, dtype=x.dtype)
+        gemm(R, G, D, (x, 0), (D, 1, 0, (h.data_ptr() - x.data_ptr()) // x.element_size()),
+             (_stacked_pair(w_ih, w_hh, x.dtype, False), 0), (1, D, 0, G * D), (g, 0), (G, 1, 0, R * G), batch=(1, 2))
+        hn = torch.empty_like(h)
+        _lib.check(_lib.lib().focus_gru_gates_fwd(_p(g[0]), _p(g[1]), _p(h), _p(hn), _p(b_ih), _p(b_hh), R, D, _dt(h),
+                                                  _stream()), "gru_fwd")
+        ctx.save_for_backward(x, h, g, w_ih, w_hh, b_ih, b_hh)
+        ctx.defer = _DEFER_ON and R <= _DEFER_MAX_ROWS and w_ih.is_leaf and w_hh.is_leaf
+        return hn
+
+    @staticmethod
+    def backward(ctx, dhn):
+        x, h, g, w_ih, w_hh, b_ih, b_hh = ctx.saved_tensors
+        R, D = h.shape
+        G = 3 * D
+        dhn = dhn.contiguous()
+        dg = torch.empty_like(g)
+        res = torch.empty(2, R, D, device=h.device, dtype=h.dtype)
+        _lib.check(_lib.lib().focus_gru_gates_bwd(_p(g[0]), _p(g[1]), _p(h), _p(dhn), _p(dg[0]), _p(dg[1]), _p(res[1]),
+                                                  _p(res[0]), R, D, _dt(h), _stream()), "gru_bwd")
+        dxh = torch.empty_like(res)
+        gemm(R, D, G, (dg, 0), (G, 1, 0, R * G), (_stacked_pair(w_ih, w_hh, h.dtype, True), 0), (1, G, 0, D * G),
+             (dxh, 0), (D, 1, 0, R * D), batch=(1, 2), residual=(res, 0))
+        dws = [None, None, None, None]
+        if ctx.defer:
+            _defer_linear(w_ih, b_ih, 1.0, dg[0], x)
+            _defer_linear(w_hh, b_hh, 1.0, dg[1], h)
+        else:
+            dws[0], dws[2] = linear_wgrad(dg[0], x, True)
+            dws[1], dws[3] = linear_wgrad(dg[1], h, True)
+        return dxh[0], dxh[1], dws[0], dws[1], dws[2], dws[3]
+
+
 def gru_cell(x, h, w_ih, w_hh, b_ih, b_hh):
-    """nn.GRUCell: two Linear GEMMs + fused gate kernel.  x, h [R,D]."""
+    """nn.GRUCell.  x, h [R,D].  bf16 with equal input and hidden widths (the slot update): _GruCellFn; otherwise two
+    Linear GEMMs + the gate kernel."""
+    if (x.dtype == torch.bfloat16 and x.shape == h.shape and x.is_contiguous() and h.is_contiguous() and x.shape[1] % 32 == 0
+            and b_ih is not None and b_hh is not None and (h.data_ptr() - x.data_ptr()) % 16 == 0 and x.is_cuda):
+        return _GruCellFn.apply(x, h, w_ih, w_hh, b_ih, b_hh)
     return _GruGatesFn.apply(linear(x, w_ih, b_ih), linear(h, w_hh, b_hh), h)

@@ -305,11 +305,16 @@ int focus_slot_kv_grad(const void* wl0, const void* wl1, const void* wl2, const 
                        int iters, void* dk_t, void* dv_t, int64_t kv_bstride, int64_t kv_ld, int B, int N, int K, int D,
                        int dtype, void* stream);
 
-/* nn.GRUCell gate math (STEVE/utils.py:107-118): gi, gh [R,3D] (bias already added), h [R,D] -> hn. */
-int focus_gru_gates_fwd(const void* gi, const void* gh, const void* h, void* hn, int R, int D, int dtype,
-                        void* stream);
+/* nn.GRUCell gate math (STEVE/utils.py:107-118): gi, gh [R,3D] gate pre-activations, h [R,D] -> hn.
+ * b_ih, b_hh (fp32 [3D]; both or neither): with them gi / gh arrive WITHOUT bias (the cell's two Linear products run as one
+ * batched bias-free launch), the kernel adds the biases and writes the biased values back into gi / gh -- what the
+ * backward reads.  NULL: gi / gh already carry their biases and are only read. */
+int focus_gru_gates_fwd(void* gi, void* gh, const void* h, void* hn, const float* b_ih, const float* b_hh, int R, int D,
+                        int dtype, void* stream);
+/* dh = the direct part dhn * z.  zero_out (may be NULL): an [R,D] buffer cleared by the same launch -- with dh it forms the
+ * [2,R,D] residual operand of the batched product [d(input) | d(h)] = [dgi | dgh] . [W_ih | W_hh] + [0 | dh]. */
 int focus_gru_gates_bwd(const void* gi, const void* gh, const void* h, const void* dhn, void* dgi, void* dgh,
-                        void* dh, int R, int D, int dtype, void* stream);
+                        void* dh, void* zero_out, int R, int D, int dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Patch embedding as GEMM (stem_helper.py:317-320): im2col of x [B,Cin,T,H,W] fp32 (loader output)
