@@ -146,3 +146,100 @@ def test_slot_train_step_runs_the_reference_schedule():
         assert abs(tau - (0.45 * math.cos(math.pi * step / 20) + 0.55)) < 1e-12
     moved = {n.split(".")[0] for n, p in m.named_parameters() if p.requires_grad and not torch.equal(p.detach(), before[n])}
     assert moved == {"dvae", "steve_encoder", "steve_decoder"}
+
+
+# ------------------------------------------------------------------------------------------------
+# the composite nodes of the slot loop, each against plain torch in fp64 on the same bf16 values
+# ------------------------------------------------------------------------------------------------
+def _rel(got, want):
+    want = want.double()
+    return float((got.double().cpu() - want.cpu()).abs().max() / want.abs().max().clamp_min(1e-30))
+
+
+@pytest.mark.parametrize("paired", [False, True])
+def test_linear_kv_matches_two_linears(paired):
+    """ops.linear_kv (steve.py:62-63): k = alpha x.Wk^T, v = x.Wv^T and the fused d(x) = alpha dk.Wk + dv.Wv.  `paired`: the
+    cotangents arrive as the two halves of one [rows, 2D] buffer (what ops.slot_attn_step's deferred k/v gradient hands
+    over) and the backward runs one product per gradient; otherwise two products with the residual epilogue."""
+    from focus_amd import ops
+    d = dev()
+    g = torch.Generator().manual_seed(11)
+    R, Din, D, alpha = 4608, 192, 192, 192 ** -0.5
+    x = torch.randn(2, R // 2, Din, generator=g).bfloat16()
+    wk, wv = torch.randn(D, Din, generator=g) * Din ** -0.5, torch.randn(D, Din, generator=g) * Din ** -0.5
+    ck, cv = torch.randn(2, R // 2, D, generator=g).bfloat16(), torch.randn(2, R // 2, D, generator=g).bfloat16()
+    xr = x.double().requires_grad_()
+    wkr, wvr = wk.bfloat16().double().requires_grad_(), wv.bfloat16().double().requires_grad_()
+    kr, vr = alpha * xr @ wkr.t(), xr @ wvr.t()
+    ((kr * ck.double()).sum() + (vr * cv.double()).sum()).backward()
+    xg = x.to(d).requires_grad_()
+    wkg, wvg = wk.to(d).requires_grad_(), wv.to(d).requires_grad_()
+    k, v = ops.linear_kv(xg, wkg, wvg, alpha_k=alpha)
+    if paired:
+        both = torch.cat([ck, cv], dim=-1).to(d)
+        torch.autograd.backward([k, v], [both[..., :D], both[..., D:]])
+    else:
+        torch.autograd.backward([k, v], [ck.to(d), cv.to(d)])
+    assert _rel(k, kr.detach()) < 2 ** -7 and _rel(v, vr.detach()) < 2 ** -7
+    assert _rel(xg.grad, xr.grad) < 2 ** -6                         # a sum of two bf16-rounded products (paired: one)
+    assert _rel(wkg.grad, wkr.grad) < 2 ** -7 and _rel(wvg.grad, wvr.grad) < 2 ** -7
+
+
+@pytest.mark.parametrize("defer", [False, True])
+def test_gru_cell_batched_matches_torch(defer):
+    """ops.gru_cell on the slot shapes (STEVE/utils.py:107-118): the batch-2 products + bias-adding gate kernel against
+    torch.nn.GRUCell in fp64; with `defer` the weight / bias gradients come from ops.deferred_wgrads' flush."""
+    from focus_amd import ops
+    d = dev()
+    g = torch.Generator().manual_seed(12)
+    R, D = 352, 192
+    cell = torch.nn.GRUCell(D, D).double()
+    with torch.no_grad():
+        for p in cell.parameters():
+            p.copy_(p.float().bfloat16().double() if p.dim() == 2 else p)
+    x, h = torch.randn(R, D, generator=g).bfloat16(), torch.randn(R, D, generator=g).bfloat16()
+    ct = torch.randn(R, D, generator=g).bfloat16()
+    xr, hr = x.double().requires_grad_(), h.double().requires_grad_()
+    (cell(xr, hr) * ct.double()).sum().backward()
+    P = {n: p.detach().float().to(d).requires_grad_() for n, p in cell.named_parameters()}
+    xg, hg = x.to(d).requires_grad_(), h.to(d).requires_grad_()
+
+    def run():
+        out = ops.gru_cell(xg, hg, P["weight_ih"], P["weight_hh"], P["bias_ih"], P["bias_hh"])
+        (out.float() * ct.to(d).float()).sum().backward()
+        return out
+
+    if defer:
+        with ops.deferred_wgrads():
+            out = run()
+    else:
+        out = run()
+    torch.cuda.synchronize()
+    assert _rel(out, cell(xr, hr).detach()) < 2 ** -6
+    assert _rel(xg.grad, xr.grad) < 2 ** -5 and _rel(hg.grad, hr.grad) < 2 ** -5      # gate derivatives from bf16 pre-activations
+    for n, p in cell.named_parameters():
+        assert P[n].grad is not None, n
+        assert _rel(P[n].grad, p.grad) < 2 ** -5, n
+
+
+def test_layer_norm_deferred_affine_gradients():
+    """Inside ops.deferred_wgrads the LayerNorm backward leaves only block partials (focus_layernorm_bwd with
+    dgamma = dbeta = NULL); the flush sums all applications at once.  Three applications of one LayerNorm against torch."""
+    from focus_amd import ops
+    d = dev()
+    g = torch.Generator().manual_seed(13)
+    R, D = 352, 192
+    w, b = 1 + 0.1 * torch.randn(D, generator=g), 0.1 * torch.randn(D, generator=g)
+    xs = [torch.randn(R, D, generator=g).bfloat16() for _ in range(3)]
+    cs = [torch.randn(R, D, generator=g) for _ in range(3)]
+    wr, br = w.double().requires_grad_(), b.double().requires_grad_()
+    xrs = [x.double().requires_grad_() for x in xs]
+    sum((torch.nn.functional.layer_norm(xr, (D,), wr, br, 1e-5) * c.double()).sum() for xr, c in zip(xrs, cs)).backward()
+    wg, bg = w.to(d).requires_grad_(), b.to(d).requires_grad_()
+    xgs = [x.to(d).requires_grad_() for x in xs]
+    with ops.deferred_wgrads():
+        sum((ops.layer_norm(xg, wg, bg, 1e-5).float() * c.to(d)).sum() for xg, c in zip(xgs, cs)).backward()
+    torch.cuda.synchronize()
+    assert _rel(wg.grad, wr.grad) < 2 ** -6 and _rel(bg.grad, br.grad) < 2 ** -6
+    for xg, xr in zip(xgs, xrs):
+        assert _rel(xg.grad, xr.grad) < 2 ** -6
