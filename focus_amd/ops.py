@@ -1031,9 +1031,17 @@ class _SmallAttnFn(torch.autograd.Function):
         dev, dt = q.device, q.dtype
         q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
         att = torch.empty(B, heads, N, M, device=dev, dtype=dt)
+        L = _lib.lib()
+        ctx.heads, ctx.scale = heads, scale
+        ctx.fused = not causal and drop is None and bool(L.focus_small_attn_ok(N, M, d))
+        if ctx.fused:       # a handful of tokens (the slot predictor): the whole attention in one launch
+            out = torch.empty(B, N, C, device=dev, dtype=dt)
+            _lib.check(L.focus_small_attn_fwd(_p(q), _p(k), _p(v), _p(att), _p(out), B, heads, N, M, d, scale, _dt(q),
+                                              _stream()), "small_attn_fwd")
+            ctx.save_for_backward(q, k, v, att, None)
+            return out
         sa = (M, 1, heads * N * M, N * M)
         gemm(N, M, d, (q, 0), (C, 1, N * C, d), (k, 0), (1, C, M * C, d), (att, 0), sa, batch=(B, heads))
-        L = _lib.lib()
         if causal:
             assert N == M, "causal self-attention"
             _lib.check(L.focus_softmax_causal_fwd(_p(att), _p(att), B * heads * N, M, M, N, scale, _dt(att), _stream()),
@@ -1045,7 +1053,6 @@ class _SmallAttnFn(torch.autograd.Function):
         out = torch.empty(B, N, C, device=dev, dtype=dt)
         gemm(N, d, M, (attd, 0), sa, (v, 0), (C, 1, M * C, d), (out, 0), (C, 1, N * C, d), batch=(B, heads))
         ctx.save_for_backward(q, k, v, att, drop)
-        ctx.heads, ctx.scale = heads, scale
         return out
 
     @staticmethod
@@ -1056,6 +1063,11 @@ class _SmallAttnFn(torch.autograd.Function):
         M = k.shape[1]
         d = C // heads
         dout = dout.contiguous()
+        if ctx.fused:
+            dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+            _lib.check(_lib.lib().focus_small_attn_bwd(_p(q), _p(k), _p(v), _p(att), _p(dout), _p(dq), _p(dk), _p(dv), B, heads,
+                                                       N, M, d, scale, _dt(q), _stream()), "small_attn_bwd")
+            return dq, dk, dv, None, None, None, None
         sa = (M, 1, heads * N * M, N * M)
         sat = (1, M, heads * N * M, N * M)
         sq = (C, 1, N * C, d)

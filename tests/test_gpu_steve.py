@@ -243,3 +243,33 @@ def test_layer_norm_deferred_affine_gradients():
     assert _rel(wg.grad, wr.grad) < 2 ** -6 and _rel(bg.grad, br.grad) < 2 ** -6
     for xg, xr in zip(xgs, xrs):
         assert _rel(xg.grad, xr.grad) < 2 ** -6
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,heads,N,M,d", [(32, 4, 11, 11, 48), (3, 3, 5, 16, 64), (2, 1, 16, 1, 8)])
+def test_small_attention_one_launch(dtype, B, heads, N, M, d):
+    """ops.small_attention on a handful of tokens (the slot predictor's 11 x 11, transformer.py:4-49) takes the one-launch
+    kernels of small_attn.hip; against softmax attention in fp64 on the same (rounded) inputs."""
+    from focus_amd import _lib, ops
+    assert _lib.lib().focus_small_attn_ok(N, M, d)
+    dv_ = dev()
+    g = torch.Generator().manual_seed(B + N + M)
+    C = heads * d
+    q, k, v = (torch.randn(B, n, C, generator=g).to(dtype) for n in (N, M, M))
+    ct = torch.randn(B, N, C, generator=g).to(dtype)
+    scale = d ** -0.5
+    qr, kr, vr = (t.double().requires_grad_() for t in (q, k, v))
+
+    def heads_of(t):
+        return t.view(t.shape[0], t.shape[1], heads, d).transpose(1, 2)
+
+    att = torch.softmax(scale * heads_of(qr) @ heads_of(kr).transpose(-1, -2), dim=-1)
+    ref = (att @ heads_of(vr)).transpose(1, 2).reshape(B, N, C)
+    (ref * ct.double()).sum().backward()
+    qg, kg, vg = (t.to(dv_).requires_grad_() for t in (q, k, v))
+    out = ops.small_attention(qg, kg, vg, heads, scale)
+    (out.float() * ct.to(dv_).float()).sum().backward()
+    tol = 2 ** -6 if dtype == torch.bfloat16 else 1e-5
+    assert _rel(out, ref.detach()) < tol
+    for got, want in ((qg.grad, qr.grad), (kg.grad, kr.grad), (vg.grad, vr.grad)):
+        assert _rel(got, want) < tol
