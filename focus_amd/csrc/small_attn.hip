@@ -36,19 +36,19 @@ template <typename T>
 __global__ __launch_bounds__(64 * WPB) void small_attn_fwd_kernel(const T* __restrict__ q, const T* __restrict__ k,
                                                                   const T* __restrict__ v, T* __restrict__ att,
                                                                   T* __restrict__ out, int nprob, int heads, int N, int M,
-                                                                  int d, float scale) {
+                                                                  int d, float scale, int64_t ldq, int64_t ldk, int64_t ldv) {
     __shared__ SmallAttnLds lds[WPB];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int p = blockIdx.x * WPB + w;                  // problem = (clip b, head h)
     if (p >= nprob) return;                              // (wave-uniform; no workgroup barrier below)
     SmallAttnLds& L = lds[w];
     const int b = p / heads, h = p - b * heads, C = heads * d;
-    const T* qb = q + ((int64_t)b * N) * C + h * d;
-    const T* kb = k + ((int64_t)b * M) * C + h * d;
-    const T* vb = v + ((int64_t)b * M) * C + h * d;
-    load_rows<T>(L.q, qb, N, d, C, lane);
-    load_rows<T>(L.k, kb, M, d, C, lane);
-    load_rows<T>(L.v, vb, M, d, C, lane);
+    const T* qb = q + ((int64_t)b * N) * ldq + h * d;
+    const T* kb = k + ((int64_t)b * M) * ldk + h * d;
+    const T* vb = v + ((int64_t)b * M) * ldv + h * d;
+    load_rows<T>(L.q, qb, N, d, ldq, lane);
+    load_rows<T>(L.k, kb, M, d, ldk, lane);
+    load_rows<T>(L.v, vb, M, d, ldv, lane);
     __builtin_amdgcn_wave_barrier();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     for (int e = lane; e < N * M; e += 64) {
@@ -87,18 +87,21 @@ __global__ __launch_bounds__(64 * WPB) void small_attn_bwd_kernel(const T* __res
                                                                   const T* __restrict__ v, const T* __restrict__ att,
                                                                   const T* __restrict__ dout, T* __restrict__ dq,
                                                                   T* __restrict__ dk, T* __restrict__ dv, int nprob,
-                                                                  int heads, int N, int M, int d, float scale) {
+                                                                  int heads, int N, int M, int d, float scale, int64_t ldq,
+                                                                  int64_t ldk, int64_t ldv) {
     __shared__ SmallAttnLds lds[WPB];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int p = blockIdx.x * WPB + w;
     if (p >= nprob) return;
     SmallAttnLds& L = lds[w];
     const int b = p / heads, h = p - b * heads, C = heads * d;
-    const int64_t qo = ((int64_t)b * N) * C + h * d, ko = ((int64_t)b * M) * C + h * d;
-    load_rows<T>(L.q, q + qo, N, d, C, lane);
-    load_rows<T>(L.k, k + ko, M, d, C, lane);
-    load_rows<T>(L.v, v + ko, M, d, C, lane);
-    load_rows<T>(L.o, dout + qo, N, d, C, lane);
+    // q / dq, k / dk, v / dv rows are ldq, ldk, ldv elements apart (the three may be column blocks of one [rows, 3C] matrix)
+    const int64_t qo = ((int64_t)b * N) * ldq + h * d, ko = ((int64_t)b * M) * ldk + h * d, vo = ((int64_t)b * M) * ldv + h * d;
+    const int64_t oo = ((int64_t)b * N) * C + h * d;
+    load_rows<T>(L.q, q + qo, N, d, ldq, lane);
+    load_rows<T>(L.k, k + ko, M, d, ldk, lane);
+    load_rows<T>(L.v, v + vo, M, d, ldv, lane);
+    load_rows<T>(L.o, dout + oo, N, d, C, lane);
     for (int e = lane; e < N * M; e += 64) L.s[e / M][e % M] = ld<T>(att + (int64_t)p * N * M + e);
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
@@ -107,7 +110,7 @@ __global__ __launch_bounds__(64 * WPB) void small_attn_bwd_kernel(const T* __res
         const int j = e / d, c = e - j * d;
         float a = 0.f;
         for (int i = 0; i < N; ++i) a = fmaf(L.s[i][j], L.o[i][c], a);
-        st<T>(dv + ko + (int64_t)j * C + c, a);
+        st<T>(dv + vo + (int64_t)j * ldv + c, a);
     }
     for (int e = lane; e < N * M; e += 64) {
         const int i = e / M, j = e - i * M;
@@ -128,13 +131,13 @@ __global__ __launch_bounds__(64 * WPB) void small_attn_bwd_kernel(const T* __res
         const int i = e / d, c = e - i * d;
         float a = 0.f;
         for (int j = 0; j < M; ++j) a = fmaf(L.t[i][j], L.k[j][c], a);
-        st<T>(dq + qo + (int64_t)i * C + c, a);
+        st<T>(dq + qo + (int64_t)i * ldq + c, a);
     }
     for (int e = lane; e < M * d; e += 64) {             // dk = dS^T q
         const int j = e / d, c = e - j * d;
         float a = 0.f;
         for (int i = 0; i < N; ++i) a = fmaf(L.t[i][j], L.q[i][c], a);
-        st<T>(dk + ko + (int64_t)j * C + c, a);
+        st<T>(dk + ko + (int64_t)j * ldk + c, a);
     }
 }
 
@@ -146,27 +149,27 @@ bool small_attn_shape_ok(int B, int heads, int N, int M, int d) {
 
 extern "C" int focus_small_attn_ok(int N, int M, int d) { return N > 0 && M > 0 && d > 0 && N <= TMAX && M <= TMAX && d <= DMAX; }
 
-extern "C" int focus_small_attn_fwd(const void* q, const void* k, const void* v, void* att, void* out, int B, int heads, int N,
-                                    int M, int d, float scale, int dtype, void* stream) {
+extern "C" int focus_small_attn_fwd(const void* q, const void* k, const void* v, int64_t ldq, int64_t ldk, int64_t ldv, void* att,
+                                    void* out, int B, int heads, int N, int M, int d, float scale, int dtype, void* stream) {
     if (!q || !k || !v || !att || !out) return FOCUS_ERR_NULL;
-    if (!small_attn_shape_ok(B, heads, N, M, d)) return FOCUS_ERR_SHAPE;
+    if (!small_attn_shape_ok(B, heads, N, M, d) || ldq < heads * d || ldk < heads * d || ldv < heads * d) return FOCUS_ERR_SHAPE;
     const int nprob = B * heads;
     DISPATCH_T(dtype, hipLaunchKernelGGL((small_attn_fwd_kernel<T>), dim3((nprob + WPB - 1) / WPB), dim3(64 * WPB), 0,
                                          (hipStream_t)stream, (const T*)q, (const T*)k, (const T*)v, (T*)att, (T*)out, nprob,
-                                         heads, N, M, d, scale));
+                                         heads, N, M, d, scale, ldq, ldk, ldv));
     FOCUS_CHECK_LAUNCH();
     return FOCUS_OK;
 }
 
-extern "C" int focus_small_attn_bwd(const void* q, const void* k, const void* v, const void* att, const void* dout, void* dq,
-                                    void* dk, void* dv, int B, int heads, int N, int M, int d, float scale, int dtype,
-                                    void* stream) {
+extern "C" int focus_small_attn_bwd(const void* q, const void* k, const void* v, int64_t ldq, int64_t ldk, int64_t ldv,
+                                    const void* att, const void* dout, void* dq, void* dk, void* dv, int B, int heads, int N,
+                                    int M, int d, float scale, int dtype, void* stream) {
     if (!q || !k || !v || !att || !dout || !dq || !dk || !dv) return FOCUS_ERR_NULL;
-    if (!small_attn_shape_ok(B, heads, N, M, d)) return FOCUS_ERR_SHAPE;
+    if (!small_attn_shape_ok(B, heads, N, M, d) || ldq < heads * d || ldk < heads * d || ldv < heads * d) return FOCUS_ERR_SHAPE;
     const int nprob = B * heads;
     DISPATCH_T(dtype, hipLaunchKernelGGL((small_attn_bwd_kernel<T>), dim3((nprob + WPB - 1) / WPB), dim3(64 * WPB), 0,
                                          (hipStream_t)stream, (const T*)q, (const T*)k, (const T*)v, (const T*)att,
-                                         (const T*)dout, (T*)dq, (T*)dk, (T*)dv, nprob, heads, N, M, d, scale));
+                                         (const T*)dout, (T*)dq, (T*)dk, (T*)dv, nprob, heads, N, M, d, scale, ldq, ldk, ldv));
     FOCUS_CHECK_LAUNCH();
     return FOCUS_OK;
 }

@@ -1029,17 +1029,22 @@ class _SmallAttnFn(torch.autograd.Function):
         M = k.shape[1]
         d = C // heads
         dev, dt = q.device, q.dtype
-        q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
         att = torch.empty(B, heads, N, M, device=dev, dtype=dt)
         L = _lib.lib()
         ctx.heads, ctx.scale = heads, scale
-        ctx.fused = not causal and drop is None and bool(L.focus_small_attn_ok(N, M, d))
+
+        def rows_ok(t):      # [B, n, C] whose rows are ld apart with no gap between clips (dense, or a column block)
+            return t.stride(2) == 1 and t.stride(0) == t.shape[1] * t.stride(1) and t.stride(1) >= C
+
+        ctx.fused = (not causal and drop is None and bool(L.focus_small_attn_ok(N, M, d))
+                     and rows_ok(q) and rows_ok(k) and rows_ok(v))
         if ctx.fused:       # a handful of tokens (the slot predictor): the whole attention in one launch
             out = torch.empty(B, N, C, device=dev, dtype=dt)
-            _lib.check(L.focus_small_attn_fwd(_p(q), _p(k), _p(v), _p(att), _p(out), B, heads, N, M, d, scale, _dt(q),
-                                              _stream()), "small_attn_fwd")
+            _lib.check(L.focus_small_attn_fwd(_p(q), _p(k), _p(v), q.stride(1), k.stride(1), v.stride(1), _p(att), _p(out), B,
+                                              heads, N, M, d, scale, _dt(q), _stream()), "small_attn_fwd")
             ctx.save_for_backward(q, k, v, att, None)
             return out
+        q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
         sa = (M, 1, heads * N * M, N * M)
         gemm(N, M, d, (q, 0), (C, 1, N * C, d), (k, 0), (1, C, M * C, d), (att, 0), sa, batch=(B, heads))
         if causal:
@@ -1064,9 +1069,21 @@ class _SmallAttnFn(torch.autograd.Function):
         d = C // heads
         dout = dout.contiguous()
         if ctx.fused:
-            dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
-            _lib.check(_lib.lib().focus_small_attn_bwd(_p(q), _p(k), _p(v), _p(att), _p(dout), _p(dq), _p(dk), _p(dv), B, heads,
-                                                       N, M, d, scale, _dt(q), _stream()), "small_attn_bwd")
+            es = q.element_size()
+            if (N == M and q.stride(1) == 3 * C == k.stride(1) == v.stride(1) and k.data_ptr() == q.data_ptr() + C * es
+                    and v.data_ptr() == k.data_ptr() + C * es):
+                # q | k | v are the column blocks of one projection output (ops.linear_qkv): so are their gradients
+                dqkv = torch.empty(B, N, 3 * C, device=q.device, dtype=q.dtype)
+                dq, dk, dv = dqkv[..., :C], dqkv[..., C:2 * C], dqkv[..., 2 * C:]
+            else:
+                dq = torch.empty(q.shape, device=q.device, dtype=q.dtype)
+                dk = torch.empty(k.shape, device=q.device, dtype=q.dtype)
+                dv = torch.empty(v.shape, device=q.device, dtype=q.dtype)
+                if not (q.is_contiguous() and k.is_contiguous() and v.is_contiguous()):
+                    q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
+            _lib.check(_lib.lib().focus_small_attn_bwd(_p(q), _p(k), _p(v), q.stride(1), k.stride(1), v.stride(1), _p(att),
+                                                       _p(dout), _p(dq), _p(dk), _p(dv), B, heads, N, M, d, scale, _dt(q),
+                                                       _stream()), "small_attn_bwd")
             return dq, dk, dv, None, None, None, None
         sa = (M, 1, heads * N * M, N * M)
         sat = (1, M, heads * N * M, N * M)
@@ -1500,6 +1517,67 @@ class _GruGatesFn(torch.autograd.Function):
         _lib.check(_lib.lib().focus_gru_gates_bwd(_p(gi), _p(gh), _p(h), _p(dhn), _p(dgi), _p(dgh), _p(dh), None, R, D,
                                                   _dt(h), _stream()), "gru_bwd")
         return dgi, dgh, dh
+
+
+def _stacked_cat(ws, dtype, transposed):
+    """The bf16 shadows of several [C, Cin] weights concatenated into one NT-GEMM B operand: rows stacked [sum C, Cin]
+    (forward), or the transposes side by side [Cin, sum C] (d(input)); cached like the shadows themselves."""
+    key = tuple(id(w) for w in ws) + (dtype, transposed, "cat")
+    stamp = tuple(x for w in ws for x in (w._version, w.data_ptr())) + (_shadow_gen,)
+    e = _stacked.get(key)
+    if e is None or e[0] != stamp:
+        t = torch.cat([shadow(w, dtype, transposed=transposed) for w in ws], dim=1 if transposed else 0).contiguous()
+        e = _stacked[key] = (stamp, t)
+    return e[1]
+
+
+class _LinearQKVFn(torch.autograd.Function):
+    """Three bias-free Linears of one input (transformer.py:33-35, self-attention) as ONE product: the outputs are the
+    column blocks of a [rows, 3C] matrix (strided views; ops.small_attention reads them in place and returns its three
+    gradients as the blocks of one matrix again), so d(input) = [dq|dk|dv] . [Wq;Wk;Wv] is one product too."""
+
+    @staticmethod
+    def forward(ctx, x, wq, wk, wv):
+        _need_gpu(x, wq)
+        shp = x.shape
+        x2 = x.reshape(-1, shp[-1])
+        if not x2.is_contiguous():
+            x2 = x2.contiguous()
+        C = wq.shape[0]
+        y = mm_nt(x2, _stacked_cat((wq, wk, wv), x.dtype, False)).view(*shp[:-1], 3 * C)
+        ctx.save_for_backward(x2, wq, wk, wv)
+        ctx.shp = shp
+        ctx.defer = _DEFER_ON and x2.shape[0] <= _DEFER_MAX_ROWS and wq.is_leaf and wk.is_leaf and wv.is_leaf
+        return y[..., :C], y[..., C:2 * C], y[..., 2 * C:]
+
+    @staticmethod
+    def backward(ctx, dq, dk, dv):
+        x2, wq, wk, wv = ctx.saved_tensors
+        C = wq.shape[0]
+        ds = [t.reshape(-1, C) for t in (dq, dk, dv)]
+        es = ds[0].element_size()
+        joint = (all(t.stride() == (3 * C, 1) for t in ds) and ds[1].data_ptr() == ds[0].data_ptr() + C * es
+                 and ds[2].data_ptr() == ds[1].data_ptr() + C * es and ds[0].dtype == torch.bfloat16 and C % 64 == 0)
+        if joint:
+            dy = torch.as_strided(ds[0], (ds[0].shape[0], 3 * C), (3 * C, 1))
+            dx = mm_nt(dy, _stacked_cat((wq, wk, wv), dy.dtype, True))
+        else:
+            ds = [t if t.is_contiguous() else t.contiguous() for t in ds]
+            dx = _dx_from(ds[0], wq, ds[0].dtype)
+            for t, w in ((ds[1], wk), (ds[2], wv)):
+                dx = dx + _dx_from(t, w, t.dtype)
+        dws = [None, None, None]
+        for i, (t, w) in enumerate(zip(ds, (wq, wk, wv))):
+            if ctx.defer:
+                _defer_linear(w, None, 1.0, t, x2)
+            else:
+                dws[i] = linear_wgrad(t if t.stride(0) % 8 == 0 else t.contiguous(), x2, False)[0]
+        return dx.reshape(ctx.shp), dws[0], dws[1], dws[2]
+
+
+def linear_qkv(x, wq, wk, wv):
+    """(x.wq^T, x.wk^T, x.wv^T) as the column blocks of one product (strided views of a [..., 3C] tensor)."""
+    return _LinearQKVFn.apply(x, wq, wk, wv)
 
 
 def _stacked_pair(wa, wb, dtype, transposed):

@@ -33,9 +33,14 @@ class MultiHeadAttention(nn.Module):
         causal = attn_mask is not None
         if causal:
             assert attn_mask.shape == (T, S) and T == S, "only the decoder's causal mask is supported"
-        Q = ops.linear(q, self.proj_q.weight)
-        Kt = ops.linear(k, self.proj_k.weight)
-        V = ops.linear(v, self.proj_v.weight)
+        if q is k and k is v and not causal and T <= 16 and q.dtype == torch.bfloat16 and self.d_model % 64 == 0:
+            # self-attention over the slots (the predictor): the three projections are the column blocks of one product,
+            # which ops.small_attention's one-launch kernels read in place
+            Q, Kt, V = ops.linear_qkv(q, self.proj_q.weight, self.proj_k.weight, self.proj_v.weight)
+        else:
+            Q = ops.linear(q, self.proj_q.weight)
+            Kt = ops.linear(k, self.proj_k.weight)
+            V = ops.linear(v, self.proj_v.weight)
         d = self.d_model // self.num_heads
         p = self.attn_dropout.p
         drop = None

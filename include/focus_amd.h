@@ -306,13 +306,16 @@ int focus_slot_kv_grad(const void* wl0, const void* wl1, const void* wl2, const 
                        int dtype, void* stream);
 
 /* Multi-head attention over a handful of tokens (STEVE's slot predictor, transformer.py:4-49: K = 11 slots, 4 heads of 48),
- * one launch each way: q [B,N,heads*d], k, v [B,M,heads*d] dense; att [B,heads,N,M] = softmax_rows(scale q k^T) is stored
- * for the backward; out [B,N,heads*d] = att v.  N, M <= 16, d <= 64 (focus_small_attn_ok); no mask, no dropout. */
+ * one launch each way: q [B,N,heads*d], k, v [B,M,heads*d] with rows ldq / ldk / ldv elements apart and no gap between
+ * clips (ld = heads*d: dense; the three may be the column blocks of one [B*N, 3*heads*d] projection output); att
+ * [B,heads,N,M] = softmax_rows(scale q k^T) is stored for the backward; out, dout [B,N,heads*d] dense = att v.  dq, dk, dv
+ * are written at the strides of q, k, v.  N, M <= 16, d <= 64 (focus_small_attn_ok); no mask, no dropout. */
 int focus_small_attn_ok(int N, int M, int d);
-int focus_small_attn_fwd(const void* q, const void* k, const void* v, void* att, void* out, int B, int heads, int N, int M,
-                         int d, float scale, int dtype, void* stream);
-int focus_small_attn_bwd(const void* q, const void* k, const void* v, const void* att, const void* dout, void* dq, void* dk,
-                         void* dv, int B, int heads, int N, int M, int d, float scale, int dtype, void* stream);
+int focus_small_attn_fwd(const void* q, const void* k, const void* v, int64_t ldq, int64_t ldk, int64_t ldv, void* att,
+                         void* out, int B, int heads, int N, int M, int d, float scale, int dtype, void* stream);
+int focus_small_attn_bwd(const void* q, const void* k, const void* v, int64_t ldq, int64_t ldk, int64_t ldv, const void* att,
+                         const void* dout, void* dq, void* dk, void* dv, int B, int heads, int N, int M, int d, float scale,
+                         int dtype, void* stream);
 
 /* nn.GRUCell gate math (STEVE/utils.py:107-118): gi, gh [R,3D] gate pre-activations, h [R,D] -> hn.
  * b_ih, b_hh (fp32 [3D]; both or neither): with them gi / gh arrive WITHOUT bias (the cell's two Linear products run as one

@@ -64,7 +64,10 @@ def test_slot_attention_baseline_shape_slice_vs_oracle(oracle):
         close(xg.grad, xr.grad, tol * 3, "dinputs %s" % dtype, floor=1e-2 * float(xr.grad.abs().max()))
         named = dict(m.named_parameters())
         for k in ("project_q.weight", "project_k.weight", "project_v.weight", "gru.weight_ih", "gru.bias_hh",
-                  "mlp.0.weight", "norm_slots.weight", "slot_mu", "predictor.blocks.0.attn.proj_o.weight"):
+                  "mlp.0.weight", "norm_slots.weight", "slot_mu", "predictor.blocks.0.attn.proj_o.weight",
+                  # the predictor's q | k | v projections run as one product (ops.linear_qkv) feeding the one-launch attention
+                  "predictor.blocks.0.attn.proj_q.weight", "predictor.blocks.0.attn.proj_k.weight",
+                  "predictor.blocks.0.attn.proj_v.weight", "predictor.blocks.0.ffn.0.weight", "norm_inputs.weight"):
             gr = p[k].grad
             close(named[k].grad, gr, tol * 3, "grad %s %s" % (k, dtype), floor=1e-2 * float(gr.abs().max()) + 1e-12)
 
