@@ -3,8 +3,9 @@
 // STEVE's slot predictor (transformer.py:4-49 inside steve.py:98) attends over the K = 11 slots of a frame: 4 heads of
 // d = 48, B = 32 clips -- 128 independent 11 x 11 problems of 0.1 MFLOP.  As strided batched GEMMs + a row softmax that is
 // 3 launches forward and 5 backward per frame (generic-kernel GEMMs of 8-9 us each: the shapes fit no MFMA tile), 24
-// frames per step.  Here one 64-lane wave owns one (clip, head): q, k, v [<= 16 tokens][<= 64 channels] sit in LDS as
-// fp32 and every product is a few dozen FMAs per lane.
+// frames per step.  Here one 256-thread workgroup owns one (clip, head): q, k, v [<= 16 tokens][<= 64 channels] sit in LDS
+// as fp32 and every product is a few dozen FMAs per thread.  (One wave per problem was LDS-latency bound: 13 / 21 us
+// forward / backward; the four waves of a workgroup share each loop.)
 //   forward : S = scale q k^T, P = softmax_rows(S) (stored, bf16/fp32 like the inputs), out = P v
 //   backward: dP = dout v^T, dV = P^T dout, dS = scale P (dP - rowsum(P dP)), dq = dS k, dk = dS^T q
 // P is rounded to the storage type before it multiplies v, as the unfused path's stored probabilities were.
@@ -12,7 +13,7 @@
 
 namespace {
 
-constexpr int TMAX = 16, DMAX = 64, WPB = 2;            // tokens, head channels, waves (= problems) per workgroup
+constexpr int TMAX = 16, DMAX = 64, NT = 256;           // tokens, head channels, threads of the workgroup that owns a problem
 
 struct SmallAttnLds {
     float q[TMAX][DMAX + 1], k[TMAX][DMAX + 1], v[TMAX][DMAX + 1], o[TMAX][DMAX + 1];   // o: dout in the backward
@@ -29,19 +30,17 @@ template <typename T> __device__ __forceinline__ float stored(float x) { T t; st
 
 template <typename T>
 __device__ __forceinline__ void load_rows(float (*dst)[DMAX + 1], const T* src, int rows, int d, int64_t rs, int lane) {
-    for (int e = lane; e < rows * d; e += 64) dst[e / d][e % d] = ld<T>(src + (int64_t)(e / d) * rs + e % d);
+    for (int e = lane; e < rows * d; e += NT) dst[e / d][e % d] = ld<T>(src + (int64_t)(e / d) * rs + e % d);
 }
 
 template <typename T>
-__global__ __launch_bounds__(64 * WPB) void small_attn_fwd_kernel(const T* __restrict__ q, const T* __restrict__ k,
+__global__ __launch_bounds__(NT) void small_attn_fwd_kernel(const T* __restrict__ q, const T* __restrict__ k,
                                                                   const T* __restrict__ v, T* __restrict__ att,
                                                                   T* __restrict__ out, int nprob, int heads, int N, int M,
                                                                   int d, float scale, int64_t ldq, int64_t ldk, int64_t ldv) {
-    __shared__ SmallAttnLds lds[WPB];
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int p = blockIdx.x * WPB + w;                  // problem = (clip b, head h)
-    if (p >= nprob) return;                              // (wave-uniform; no workgroup barrier below)
-    SmallAttnLds& L = lds[w];
+    __shared__ SmallAttnLds L;
+    const int lane = threadIdx.x;                        // (index within the problem's workgroup)
+    const int p = blockIdx.x;                            // problem = (clip b, head h)
     const int b = p / heads, h = p - b * heads, C = heads * d;
     const T* qb = q + ((int64_t)b * N) * ldq + h * d;
     const T* kb = k + ((int64_t)b * M) * ldk + h * d;
@@ -49,16 +48,14 @@ __global__ __launch_bounds__(64 * WPB) void small_attn_fwd_kernel(const T* __res
     load_rows<T>(L.q, qb, N, d, ldq, lane);
     load_rows<T>(L.k, kb, M, d, ldk, lane);
     load_rows<T>(L.v, vb, M, d, ldv, lane);
-    __builtin_amdgcn_wave_barrier();
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    for (int e = lane; e < N * M; e += 64) {
+    __syncthreads();
+    for (int e = lane; e < N * M; e += NT) {
         const int i = e / M, j = e - i * M;
         float a = 0.f;
         for (int c = 0; c < d; ++c) a = fmaf(L.q[i][c], L.k[j][c], a);
         L.s[i][j] = a * scale;
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_wave_barrier();
+    __syncthreads();
     if (lane < N) {                                      // one lane per row: M <= 16 terms
         float m = -INFINITY, sum = 0.f;
         for (int j = 0; j < M; ++j) m = fmaxf(m, L.s[lane][j]);
@@ -71,10 +68,9 @@ __global__ __launch_bounds__(64 * WPB) void small_attn_fwd_kernel(const T* __res
             L.s[lane][j] = pr;
         }
     }
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_wave_barrier();
+    __syncthreads();
     T* ob = out + ((int64_t)b * N) * C + h * d;
-    for (int e = lane; e < N * d; e += 64) {
+    for (int e = lane; e < N * d; e += NT) {
         const int i = e / d, c = e - i * d;
         float a = 0.f;
         for (int j = 0; j < M; ++j) a = fmaf(L.s[i][j], L.v[j][c], a);
@@ -83,17 +79,15 @@ __global__ __launch_bounds__(64 * WPB) void small_attn_fwd_kernel(const T* __res
 }
 
 template <typename T>
-__global__ __launch_bounds__(64 * WPB) void small_attn_bwd_kernel(const T* __restrict__ q, const T* __restrict__ k,
+__global__ __launch_bounds__(NT) void small_attn_bwd_kernel(const T* __restrict__ q, const T* __restrict__ k,
                                                                   const T* __restrict__ v, const T* __restrict__ att,
                                                                   const T* __restrict__ dout, T* __restrict__ dq,
                                                                   T* __restrict__ dk, T* __restrict__ dv, int nprob,
                                                                   int heads, int N, int M, int d, float scale, int64_t ldq,
                                                                   int64_t ldk, int64_t ldv) {
-    __shared__ SmallAttnLds lds[WPB];
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int p = blockIdx.x * WPB + w;
-    if (p >= nprob) return;
-    SmallAttnLds& L = lds[w];
+    __shared__ SmallAttnLds L;
+    const int lane = threadIdx.x;
+    const int p = blockIdx.x;
     const int b = p / heads, h = p - b * heads, C = heads * d;
     // q / dq, k / dk, v / dv rows are ldq, ldk, ldv elements apart (the three may be column blocks of one [rows, 3C] matrix)
     const int64_t qo = ((int64_t)b * N) * ldq + h * d, ko = ((int64_t)b * M) * ldk + h * d, vo = ((int64_t)b * M) * ldv + h * d;
@@ -102,38 +96,35 @@ __global__ __launch_bounds__(64 * WPB) void small_attn_bwd_kernel(const T* __res
     load_rows<T>(L.k, k + ko, M, d, ldk, lane);
     load_rows<T>(L.v, v + vo, M, d, ldv, lane);
     load_rows<T>(L.o, dout + oo, N, d, C, lane);
-    for (int e = lane; e < N * M; e += 64) L.s[e / M][e % M] = ld<T>(att + (int64_t)p * N * M + e);
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_wave_barrier();
+    for (int e = lane; e < N * M; e += NT) L.s[e / M][e % M] = ld<T>(att + (int64_t)p * N * M + e);
+    __syncthreads();
     // dV = P^T dout;  dP = dout v^T
-    for (int e = lane; e < M * d; e += 64) {
+    for (int e = lane; e < M * d; e += NT) {
         const int j = e / d, c = e - j * d;
         float a = 0.f;
         for (int i = 0; i < N; ++i) a = fmaf(L.s[i][j], L.o[i][c], a);
         st<T>(dv + vo + (int64_t)j * ldv + c, a);
     }
-    for (int e = lane; e < N * M; e += 64) {
+    for (int e = lane; e < N * M; e += NT) {
         const int i = e / M, j = e - i * M;
         float a = 0.f;
         for (int c = 0; c < d; ++c) a = fmaf(L.o[i][c], L.v[j][c], a);
         L.t[i][j] = a;
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_wave_barrier();
+    __syncthreads();
     if (lane < N) {                                      // dS = scale P (dP - sum_j P dP)
         float dot = 0.f;
         for (int j = 0; j < M; ++j) dot = fmaf(L.s[lane][j], L.t[lane][j], dot);
         for (int j = 0; j < M; ++j) L.t[lane][j] = scale * L.s[lane][j] * (L.t[lane][j] - dot);
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_wave_barrier();
-    for (int e = lane; e < N * d; e += 64) {             // dq = dS k
+    __syncthreads();
+    for (int e = lane; e < N * d; e += NT) {             // dq = dS k
         const int i = e / d, c = e - i * d;
         float a = 0.f;
         for (int j = 0; j < M; ++j) a = fmaf(L.t[i][j], L.k[j][c], a);
         st<T>(dq + qo + (int64_t)i * ldq + c, a);
     }
-    for (int e = lane; e < M * d; e += 64) {             // dk = dS^T q
+    for (int e = lane; e < M * d; e += NT) {             // dk = dS^T q
         const int j = e / d, c = e - j * d;
         float a = 0.f;
         for (int i = 0; i < N; ++i) a = fmaf(L.t[i][j], L.q[i][c], a);
@@ -154,7 +145,7 @@ extern "C" int focus_small_attn_fwd(const void* q, const void* k, const void* v,
     if (!q || !k || !v || !att || !out) return FOCUS_ERR_NULL;
     if (!small_attn_shape_ok(B, heads, N, M, d) || ldq < heads * d || ldk < heads * d || ldv < heads * d) return FOCUS_ERR_SHAPE;
     const int nprob = B * heads;
-    DISPATCH_T(dtype, hipLaunchKernelGGL((small_attn_fwd_kernel<T>), dim3((nprob + WPB - 1) / WPB), dim3(64 * WPB), 0,
+    DISPATCH_T(dtype, hipLaunchKernelGGL((small_attn_fwd_kernel<T>), dim3(nprob), dim3(NT), 0,
                                          (hipStream_t)stream, (const T*)q, (const T*)k, (const T*)v, (T*)att, (T*)out, nprob,
                                          heads, N, M, d, scale, ldq, ldk, ldv));
     FOCUS_CHECK_LAUNCH();
@@ -167,7 +158,7 @@ extern "C" int focus_small_attn_bwd(const void* q, const void* k, const void* v,
     if (!q || !k || !v || !att || !dout || !dq || !dk || !dv) return FOCUS_ERR_NULL;
     if (!small_attn_shape_ok(B, heads, N, M, d) || ldq < heads * d || ldk < heads * d || ldv < heads * d) return FOCUS_ERR_SHAPE;
     const int nprob = B * heads;
-    DISPATCH_T(dtype, hipLaunchKernelGGL((small_attn_bwd_kernel<T>), dim3((nprob + WPB - 1) / WPB), dim3(64 * WPB), 0,
+    DISPATCH_T(dtype, hipLaunchKernelGGL((small_attn_bwd_kernel<T>), dim3(nprob), dim3(NT), 0,
                                          (hipStream_t)stream, (const T*)q, (const T*)k, (const T*)v, (const T*)att,
                                          (const T*)dout, (T*)dq, (T*)dk, (T*)dv, nprob, heads, N, M, d, scale, ldq, ldk, ldv));
     FOCUS_CHECK_LAUNCH();
