@@ -264,13 +264,13 @@ __global__ __launch_bounds__(256) void ln_fwd_v16_kernel(const bf16_t* __restric
 
 // Backward: per-lane partial dgamma/dbeta over every row the lane's sub-wave visits, combined across the workgroup's
 // 4 * (64 / LPR) sub-waves through LDS into partial[0|1][blk][D] (ln_bwd_finish sums the blocks).
-template <int LPR, int NV>
-__global__ __launch_bounds__(256) void ln_bwd_v16_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x,
+template <int LPR, int NV, int NW>     // NW waves per workgroup
+__global__ __launch_bounds__(64 * NW) void ln_bwd_v16_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x,
                                                          const float* __restrict__ gamma, const float* __restrict__ mean,
                                                          const float* __restrict__ rstd, const bf16_t* __restrict__ dres,
                                                          bf16_t* __restrict__ dx, float* __restrict__ partial, int rows, int D,
                                                          int rpb, int64_t xbs) {
-    constexpr int RPW = 64 / LPR, UN = NV == 1 ? 4 : 2, NSUB = 4 * RPW;
+    constexpr int RPW = 64 / LPR, UN = NV == 1 ? 4 : 2, NSUB = NW * RPW;
     extern __shared__ float red[];                                // [2][NSUB][D]
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, sub = lane / LPR, sl = lane % LPR;
     float g[NV][8], dg[NV][8], db[NV][8];
@@ -283,7 +283,7 @@ __global__ __launch_bounds__(256) void ln_bwd_v16_kernel(const bf16_t* __restric
         for (int e = 0; e < 8; ++e) { g[i][e] = 0.f; dg[i][e] = 0.f; db[i][e] = 0.f; }
         if (act[i]) load8f(gamma + c, g[i]);
     }
-    const int wave = blockIdx.x * 4 + w, nwaves = gridDim.x * 4;
+    const int wave = blockIdx.x * NW + w, nwaves = gridDim.x * NW;
     const float invD = 1.f / (float)D;
     for (int r0 = wave * (RPW * UN); r0 < rows; r0 += nwaves * (RPW * UN)) {
         uint4 xv[UN][NV], dv[UN][NV];
@@ -351,7 +351,7 @@ __global__ __launch_bounds__(256) void ln_bwd_v16_kernel(const bf16_t* __restric
             for (int e = 0; e < 8; ++e) { rg[c + e] = dg[i][e]; rb[c + e] = db[i][e]; }
         }
     __syncthreads();
-    for (int c = threadIdx.x; c < 2 * D; c += 256) {
+    for (int c = threadIdx.x; c < 2 * D; c += 64 * NW) {
         const int which = c >= D, col = which ? c - D : c;
         float t = 0.f;
 #pragma unroll
@@ -451,9 +451,16 @@ static int ln_bwd_any(const void* dy, const void* x, int rpb, int64_t xbs, const
     hipStream_t s = (hipStream_t)stream;
     const int nblk = focus_layernorm_bwd_blocks(rows);
     if (ln_v16_ok(dy, x, dx, dres, rows, D, xbs, dtype) && focus_aligned(gamma, 16)) {
+    // nblk is capped (the finish walks nblk partial rows): beyond 64 rows per wave the workgroups get 8 waves instead of 4,
+    // so that a CU holds 16 waves' worth of loads in flight (frame tokens of STEVE: 131072 rows)
+    const bool wide = (int64_t)rows >= (int64_t)nblk * 4 * 64;
 #define LNB(LPR, NV) do { \
-        const size_t lds = (size_t)2 * 4 * (64 / LPR) * D * sizeof(float); \
-        hipLaunchKernelGGL((ln_bwd_v16_kernel<LPR, NV>), dim3(nblk), dim3(256), lds, s, (const bf16_t*)dy, (const bf16_t*)x, gamma, mean, rstd, (const bf16_t*)dres, (bf16_t*)dx, partial, rows, D, rpb, xbs); } while (0)
+        if (wide) { \
+            const size_t lds = (size_t)2 * 8 * (64 / LPR) * D * sizeof(float); \
+            hipLaunchKernelGGL((ln_bwd_v16_kernel<LPR, NV, 8>), dim3(nblk), dim3(512), lds, s, (const bf16_t*)dy, (const bf16_t*)x, gamma, mean, rstd, (const bf16_t*)dres, (bf16_t*)dx, partial, rows, D, rpb, xbs); \
+        } else { \
+            const size_t lds = (size_t)2 * 4 * (64 / LPR) * D * sizeof(float); \
+            hipLaunchKernelGGL((ln_bwd_v16_kernel<LPR, NV, 4>), dim3(nblk), dim3(256), lds, s, (const bf16_t*)dy, (const bf16_t*)x, gamma, mean, rstd, (const bf16_t*)dres, (bf16_t*)dx, partial, rows, D, rpb, xbs); } } while (0)
         LN_V16_DISPATCH(LNB);
 #undef LNB
         FOCUS_CHECK_LAUNCH();

@@ -111,7 +111,8 @@ def test_linear_and_mlp(oracle, dtype, shape):
 @pytest.mark.parametrize("rows,D", [(37, 64), (1569, 768), (3, 192), (50, 12),
                                     # >= 4096 rows in bf16: the sub-wave 16-byte kernels (8 / 16 / 32 / 64 lanes per row,
                                     # one and two chunks per lane, ragged last pass and a half-empty last chunk)
-                                    (4100, 192), (4097, 768), (5003, 64), (4099, 128), (4096, 520), (4101, 328)])
+                                    (4100, 192), (4097, 768), (5003, 64), (4099, 128), (4096, 520), (4101, 328),
+                                    (131077, 192)])            # (>= 131072 rows: the backward's 8-wave workgroups)
 def test_layernorm(oracle, dtype, rows, D):
     from focus_amd import ops
     g = torch.Generator().manual_seed(1)
