@@ -19,6 +19,32 @@ __device__ __forceinline__ float dot64(const T* row, const float* q) {
     return s;
 }
 
+// 8 consecutive channels of a row as floats (one 16-byte load for bf16, two for fp32)
+template <typename T> __device__ __forceinline__ void ld8(const T* p, float (&f)[8]);
+template <> __device__ __forceinline__ void ld8<bf16_t>(const bf16_t* p, float (&f)[8]) {
+    const uint4 u = *reinterpret_cast<const uint4*>(p);
+    f[0] = __uint_as_float(u.x << 16); f[1] = __uint_as_float(u.x & 0xffff0000u);
+    f[2] = __uint_as_float(u.y << 16); f[3] = __uint_as_float(u.y & 0xffff0000u);
+    f[4] = __uint_as_float(u.z << 16); f[5] = __uint_as_float(u.z & 0xffff0000u);
+    f[6] = __uint_as_float(u.w << 16); f[7] = __uint_as_float(u.w & 0xffff0000u);
+}
+template <> __device__ __forceinline__ void ld8<float>(const float* p, float (&f)[8]) {
+    const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+    f[0] = a.x; f[1] = a.y; f[2] = a.z; f[3] = a.w; f[4] = b.x; f[5] = b.y; f[6] = b.z; f[7] = b.w;
+}
+// sum over the 8 lanes of a key group (lanes 8k .. 8k+7)
+__device__ __forceinline__ float group8_sum(float v) {
+    v += __shfl_xor(v, 1, 64);
+    v += __shfl_xor(v, 2, 64);
+    return v + __shfl_xor(v, 4, 64);
+}
+// sum over the 8 key groups of a wave (same channel lane in every group)
+__device__ __forceinline__ float across_groups_sum(float v) {
+    v += __shfl_xor(v, 8, 64);
+    v += __shfl_xor(v, 16, 64);
+    return v + __shfl_xor(v, 32, 64);
+}
+
 // The N keys of one (b,h) are split over NS workgroups (flash-decoding style): with one workgroup per (b,h) only 96
 // of the 256 CUs had work and each streamed its 400 KB of K/V rows at latency (39 / 58 us per call).
 constexpr int NS = 8;            // key splits per (b,h)
@@ -26,6 +52,9 @@ constexpr int FW = 2 + HD;       // forward partial: max, sum, out[64]
 constexpr int BW = 1 + 2 * HD;   // backward partial: sum a*da, sum a*da*K[64], sum a*K[64]
 
 // Forward, part: split sp of (b,h) -> scratch[bh][sp] = (m, sum exp(l - m), sum exp(l - m) * V[n,:])
+// Eight lanes share a key: each reads 16 bytes (8 channels) of its K and V rows, so a wave instruction covers 8 whole
+// 128-byte head rows.  (One thread per key read its row in sixteen 8-byte pieces, 4.6 KB apart from its neighbours'
+// -- every piece a separate cache-line access -- and V in 2-byte pieces: 22.6 us per launch for 19 MB.)
 template <typename T>
 __global__ __launch_bounds__(256) void cls_fwd_part_kernel(const T* __restrict__ qkv, float* __restrict__ scratch, int N,
                                                           int heads) {
@@ -37,25 +66,56 @@ __global__ __launch_bounds__(256) void cls_fwd_part_kernel(const T* __restrict__
     const int chunk = (N + NS - 1) / NS, n0 = sp * chunk, n1 = min(N, n0 + chunk);
     if (threadIdx.x < HD) sq[threadIdx.x] = ld<T>(base + threadIdx.x) * scale;
     __syncthreads();
-    const int dch = threadIdx.x & 63, pr = threadIdx.x >> 6;
-    float m = -INFINITY, ssum = 0.f, acc = 0.f;
-    for (int c0 = n0; c0 < n1; c0 += 256) {                   // (one pass for chunk <= 256 keys)
-        const int n = c0 + threadIdx.x;
-        const float l = n < n1 ? dot64<T>(base + (int64_t)n * tok + C, sq) : -INFINITY;
+    const int l8 = threadIdx.x & 7, kg = threadIdx.x >> 3, w = threadIdx.x >> 6;     // channel octet, key group 0..31
+    float q8[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) q8[i] = sq[l8 * 8 + i];
+    float m = -INFINITY, ssum = 0.f, acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int c0 = n0; c0 < n1; c0 += 256) {
+        // logits of keys c0 .. c0+255: 8 sub-passes of 32 keys
+#pragma unroll
+        for (int s8 = 0; s8 < 8; ++s8) {
+            const int n = c0 + s8 * 32 + kg;
+            float d = 0.f;
+            if (n < n1) {
+                float k8[8];
+                ld8<T>(base + (int64_t)n * tok + C + l8 * 8, k8);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) d = fmaf(k8[i], q8[i], d);
+            }
+            d = group8_sum(d);
+            if (l8 == 0) prob[s8 * 32 + kg] = n < n1 ? d : -INFINITY;
+        }
+        __syncthreads();
+        const float l = prob[threadIdx.x];
         const float mc = fmaxf(m, block_max(l, red));
         __syncthreads();
-        const float e = n < n1 ? __expf(l - mc) : 0.f;
+        const float e = l > -INFINITY ? __expf(l - mc) : 0.f;
         prob[threadIdx.x] = e;
         const float resc = __expf(m - mc);                    // 0 on the first pass (m = -inf)
         ssum = ssum * resc + block_sum(e, red);
         __syncthreads();
-        acc *= resc;
-        const int cnt = min(256, n1 - c0);
-        for (int j = pr; j < cnt; j += 4) acc += prob[j] * ld<T>(base + (int64_t)(c0 + j) * tok + 2 * C + dch);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] *= resc;
+#pragma unroll
+        for (int s8 = 0; s8 < 8; ++s8) {
+            const int n = c0 + s8 * 32 + kg;
+            if (n < n1) {
+                float v8[8];
+                ld8<T>(base + (int64_t)n * tok + 2 * C + l8 * 8, v8);
+                const float pj = prob[s8 * 32 + kg];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) acc[i] = fmaf(pj, v8[i], acc[i]);
+            }
+        }
         m = mc;
         __syncthreads();
     }
-    part[pr][dch] = acc;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const float t = across_groups_sum(acc[i]);
+        if ((threadIdx.x & 63) < 8) part[w][l8 * 8 + i] = t;
+    }
     __syncthreads();
     float* out = scratch + ((int64_t)bh * NS + sp) * FW;
     if (threadIdx.x < HD) out[2 + threadIdx.x] = part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x];
@@ -84,12 +144,14 @@ __global__ __launch_bounds__(64) void cls_fwd_comb_kernel(const float* __restric
 
 // Backward, phase A (split sp of (b,h)): probabilities from the saved lse, da[n] = dcls . V[n]; both go to scratch
 // for phase B together with this split's partial sums  sum a*da,  sum a*da*K[n,:],  sum a*K[n,:].
+// Eight lanes share a key (16-byte K and V pieces, as in the forward); the K octet that gave the logit stays in
+// registers for the two weighted sums, so K is read once.
 template <typename T>
 __global__ __launch_bounds__(256) void cls_bwd_a_kernel(const T* __restrict__ qkv, const float* __restrict__ cls_lse,
                                                         const T* __restrict__ dcls, float* __restrict__ prob_g,
                                                         float* __restrict__ da_g, float* __restrict__ parts, int N,
                                                         int heads) {
-    __shared__ float sq[HD], sd[HD], red[4], pa[256], pd[256], part[2][4][HD];
+    __shared__ float sq[HD], sd[HD], red[4], part[2][4][HD];
     const int sp = blockIdx.x, bh = blockIdx.y, b = bh / heads, hh = bh % heads, C = heads * HD;
     const int64_t tok = 3 * (int64_t)C;
     const T* base = qkv + (int64_t)b * N * tok + hh * HD;
@@ -100,33 +162,38 @@ __global__ __launch_bounds__(256) void cls_bwd_a_kernel(const T* __restrict__ qk
         sd[threadIdx.x] = ld<T>(dcls + (int64_t)b * C + hh * HD + threadIdx.x);
     }
     __syncthreads();
-    const int dch = threadIdx.x & 63, pr = threadIdx.x >> 6;
-    float dot = 0.f, u = 0.f, wv = 0.f;
-    for (int c0 = n0; c0 < n1; c0 += 256) {
-        const int n = c0 + threadIdx.x;
-        float a = 0.f, da = 0.f;
-        if (n < n1) {
+    const int l8 = threadIdx.x & 7, kg = threadIdx.x >> 3, w = threadIdx.x >> 6;
+    float q8[8], d8[8], u[8], wv[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { q8[i] = sq[l8 * 8 + i]; d8[i] = sd[l8 * 8 + i]; u[i] = 0.f; wv[i] = 0.f; }
+    float dot = 0.f;
+    for (int n = n0 + kg; n < n0 + ((n1 - n0 + 31) / 32) * 32; n += 32) {     // (uniform trip count: the shuffles need every lane)
+        float k8[8], a = 0.f, da = 0.f;
+        const bool ok = n < n1;
+        if (ok) {
+            float v8[8];
             const T* row = base + (int64_t)n * tok;
-            a = __expf(dot64<T>(row + C, sq) - lse);
-            da = dot64<T>(row + 2 * C, sd);
-            prob_g[(int64_t)bh * N + n] = a;
-            da_g[(int64_t)bh * N + n] = da;
+            ld8<T>(row + C + l8 * 8, k8);
+            ld8<T>(row + 2 * C + l8 * 8, v8);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { a = fmaf(k8[i], q8[i], a); da = fmaf(v8[i], d8[i], da); }
         }
-        dot += a * da;
-        pa[threadIdx.x] = a;
-        pd[threadIdx.x] = a * da;
-        __syncthreads();
-        const int cnt = min(256, n1 - c0);
-        for (int j = pr; j < cnt; j += 4) {
-            const float k = ld<T>(base + (int64_t)(c0 + j) * tok + C + dch);
-            u += pd[j] * k;
-            wv += pa[j] * k;
+        a = group8_sum(a);
+        da = group8_sum(da);
+        if (ok) {
+            a = __expf(a - lse);
+            if (l8 == 0) { prob_g[(int64_t)bh * N + n] = a; da_g[(int64_t)bh * N + n] = da; dot += a * da; }
+            const float ad = a * da;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { u[i] = fmaf(ad, k8[i], u[i]); wv[i] = fmaf(a, k8[i], wv[i]); }
         }
-        __syncthreads();
     }
     dot = block_sum(dot, red);
-    part[0][pr][dch] = u;
-    part[1][pr][dch] = wv;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const float tu = across_groups_sum(u[i]), tw = across_groups_sum(wv[i]);
+        if ((threadIdx.x & 63) < 8) { part[0][w][l8 * 8 + i] = tu; part[1][w][l8 * 8 + i] = tw; }
+    }
     __syncthreads();
     float* out = parts + ((int64_t)bh * NS + sp) * BW;
     if (threadIdx.x < 2 * HD) {
