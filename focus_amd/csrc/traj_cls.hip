@@ -32,6 +32,19 @@ template <> __device__ __forceinline__ void ld8<float>(const float* p, float (&f
     const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
     f[0] = a.x; f[1] = a.y; f[2] = a.z; f[3] = a.w; f[4] = b.x; f[5] = b.y; f[6] = b.z; f[7] = b.w;
 }
+template <typename T> __device__ __forceinline__ void st8(T* p, const float (&f)[8]);
+template <> __device__ __forceinline__ void st8<bf16_t>(bf16_t* p, const float (&f)[8]) {
+    uint4 o;
+    o.x = (uint32_t)f32_to_bf16(f[0]) | ((uint32_t)f32_to_bf16(f[1]) << 16);
+    o.y = (uint32_t)f32_to_bf16(f[2]) | ((uint32_t)f32_to_bf16(f[3]) << 16);
+    o.z = (uint32_t)f32_to_bf16(f[4]) | ((uint32_t)f32_to_bf16(f[5]) << 16);
+    o.w = (uint32_t)f32_to_bf16(f[6]) | ((uint32_t)f32_to_bf16(f[7]) << 16);
+    *reinterpret_cast<uint4*>(p) = o;
+}
+template <> __device__ __forceinline__ void st8<float>(float* p, const float (&f)[8]) {
+    *reinterpret_cast<float4*>(p) = make_float4(f[0], f[1], f[2], f[3]);
+    *reinterpret_cast<float4*>(p + 4) = make_float4(f[4], f[5], f[6], f[7]);
+}
 // sum over the 8 lanes of a key group (lanes 8k .. 8k+7)
 __device__ __forceinline__ float group8_sum(float v) {
     v += __shfl_xor(v, 1, 64);
@@ -205,7 +218,7 @@ __global__ __launch_bounds__(256) void cls_bwd_a_kernel(const T* __restrict__ qk
 
 // Phase B (grid: 64-row strips x (b,h)): dl[n] = scale * a[n] * (da[n] - dot);  dK[n,:] (+)= dl[n] * q0,
 // dV[n,:] (+)= a[n] * dcls; token 0 is written plainly, tokens 1.. are read-modify-written (the patch kernels wrote
-// them first).  16-byte accesses.  Strip 0 also writes dq0 = scale * (sum a*da*K - dot * sum a*K).
+// them first).  16-byte pieces.  Strip 0 also writes dq0 = scale * (sum a*da*K - dot * sum a*K).
 template <typename T>
 __global__ __launch_bounds__(256) void cls_bwd_b_kernel(const T* __restrict__ qkv, const T* __restrict__ dcls,
                                                         const float* __restrict__ prob_g,
@@ -225,18 +238,25 @@ __global__ __launch_bounds__(256) void cls_bwd_b_kernel(const T* __restrict__ qk
         // q0 was pre-multiplied by scale in phase A: the logits' derivative w.r.t. q0 carries one factor of scale
         st<T>(dqkv + (int64_t)b * N * tok + hh * HD + threadIdx.x, scale * (u - dot * wv));
     }
-    for (int it = threadIdx.x; it < 64 * 16 * 2; it += 256) {
-        const int which = it / (64 * 16), rem = it % (64 * 16), n = blockIdx.x * 64 + rem / 16, c = (rem % 16) * 4;
+    for (int it = threadIdx.x; it < 64 * 8 * 2; it += 256) {     // 16-byte pieces: (part, row, channel octet)
+        const int which = it / (64 * 8), rem = it % (64 * 8), n = blockIdx.x * 64 + rem / 8, c = (rem % 8) * 8;
         if (n >= N) continue;
         const float a = prob_g[(int64_t)bh * N + n];
         const float w = which == 0 ? scale * a * (da_g[(int64_t)bh * N + n] - dot) : a;
         const T* src = which == 0 ? qkv + (int64_t)b * N * tok + hh * HD + c          // q0 (token 0, q part)
                                   : dcls + (int64_t)b * C + hh * HD + c;
-        const f4 v = ld4<T>(src);
+        float v[8], o[8];
+        ld8<T>(src, v);
         T* dst = dqkv + ((int64_t)b * N + n) * tok + (which == 0 ? C : 2 * C) + hh * HD + c;
-        f4 o = {w * v.x, w * v.y, w * v.z, w * v.w};
-        if (n > 0) { const f4 old = ld4<T>(dst); o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w; }
-        st4<T>(dst, o);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o[i] = w * v[i];
+        if (n > 0) {
+            float old[8];
+            ld8<T>(dst, old);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) o[i] += old[i];
+        }
+        st8<T>(dst, o);
     }
 }
 
