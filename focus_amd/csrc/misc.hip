@@ -550,22 +550,25 @@ extern "C" int focus_cell_amax_bwd(const void* dy, const int32_t* arg, void* dx,
 template <typename T>
 __global__ void scale_add_kernel(const T* __restrict__ x, const T* __restrict__ y, const float* __restrict__ scale,
                                  float keep, T* __restrict__ out, int64_t total, int64_t per) {
-    const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 8;       // 16-byte pieces (per % 8 == 0)
     if (i >= total) return;
     float sc = scale[i / per];
     if (keep > 0.f) sc = __fdiv_rn(floorf(__fadd_rn(keep, sc)), keep);   // scale = the uniform draw: mask / keep_prob
-    const f4 b = ld4<T>(y + i);
-    f4 a = {0.f, 0.f, 0.f, 0.f};
-    if (x) a = ld4<T>(x + i);
-    st4<T>(out + i, (f4){a.x + sc * b.x, a.y + sc * b.y, a.z + sc * b.z, a.w + sc * b.w});
+    float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, b[8];
+    ld8<T>(y + i, b);
+    if (x) ld8<T>(x + i, a);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) a[e] += sc * b[e];
+    st8<T>(out + i, a);
 }
 extern "C" int focus_scale_add(const void* x, const void* y, const float* scale, float keep, void* out, int B,
                                int64_t per, int dtype, void* stream) {
     if (!y || !scale || !out) return FOCUS_ERR_NULL;
     if (B <= 0 || per <= 0) return FOCUS_OK;
     if (per & 7) return FOCUS_ERR_SHAPE;
+    if (!focus_aligned(y, 16) || !focus_aligned(out, 16) || (x && !focus_aligned(x, 16))) return FOCUS_ERR_ALIGN;
     const int64_t total = (int64_t)B * per;
-    DISPATCH_T(dtype, hipLaunchKernelGGL((scale_add_kernel<T>), dim3(nblk(total / 4, 256)), dim3(256), 0,
+    DISPATCH_T(dtype, hipLaunchKernelGGL((scale_add_kernel<T>), dim3(nblk(total / 8, 256)), dim3(256), 0,
                                          (hipStream_t)stream, (const T*)x, (const T*)y, scale, keep, (T*)out, total, per));
     FOCUS_CHECK_LAUNCH();
     return FOCUS_OK;

@@ -19,32 +19,6 @@ __device__ __forceinline__ float dot64(const T* row, const float* q) {
     return s;
 }
 
-// 8 consecutive channels of a row as floats (one 16-byte load for bf16, two for fp32)
-template <typename T> __device__ __forceinline__ void ld8(const T* p, float (&f)[8]);
-template <> __device__ __forceinline__ void ld8<bf16_t>(const bf16_t* p, float (&f)[8]) {
-    const uint4 u = *reinterpret_cast<const uint4*>(p);
-    f[0] = __uint_as_float(u.x << 16); f[1] = __uint_as_float(u.x & 0xffff0000u);
-    f[2] = __uint_as_float(u.y << 16); f[3] = __uint_as_float(u.y & 0xffff0000u);
-    f[4] = __uint_as_float(u.z << 16); f[5] = __uint_as_float(u.z & 0xffff0000u);
-    f[6] = __uint_as_float(u.w << 16); f[7] = __uint_as_float(u.w & 0xffff0000u);
-}
-template <> __device__ __forceinline__ void ld8<float>(const float* p, float (&f)[8]) {
-    const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
-    f[0] = a.x; f[1] = a.y; f[2] = a.z; f[3] = a.w; f[4] = b.x; f[5] = b.y; f[6] = b.z; f[7] = b.w;
-}
-template <typename T> __device__ __forceinline__ void st8(T* p, const float (&f)[8]);
-template <> __device__ __forceinline__ void st8<bf16_t>(bf16_t* p, const float (&f)[8]) {
-    uint4 o;
-    o.x = (uint32_t)f32_to_bf16(f[0]) | ((uint32_t)f32_to_bf16(f[1]) << 16);
-    o.y = (uint32_t)f32_to_bf16(f[2]) | ((uint32_t)f32_to_bf16(f[3]) << 16);
-    o.z = (uint32_t)f32_to_bf16(f[4]) | ((uint32_t)f32_to_bf16(f[5]) << 16);
-    o.w = (uint32_t)f32_to_bf16(f[6]) | ((uint32_t)f32_to_bf16(f[7]) << 16);
-    *reinterpret_cast<uint4*>(p) = o;
-}
-template <> __device__ __forceinline__ void st8<float>(float* p, const float (&f)[8]) {
-    *reinterpret_cast<float4*>(p) = make_float4(f[0], f[1], f[2], f[3]);
-    *reinterpret_cast<float4*>(p + 4) = make_float4(f[4], f[5], f[6], f[7]);
-}
 // sum over the 8 lanes of a key group (lanes 8k .. 8k+7)
 __device__ __forceinline__ float group8_sum(float v) {
     v += __shfl_xor(v, 1, 64);
