@@ -268,9 +268,16 @@ focus_tn_plan focus_gemm_tn_ws_plan(int M, int N, int K) {
     static const int rounds_env = getenv("FOCUS_GEMM_TN_ROUNDS") ? atoi(getenv("FOCUS_GEMM_TN_ROUNDS")) : 0;
     focus_tn_plan p = {};
     if (!enabled || M < 128 || N < 128 || K < 2048) return p;
-    // the longer output side takes the 256 edge (fewer partial tiles hanging over the matrix edge)
-    const bool wide_i = (M >= N || N % 256 != 0) && M >= 256;
-    if (!wide_i && N < 256) return p;
+    // the longer output side takes the 256 edge (fewer partial tiles hanging over the matrix edge) -- unless the output is
+    // narrower than one 256 tile and the other orientation pads strictly less: [dk|dv]^T x of STEVE is 384 x 192, 4 tiles of 256 x 128 cover 512 x 256 (56 % useful
+    // MFMA work), 3 tiles of 128 x 256 cover 384 x 256 (75 %)
+    const int64_t pad1 = (int64_t)((M + 255) / 256 * 256) * ((N + 127) / 128 * 128);
+    const int64_t pad2 = (int64_t)((M + 127) / 128 * 128) * ((N + 255) / 256 * 256);
+    bool wide_i = (M >= N || N % 256 != 0) && M >= 256;
+    static const bool pad_rule = !(getenv("FOCUS_GEMM_TN_PAD_RULE") && atoi(getenv("FOCUS_GEMM_TN_PAD_RULE")) == 0);
+    // (only for N < 256: at 384 x 768, ORViT's patch_to_d gradient, the flip measured 0.6 % of the step slower)
+    if (wide_i && pad_rule && pad2 < pad1 && N < 256) wide_i = false;
+    if (!wide_i && N < 256 && !(pad2 < pad1)) return p;
     const int bi = wide_i ? 256 : 128, bj = wide_i ? 128 : 256;
     p.kind = wide_i ? 1 : 2;
     p.tiles_i = (M + bi - 1) / bi;

@@ -578,7 +578,9 @@ def test_tr16_probe_documents_transposed_lds_read():
 
 
 @pytest.mark.parametrize("shape", [(768, 384, 12552), (384, 768, 4104), (136, 264, 2500), (264, 136, 2055),
-                                   (2304, 768, 6280), (256, 256, 2048)])
+                                   (2304, 768, 6280), (256, 256, 2048),
+                                   # 128 x 256 tiles chosen because they pad less: STEVE's [dk|dv]^T x, and a ragged cousin
+                                   (384, 192, 8200), (392, 136, 4100)])
 def test_weight_grad_gemm_ws(shape):
     """dW = dY^T . X through the wave-specialised TN kernel (long reductions, ragged edges on every side) against
     an fp64 product of the same bf16 operands; the result is fp32 (exact products, fp32 accumulation order differs)."""
