@@ -276,3 +276,48 @@ def test_small_attention_one_launch(dtype, B, heads, N, M, d):
     assert _rel(out, ref.detach()) < tol
     for got, want in ((qg.grad, qr.grad), (kg.grad, kr.grad), (vg.grad, vr.grad)):
         assert _rel(got, want) < tol
+
+
+@pytest.mark.parametrize("defer", [False, True])
+def test_linear_qkv_feeds_the_one_launch_attention_in_place(defer):
+    """ops.linear_qkv -> ops.small_attention on the predictor's shapes (transformer.py:33-49): q | k | v are the column
+    blocks of one [rows, 3C] product, the attention reads them in place and returns its three gradients as the blocks of one
+    matrix again, so d(x) is one product.  Against fp64 on the same bf16 values, weight gradients immediate and deferred."""
+    from focus_amd import ops
+    d = dev()
+    g = torch.Generator().manual_seed(21)
+    B, N, C, heads = 32, 11, 192, 4
+    x = torch.randn(B, N, C, generator=g).bfloat16()
+    ws = [torch.randn(C, C, generator=g) * C ** -0.5 for _ in range(3)]
+    ct = torch.randn(B, N, C, generator=g).bfloat16()
+    scale = (C // heads) ** -0.5
+    xr = x.double().requires_grad_()
+    wr = [w.bfloat16().double().requires_grad_() for w in ws]
+
+    def split(t):
+        return t.view(B, N, heads, C // heads).transpose(1, 2)
+
+    qr, kr, vr = (xr @ w.t() for w in wr)
+    att = torch.softmax(scale * split(qr) @ split(kr).transpose(-1, -2), dim=-1)
+    ref = (att @ split(vr)).transpose(1, 2).reshape(B, N, C)
+    (ref * ct.double()).sum().backward()
+    xg = x.to(d).requires_grad_()
+    wg = [w.to(d).requires_grad_() for w in ws]
+
+    def run():
+        q, k, v = ops.linear_qkv(xg, *wg)
+        assert q.stride() == (N * 3 * C, 3 * C, 1) and k.data_ptr() == q.data_ptr() + 2 * C       # column blocks of one buffer
+        out = ops.small_attention(q, k, v, heads, scale)
+        (out.float() * ct.to(d).float()).sum().backward()
+        return out
+
+    if defer:
+        with ops.deferred_wgrads():
+            out = run()
+    else:
+        out = run()
+    torch.cuda.synchronize()
+    assert _rel(out, ref.detach()) < 2 ** -6
+    assert _rel(xg.grad, xr.grad) < 2 ** -5
+    for got, want in zip(wg, wr):
+        assert got.grad is not None and _rel(got.grad, want.grad) < 2 ** -5
