@@ -51,9 +51,52 @@ __global__ __launch_bounds__(256) void layout_fwd_kernel(const T* __restrict__ v
     }
 }
 
-// grid (O, NF): dvec[n,o,:] = sum_{y,x} wy*wx*dout[n,y,x,:]
+// grid (O, NF): dvec[n,o,:] = sum_{y,x} wy*wx*dout[n,y,x,:].  384 threads = up to 96 channel octets (16-byte loads) x 4
+// cell groups that meet in LDS.  (One thread per 4 channels walking all H*W cells by itself took 63 us for 19 MB.)
+constexpr int LB_GROUPS = 4, LB_OCT = 96;
 template <typename T>
-__global__ __launch_bounds__(256) void layout_bwd_kernel(const T* __restrict__ dout, const float* __restrict__ boxes,
+__global__ __launch_bounds__(LB_GROUPS * LB_OCT) void layout_bwd_kernel(const T* __restrict__ dout, const float* __restrict__ boxes,
+                                                                     T* __restrict__ dvecs, int O, int C, int H, int W) {
+    __shared__ float wy[64], wx[64];
+    __shared__ float red[LB_GROUPS][LB_OCT * 8];
+    const int n = blockIdx.y, o = blockIdx.x;
+    const BoxW b = box_xyxy(boxes + ((int64_t)n * O + o) * 4);
+    for (int i = threadIdx.x; i < H + W; i += LB_GROUPS * LB_OCT) {
+        if (i < H) wy[i] = b.keep ? wfun((lin(i, H) - b.y0) / b.y1) : 0.f;
+        else wx[i - H] = b.keep ? wfun((lin(i - H, W) - b.x0) / b.x1) : 0.f;
+    }
+    __syncthreads();
+    const int oct = threadIdx.x % LB_OCT, grp = threadIdx.x / LB_OCT, noct = C >> 3;
+    for (int c0 = 0; c0 < noct; c0 += LB_OCT) {                    // (one pass for C <= 768)
+        const int c = (c0 + oct) * 8;
+        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (c0 + oct < noct) {
+            for (int cell = grp; cell < H * W; cell += LB_GROUPS) {
+                const int y = cell / W, x = cell - y * W;
+                const float w = wy[y] * wx[x];
+                if (w == 0.f) continue;
+                float v[8];
+                ld8<T>(dout + (((int64_t)n * H + y) * W + x) * C + c, v);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[e] = fmaf(w, v[e], acc[e]);
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) red[grp][oct * 8 + e] = acc[e];
+        __syncthreads();
+        if (grp == 0 && c0 + oct < noct) {
+            float t[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) t[e] = red[0][oct * 8 + e] + red[1][oct * 8 + e] + red[2][oct * 8 + e] + red[3][oct * 8 + e];
+            st8<T>(dvecs + ((int64_t)n * O + o) * C + c, t);
+        }
+        __syncthreads();
+    }
+}
+
+// any C % 4 == 0 / alignment: one thread per 4 channels (grid (O, NF))
+template <typename T>
+__global__ __launch_bounds__(256) void layout_bwd_scalar_kernel(const T* __restrict__ dout, const float* __restrict__ boxes,
                                                          T* __restrict__ dvecs, int O, int C, int H, int W) {
     __shared__ float wy[64], wx[64];
     const int n = blockIdx.y, o = blockIdx.x;
@@ -104,11 +147,18 @@ extern "C" int focus_box_layout_bwd(const void* dout, const float* boxes, void* 
     if (NF <= 0 || O <= 0) return FOCUS_OK;
     if ((C & 3) || O > MAXO || W > 64 || H > 64 || NF > 65535) return FOCUS_ERR_SHAPE;
     dim3 grid(O, NF);
-    if (dtype == FOCUS_BF16)
-        hipLaunchKernelGGL((layout_bwd_kernel<bf16_t>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dout,
+    const bool wide = (C & 7) == 0 && focus_aligned(dout, 16) && focus_aligned(dvecs, 16);
+    if (wide && dtype == FOCUS_BF16)
+        hipLaunchKernelGGL((layout_bwd_kernel<bf16_t>), grid, dim3(LB_GROUPS * LB_OCT), 0, (hipStream_t)stream,
+                           (const bf16_t*)dout, boxes, (bf16_t*)dvecs, O, C, H, W);
+    else if (wide)
+        hipLaunchKernelGGL((layout_bwd_kernel<float>), grid, dim3(LB_GROUPS * LB_OCT), 0, (hipStream_t)stream,
+                           (const float*)dout, boxes, (float*)dvecs, O, C, H, W);
+    else if (dtype == FOCUS_BF16)
+        hipLaunchKernelGGL((layout_bwd_scalar_kernel<bf16_t>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dout,
                            boxes, (bf16_t*)dvecs, O, C, H, W);
     else
-        hipLaunchKernelGGL((layout_bwd_kernel<float>), grid, dim3(256), 0, (hipStream_t)stream, (const float*)dout,
+        hipLaunchKernelGGL((layout_bwd_scalar_kernel<float>), grid, dim3(256), 0, (hipStream_t)stream, (const float*)dout,
                            boxes, (float*)dvecs, O, C, H, W);
     FOCUS_CHECK_LAUNCH();
     return FOCUS_OK;

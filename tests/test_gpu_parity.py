@@ -511,6 +511,16 @@ def test_box_layout(oracle, dtype):
     ref = oracle.box_layout(vv, bx, 14, 14)
     got = ops.box_layout(vv.to(d, dtype).reshape(6, 4, 16), bx.to(d).reshape(6, 4, 4), 14, 14)
     close(got.view(3, 2, 14, 14, 16), ref, tol, "layout 14x14")
+    # backward at channel counts that take one full pass, a ragged second pass (97 octets) and the scalar kernel (C % 8 != 0)
+    for Cc in (768, 776, 12):
+        vv = torch.randn(3, 2, 4, Cc, generator=g)
+        ct = torch.randn(3, 2, 14, 14, Cc, generator=g)
+        vr = vv.clone().requires_grad_()
+        (oracle.box_layout(vr, bx, 14, 14) * ct).sum().backward()
+        vg2 = vv.to(d, dtype).reshape(6, 4, Cc).requires_grad_()
+        o2 = ops.box_layout(vg2, bx.to(d).reshape(6, 4, 4), 14, 14)
+        (o2.float().view(3, 2, 14, 14, Cc) * ct.to(d)).sum().backward()
+        close(vg2.grad.view(3, 2, 4, Cc), vr.grad, tol, "layout dvecs C=%d" % Cc)
 
 
 # ------------------------------------------------------------------------------------------------
