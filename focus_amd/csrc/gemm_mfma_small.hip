@@ -56,6 +56,24 @@ __global__ __launch_bounds__(256) void gemm_nt_small_kernel(const focus_gemm_des
             fb[s][i] = *reinterpret_cast<const bf16x8*>(brow[i] + ks);
         }
     }
+    // the epilogue's own operands (bias, residual, saved activation of the sub-tile this wave finishes) are requested now,
+    // together with the fragments: after the LDS combine they would be a second, fully exposed round trip
+    const int gm = m0 + 16 * (w >> 1) + frow, gn = n0 + 16 * (w & 1) + 4 * fq;
+    const bool live = gm < d.M && gn < d.N;
+    const int64_t off = (int64_t)gm * d.rsC + gn;                 // csC == 1 (checked by the dispatcher)
+    const bool full = gn + 3 < d.N && ((d.rsC & 3) == 0);
+    float xs[4] = {0.f, 0.f, 0.f, 0.f}, bs[4] = {0.f, 0.f, 0.f, 0.f}, rs[4] = {0.f, 0.f, 0.f, 0.f};
+    if (live) {
+        for (int r = 0; r < 4; ++r) {
+            if (gn + r >= d.N) break;
+            if (d.bias) bs[r] = d.bias[gn + r];
+            if constexpr (EPI >= FOCUS_EPI_DGELU) xs[r] = ld<TC>(X + off + r);
+        }
+        if (R) {
+            if (full) { const f4 rr = ld4<TC>(R + off); rs[0] = rr.x; rs[1] = rr.y; rs[2] = rr.z; rs[3] = rr.w; }
+            else for (int r = 0; r < 4 && gn + r < d.N; ++r) rs[r] = ld<TC>(R + off + r);
+        }
+    }
     f32x4 acc[2][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -84,19 +102,11 @@ __global__ __launch_bounds__(256) void gemm_nt_small_kernel(const focus_gemm_des
         const float4 p = *reinterpret_cast<const float4*>(&part[ww][w][lane][0]);
         v[0] += p.x; v[1] += p.y; v[2] += p.z; v[3] += p.w;
     }
-    const int gm = m0 + 16 * (w >> 1) + frow, gn = n0 + 16 * (w & 1) + 4 * fq;
-    if (gm >= d.M || gn >= d.N) return;
-    const int64_t off = (int64_t)gm * d.rsC + gn;                 // csC == 1 (checked by the dispatcher)
-    const bool full = gn + 3 < d.N && ((d.rsC & 3) == 0);
-    float xs[4] = {0.f, 0.f, 0.f, 0.f}, pre[4];
-    if constexpr (EPI >= FOCUS_EPI_DGELU) {
-        for (int r = 0; r < 4; ++r)
-            if (gn + r < d.N) xs[r] = ld<TC>(X + off + r);
-    }
+    if (!live) return;
+    float pre[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        float t = d.alpha * v[r];
-        if (d.bias && gn + r < d.N) t += d.bias[gn + r];
+        float t = d.alpha * v[r] + bs[r];
         pre[r] = t;
         if constexpr (EPI == FOCUS_EPI_GELU) t = gelu_erf(t);
         else if constexpr (EPI == FOCUS_EPI_RELU) t = fmaxf(t, 0.f);
@@ -104,19 +114,16 @@ __global__ __launch_bounds__(256) void gemm_nt_small_kernel(const focus_gemm_des
         else if constexpr (EPI == FOCUS_EPI_DGELU) t *= dgelu_erf(xs[r]);
         else if constexpr (EPI == FOCUS_EPI_DRELU) t = xs[r] > 0.f ? t : 0.f;
         else if constexpr (EPI == FOCUS_EPI_DTANH) t *= (1.f - xs[r] * xs[r]);
-        v[r] = t;
+        v[r] = t + rs[r];
     }
     if (full) {
         if constexpr (EPI == FOCUS_EPI_GELU) { if (X) st4<TC>(X + off, (f4){pre[0], pre[1], pre[2], pre[3]}); }
-        if (R) { const f4 rr = ld4<TC>(R + off); v[0] += rr.x; v[1] += rr.y; v[2] += rr.z; v[3] += rr.w; }
         st4<TC>(C + off, (f4){v[0], v[1], v[2], v[3]});
     } else {
         for (int r = 0; r < 4; ++r) {
             if (gn + r >= d.N) break;
             if constexpr (EPI == FOCUS_EPI_GELU) { if (X) st<TC>(X + off + r, pre[r]); }
-            float t = v[r];
-            if (R) t += ld<TC>(R + off + r);
-            st<TC>(C + off + r, t);
+            st<TC>(C + off + r, v[r]);
         }
     }
 }
