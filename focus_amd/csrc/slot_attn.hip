@@ -97,17 +97,19 @@ __global__ __launch_bounds__(256) void slot_fwd_kernel(const T* __restrict__ kt,
 // launch" ticket protocol -- was measured and dropped: with agent-scope release fences every one of the 512 workgroups
 // writes the L2 back, 22 -> 68 us per launch; with write-through (sc1) partial stores and no fences the single reducing
 // workgroup reads its 135 KB through dependent sc1 round trips, 22 -> 51 us.  The separate launch below costs 6 us.)
-// grid (K, B), 256 threads = 64 channel lanes x 4 chunk lanes: reduce the partials over the chunks, normalise.  (With 64
+// grid (K, B), 64 channel lanes x FIN_CL chunk lanes: reduce the partials over the chunks, normalise.  (With 64
 // threads walking the chunks one after the other the launch was a chain of dependent L2 round trips: 16.6 us for 16
 // chunks; here every thread's loads are independent and the four chunk lanes meet in LDS.)
+constexpr int FIN_CL = 16;      // chunk lanes of the finish kernels: 64 channel lanes x 16 chunk lanes = 1024 threads, so
+                                // that with <= 16 chunks every load of the launch is issued at once (one round trip)
 template <typename T>
-__global__ __launch_bounds__(256) void slot_fwd_finish(const float* __restrict__ partial, T* __restrict__ upd,
-                                                       float* __restrict__ colsum, int nchunk, int K, int D) {
-    __shared__ float red[4][4][64], redc[4];
+__global__ __launch_bounds__(64 * FIN_CL) void slot_fwd_finish(const float* __restrict__ partial, T* __restrict__ upd,
+                                                               float* __restrict__ colsum, int nchunk, int K, int D) {
+    __shared__ float red[FIN_CL][4][64], redc[FIN_CL];
     const int k = blockIdx.x, b = blockIdx.y, lane = threadIdx.x & 63, cl = threadIdx.x >> 6;
     const float* p = partial + (int64_t)b * nchunk * K * (D + 1) + (int64_t)k * (D + 1);
     float s[4] = {0.f, 0.f, 0.f, 0.f}, c = 0.f;
-    for (int ch = cl; ch < nchunk; ch += 4) {
+    for (int ch = cl; ch < nchunk; ch += FIN_CL) {
         const float* pc = p + (int64_t)ch * K * (D + 1);
 #pragma unroll
         for (int j = 0; j < 4; ++j)
@@ -118,13 +120,18 @@ __global__ __launch_bounds__(256) void slot_fwd_finish(const float* __restrict__
     for (int j = 0; j < 4; ++j) red[cl][j][lane] = s[j];
     if (lane == 0) redc[cl] = c;
     __syncthreads();
-    if (cl == 0) {
-        c = redc[0] + redc[1] + redc[2] + redc[3];
-        if (lane == 0) colsum[b * K + k] = c;
+    if (cl < 4) {                       // wave j of the first four sums channel block j over the chunk lanes
+        const int j = cl;
+        c = 0.f;
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-            if (lane + 64 * j < D)
-                st<T>(upd + ((int64_t)b * K + k) * D + lane + 64 * j, (red[0][j][lane] + red[1][j][lane] + red[2][j][lane] + red[3][j][lane]) / c);
+        for (int q = 0; q < FIN_CL; ++q) c += redc[q];
+        if (j == 0 && lane == 0) colsum[b * K + k] = c;
+        if (lane + 64 * j < D) {
+            float t = 0.f;
+#pragma unroll
+            for (int q = 0; q < FIN_CL; ++q) t += red[q][j][lane];
+            st<T>(upd + ((int64_t)b * K + k) * D + lane + 64 * j, t / c);
+        }
     }
 }
 
@@ -238,12 +245,12 @@ __global__ __launch_bounds__(256) void slot_bwd_kernel(const T* __restrict__ kt,
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void slot_bwd_finish(const float* __restrict__ partial, T* __restrict__ dq, int nchunk, int K,
-                                                       int D) {
-    __shared__ float red[4][4][64];
+__global__ __launch_bounds__(64 * FIN_CL) void slot_bwd_finish(const float* __restrict__ partial, T* __restrict__ dq, int nchunk,
+                                                               int K, int D) {
+    __shared__ float red[FIN_CL][4][64];
     const int k = blockIdx.x, b = blockIdx.y, lane = threadIdx.x & 63, cl = threadIdx.x >> 6;
     float s[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int ch = cl; ch < nchunk; ch += 4) {
+    for (int ch = cl; ch < nchunk; ch += FIN_CL) {
         const float* pc = partial + (((int64_t)b * nchunk + ch) * K + k) * D;
 #pragma unroll
         for (int j = 0; j < 4; ++j)
@@ -252,11 +259,11 @@ __global__ __launch_bounds__(256) void slot_bwd_finish(const float* __restrict__
 #pragma unroll
     for (int j = 0; j < 4; ++j) red[cl][j][lane] = s[j];
     __syncthreads();
-    if (cl == 0) {
+    if (cl < 4 && lane + 64 * cl < D) {
+        float t = 0.f;
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-            if (lane + 64 * j < D)
-                st<T>(dq + ((int64_t)b * K + k) * D + lane + 64 * j, red[0][j][lane] + red[1][j][lane] + red[2][j][lane] + red[3][j][lane]);
+        for (int q = 0; q < FIN_CL; ++q) t += red[q][cl][lane];
+        st<T>(dq + ((int64_t)b * K + k) * D + lane + 64 * cl, t);
     }
 }
 
@@ -938,7 +945,7 @@ extern "C" int focus_slot_attn_fwd(const void* k_t, const void* v_t, int64_t kv_
 #undef SFM
 #undef SFM_
         FOCUS_CHECK_LAUNCH();
-        hipLaunchKernelGGL((slot_fwd_finish<bf16_t>), dim3(K, B), dim3(256), 0, s, (const float*)partial, (bf16_t*)upd, colsum,
+        hipLaunchKernelGGL((slot_fwd_finish<bf16_t>), dim3(K, B), dim3(64 * FIN_CL), 0, s, (const float*)partial, (bf16_t*)upd, colsum,
                            nchunks_mfma(N), K, D);
         FOCUS_CHECK_LAUNCH();
         return FOCUS_OK;
@@ -961,10 +968,10 @@ extern "C" int focus_slot_attn_fwd(const void* k_t, const void* v_t, int64_t kv_
 #undef SLOT_CASE
     FOCUS_CHECK_LAUNCH();
     if (dtype == FOCUS_BF16)
-        hipLaunchKernelGGL((slot_fwd_finish<bf16_t>), dim3(K, B), dim3(256), 0, s, (const float*)partial, (bf16_t*)upd,
+        hipLaunchKernelGGL((slot_fwd_finish<bf16_t>), dim3(K, B), dim3(64 * FIN_CL), 0, s, (const float*)partial, (bf16_t*)upd,
                            colsum, nchunks(N), K, D);
     else
-        hipLaunchKernelGGL((slot_fwd_finish<float>), dim3(K, B), dim3(256), 0, s, (const float*)partial, (float*)upd,
+        hipLaunchKernelGGL((slot_fwd_finish<float>), dim3(K, B), dim3(64 * FIN_CL), 0, s, (const float*)partial, (float*)upd,
                            colsum, nchunks(N), K, D);
     FOCUS_CHECK_LAUNCH();
     return FOCUS_OK;
@@ -994,7 +1001,7 @@ extern "C" int focus_slot_attn_bwd(const void* k_t, const void* v_t, int64_t kv_
 #undef SBM
 #undef SBD
         FOCUS_CHECK_LAUNCH();
-        hipLaunchKernelGGL((slot_bwd_finish<bf16_t>), dim3(K, B), dim3(256), 0, s, (const float*)partial, (bf16_t*)dq,
+        hipLaunchKernelGGL((slot_bwd_finish<bf16_t>), dim3(K, B), dim3(64 * FIN_CL), 0, s, (const float*)partial, (bf16_t*)dq,
                            nchunks_mfma(N), K, D);
         FOCUS_CHECK_LAUNCH();
         return FOCUS_OK;
@@ -1019,10 +1026,10 @@ extern "C" int focus_slot_attn_bwd(const void* k_t, const void* v_t, int64_t kv_
 #undef SLOT_CASE
     FOCUS_CHECK_LAUNCH();
     if (dtype == FOCUS_BF16)
-        hipLaunchKernelGGL((slot_bwd_finish<bf16_t>), dim3(K, B), dim3(256), 0, s, (const float*)partial, (bf16_t*)dq,
+        hipLaunchKernelGGL((slot_bwd_finish<bf16_t>), dim3(K, B), dim3(64 * FIN_CL), 0, s, (const float*)partial, (bf16_t*)dq,
                            nchunks(N), K, D);
     else
-        hipLaunchKernelGGL((slot_bwd_finish<float>), dim3(K, B), dim3(256), 0, s, (const float*)partial, (float*)dq,
+        hipLaunchKernelGGL((slot_bwd_finish<float>), dim3(K, B), dim3(64 * FIN_CL), 0, s, (const float*)partial, (float*)dq,
                            nchunks(N), K, D);
     FOCUS_CHECK_LAUNCH();
     return FOCUS_OK;
