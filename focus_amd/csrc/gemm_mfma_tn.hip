@@ -186,6 +186,7 @@ __global__ void tn_reduce_kernel(const float* __restrict__ parts, float* __restr
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n4) return;
     float4 s = reinterpret_cast<const float4*>(parts)[i];
+#pragma unroll 4                                                      // (four slab loads in flight: left rolled, each waits for the last)
     for (int k = 1; k < splits; ++k) {
         const float4 v = reinterpret_cast<const float4*>(parts)[(int64_t)k * n4 + i];
         s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
@@ -266,6 +267,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
         const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
         if (i >= n4) return;
         float4 s = reinterpret_cast<const float4*>(parts)[i];
+#pragma unroll 4
         for (int k = 1; k < splits; ++k) {
             const float4 v = reinterpret_cast<const float4*>(parts)[(int64_t)k * n4 + i];
             s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
@@ -279,6 +281,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     const int col = ((int)blockIdx.x - nb_main) * 16 + c;
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
     if (col < bn4)
+#pragma unroll 4
         for (int r = rr; r < brows; r += 16) {
             const float4 v = reinterpret_cast<const float4*>(bparts)[(int64_t)r * bn4 + col];
             s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;

@@ -157,8 +157,10 @@ __global__ __launch_bounds__(1024) void ln_bwd_finish(const float* __restrict__ 
     const int c = blockIdx.x * 64 + cl;
     const float* p = partial + (int64_t)blockIdx.y * nblk * D;
     float a = 0.f;
-    if (c < D)
+    if (c < D) {
+#pragma unroll 8                                                      // (eight partial rows in flight per thread)
         for (int k = rl; k < nblk; k += 16) a += p[(int64_t)k * D + c];
+    }
     red[rl][cl] = a;
     __syncthreads();
     if (rl == 0 && c < D) {
