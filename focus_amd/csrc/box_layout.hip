@@ -52,7 +52,7 @@ __global__ __launch_bounds__(256) void layout_fwd_kernel(const T* __restrict__ v
 }
 
 // grid (O, NF): dvec[n,o,:] = sum_{y,x} wy*wx*dout[n,y,x,:].  384 threads = up to 96 channel octets (16-byte loads) x 4
-// cell groups that meet in LDS.  (One thread per 4 channels walking all H*W cells by itself took 63 us for 19 MB.)
+// row groups that meet in LDS.  (One thread per 4 channels walking all H*W cells by itself took 63 us for 19 MB.)
 constexpr int LB_GROUPS = 4, LB_OCT = 96;
 template <typename T>
 __global__ __launch_bounds__(LB_GROUPS * LB_OCT) void layout_bwd_kernel(const T* __restrict__ dout, const float* __restrict__ boxes,
@@ -71,14 +71,20 @@ __global__ __launch_bounds__(LB_GROUPS * LB_OCT) void layout_bwd_kernel(const T*
         const int c = (c0 + oct) * 8;
         float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         if (c0 + oct < noct) {
-            for (int cell = grp; cell < H * W; cell += LB_GROUPS) {
-                const int y = cell / W, x = cell - y * W;
-                const float w = wy[y] * wx[x];
-                if (w == 0.f) continue;
-                float v[8];
-                ld8<T>(dout + (((int64_t)n * H + y) * W + x) * C + c, v);
+            // group grp takes the rows y = grp, grp + 4, ...; a row without weight is skipped by the whole workgroup's group
+            // (the box is the same for all of it), a row with weight is read whole, its loads in flight together
+            for (int y = grp; y < H; y += LB_GROUPS) {
+                const float wrow = wy[y];
+                if (wrow == 0.f) continue;
+                const T* rowp = dout + (((int64_t)n * H + y) * W) * C + c;
+#pragma unroll 7
+                for (int x = 0; x < W; ++x) {
+                    float v[8];
+                    ld8<T>(rowp + (int64_t)x * C, v);
+                    const float w = wrow * wx[x];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) acc[e] = fmaf(w, v[e], acc[e]);
+                    for (int e = 0; e < 8; ++e) acc[e] = fmaf(w, v[e], acc[e]);
+                }
             }
         }
 #pragma unroll

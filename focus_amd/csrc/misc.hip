@@ -272,6 +272,7 @@ __global__ __launch_bounds__(256) void cell_amax_fwd_vec_kernel(const bf16_t* __
     int a[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) { m[e] = -INFINITY; a[e] = 0x7fffffff; }
+#pragma unroll 5                                                      // (five cell rows in flight per thread)
     for (int j = ph; j < cells; j += 8) {
         const uint4 r = *reinterpret_cast<const uint4*>(p + (int64_t)j * C);
         const float v[8] = {__uint_as_float(r.x << 16), __uint_as_float(r.x & 0xffff0000u), __uint_as_float(r.y << 16),
