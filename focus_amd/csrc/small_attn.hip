@@ -52,6 +52,7 @@ __global__ __launch_bounds__(NT) void small_attn_fwd_kernel(const T* __restrict_
     for (int e = lane; e < N * M; e += NT) {
         const int i = e / M, j = e - i * M;
         float a = 0.f;
+#pragma unroll 8
         for (int c = 0; c < d; ++c) a = fmaf(L.q[i][c], L.k[j][c], a);
         L.s[i][j] = a * scale;
     }
@@ -73,6 +74,7 @@ __global__ __launch_bounds__(NT) void small_attn_fwd_kernel(const T* __restrict_
     for (int e = lane; e < N * d; e += NT) {
         const int i = e / d, c = e - i * d;
         float a = 0.f;
+#pragma unroll 4
         for (int j = 0; j < M; ++j) a = fmaf(L.s[i][j], L.v[j][c], a);
         st<T>(ob + (int64_t)i * C + c, a);
     }
@@ -102,12 +104,14 @@ __global__ __launch_bounds__(NT) void small_attn_bwd_kernel(const T* __restrict_
     for (int e = lane; e < M * d; e += NT) {
         const int j = e / d, c = e - j * d;
         float a = 0.f;
+#pragma unroll 4
         for (int i = 0; i < N; ++i) a = fmaf(L.s[i][j], L.o[i][c], a);
         st<T>(dv + vo + (int64_t)j * ldv + c, a);
     }
     for (int e = lane; e < N * M; e += NT) {
         const int i = e / M, j = e - i * M;
         float a = 0.f;
+#pragma unroll 8
         for (int c = 0; c < d; ++c) a = fmaf(L.o[i][c], L.v[j][c], a);
         L.t[i][j] = a;
     }
@@ -121,12 +125,14 @@ __global__ __launch_bounds__(NT) void small_attn_bwd_kernel(const T* __restrict_
     for (int e = lane; e < N * d; e += NT) {             // dq = dS k
         const int i = e / d, c = e - i * d;
         float a = 0.f;
+#pragma unroll 4
         for (int j = 0; j < M; ++j) a = fmaf(L.t[i][j], L.k[j][c], a);
         st<T>(dq + qo + (int64_t)i * ldq + c, a);
     }
     for (int e = lane; e < M * d; e += NT) {             // dk = dS^T q
         const int j = e / d, c = e - j * d;
         float a = 0.f;
+#pragma unroll 4
         for (int i = 0; i < N; ++i) a = fmaf(L.t[i][j], L.q[i][c], a);
         st<T>(dk + ko + (int64_t)j * ldk + c, a);
     }
