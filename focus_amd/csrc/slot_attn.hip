@@ -824,6 +824,7 @@ __global__ __launch_bounds__(256) void slot_kv_grad_kernel(const KvGradArgs a, i
     // row blocks, so the transpose is amortised over 512 rows)
     // (the stacked slot is the fastest index over the lanes: a wave's 64 two-byte writes of one j land in one image row,
     // two lanes per dword; with the channel group fastest all 64 lanes hit one bank, 288 dwords apart)
+#pragma unroll 4                                                      // (four slot-row loads in flight; rolled, 12 round trips in a row)
     for (int e = tid; e < 2 * 64 * (D / 8); e += 256) {
         const int sl = e & 63, rest = e >> 6, d8 = rest % (D / 8), m = rest / (D / 8);
         const int i = sl >> 4, k = sl & 15;
