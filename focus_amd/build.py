@@ -83,6 +83,35 @@ def _compile(src, headers):
     return obj
 
 
+def source_hash():
+    """sha1 (12 hex digits) over the kernel sources and the public header: identifies WHICH kernels a build or a
+    profile belongs to (bench.py only quotes PMC traffic recorded for the sources it is running)."""
+    import hashlib
+    h = hashlib.sha1()
+    for f in sorted(glob.glob(os.path.join(CSRC, "*.hip")) + glob.glob(os.path.join(CSRC, "*.h"))) + [
+            os.path.join(HERE, "..", "include", "focus_amd.h")]:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:12]
+
+
+def _stamp():
+    """focus_amd/lib/BUILD_HEAD: `<git head>[-dirty] src:<source_hash>` of the tree the library was built from (.git does
+    not travel to the GPU box; this sidecar does)."""
+    root = os.path.join(HERE, "..")
+    head = "nogit"
+    try:
+        head = subprocess.run(["git", "-C", root, "rev-parse", "--short", "HEAD"], capture_output=True, text=True,
+                              check=True).stdout.strip()
+        if subprocess.run(["git", "-C", root, "status", "--porcelain", "--", "focus_amd/csrc", "include"],
+                          capture_output=True, text=True).stdout.strip():
+            head += "-dirty"
+    except Exception:
+        pass
+    with open(os.path.join(HERE, "lib", "BUILD_HEAD"), "w") as f:
+        f.write("%s src:%s\n" % (head, source_hash()))
+
+
 def build(force=False, verbose=True):
     os.makedirs(OBJ, exist_ok=True)
     srcs = sorted(glob.glob(os.path.join(CSRC, "*.hip")))
@@ -94,6 +123,8 @@ def build(force=False, verbose=True):
         objs = list(ex.map(lambda s: _compile(s, headers), srcs))
     if _stale(LIB, objs):
         subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs)
+    if os.path.isdir(os.path.join(HERE, "..", ".git")):
+        _stamp()
     if verbose:
         print("built", LIB)
     return LIB
