@@ -30,7 +30,7 @@ class GemmDesc(ctypes.Structure):
 
 
 _CTYPE = {"int": ctypes.c_int, "int32_t": ctypes.c_int32, "int64_t": ctypes.c_int64,
-          "size_t": ctypes.c_size_t, "float": ctypes.c_float}
+          "size_t": ctypes.c_size_t, "float": ctypes.c_float, "double": ctypes.c_double}
 
 
 def parse_header(path=HEADER):

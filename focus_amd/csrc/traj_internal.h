@@ -19,3 +19,20 @@ int focus_traj_cls_bwd(const void* qkv, const float* cls_lse, const void* dcls, 
                        int heads, int dtype, hipStream_t s);   // scratch: 2*B*heads*N floats
 // re-associated temporal step (traj_time2.hip)
 bool focus_traj_time2_ok(int F, int heads, int d, int dtype);
+
+#ifdef __HIPCC__
+// Workgroups that share blockIdx.y (one (batch, head)) read the same K / V / Q panels.  The dispatcher deals consecutive
+// linear workgroup ids round-robin over the 8 XCDs, so the gridDim.x workgroups of one (b, h) land on up to 8 different L2s
+// and each fetches the panels from HBM again (PMC: traj_dq 506 MB per launch against ~215 MB algorithmic).  This remap gives
+// every XCD a contiguous range of the linear ids instead: all workgroups of a (b, h) on one XCD, panels fetched once.
+// Placement is a speed matter only (MI355X_MICROARCH.md, Workgroup dispatch): any assignment computes the same result.
+__device__ __forceinline__ void focus_xcd_group(int& bx, int& by) {
+    const int gx = gridDim.x, total = gx * gridDim.y;
+    const int id = blockIdx.x + gx * blockIdx.y;
+    const int xcd = id & 7, slot = id >> 3;
+    const int q = total >> 3, r = total & 7;
+    const int v = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+    by = v / gx;
+    bx = v - by * gx;
+}
+#endif

@@ -134,10 +134,12 @@ __global__ __launch_bounds__(256, 2) void traj_dq_kernel(const bf16_t* __restric
 
     const int S = F * P, N = S + 1, C = heads * HD;
     const int64_t tok = 3 * (int64_t)C;
-    const int bh = blockIdx.y, b = bh / heads, hh = bh % heads;
+    int bx, bh;
+    focus_xcd_group(bx, bh);                                   // the query tiles of one (b, h) share an XCD's L2
+    const int b = bh / heads, hh = bh % heads;
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
-    const int s_raw = blockIdx.x * QT + w * 32 + r;
+    const int s_raw = bx * QT + w * 32 + r;
     const bool q_valid = s_raw < S;
     const int s_q = min(s_raw, S - 1);
     const bf16_t* base = qkv + (int64_t)b * N * tok + hh * HD;
@@ -158,7 +160,7 @@ __global__ __launch_bounds__(256, 2) void traj_dq_kernel(const bf16_t* __restric
     auto dma_dx = [&](int f) __attribute__((always_inline)) {            // this wave's 32 dX rows of frame f
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            const int s = min(blockIdx.x * QT + w * 32 + g * 8 + drow, S - 1);
+            const int s = min(bx * QT + w * 32 + g * 8 + drow, S - 1);
             const bool own = s >= f * P && s < (f + 1) * P;
             const bf16_t* rowp = own ? dxsum + ((int64_t)b * S + s) * C : dxt + (((int64_t)b * S + s) * F + f) * C;
             glds16(rowp + hh * HD + ((dchunk ^ (dkey | (g & 1))) << 3), __builtin_amdgcn_readfirstlane(dx_a + g * 1024));
@@ -271,7 +273,7 @@ __global__ __launch_bounds__(256, 2) void traj_dq_kernel(const bf16_t* __restric
         const int row = p4 * 8 + (lane >> 3), q8 = lane & 7;
         uint4 raw = *reinterpret_cast<const uint4*>(slab + row * 128 + ((q8 ^ ((row & 15) >> 1)) << 4));
         if (row & 1) { const uint32_t a0 = raw.x, a1 = raw.y; raw.x = raw.z; raw.y = raw.w; raw.z = a0; raw.w = a1; }
-        const int s_row = blockIdx.x * QT + w * 32 + row;
+        const int s_row = bx * QT + w * 32 + row;
         if (s_row < S)
             *reinterpret_cast<uint4*>(dqkv + ((int64_t)b * N + 1 + s_row) * tok + hh * HD + q8 * 8) = raw;
     }
@@ -294,7 +296,9 @@ __global__ __launch_bounds__(64 * NKB) void traj_dkv_kernel(const bf16_t* __rest
     const int S = F * P, N = S + 1, C = heads * HD;
     const int64_t tok = 3 * (int64_t)C;
     // workgroup = key tile jt (NKB blocks of 32 keys) of frame f; a frame has NT tiles (1 unless P > 224)
-    const int f = blockIdx.x / NT, jt = blockIdx.x - f * NT, bh = blockIdx.y, b = bh / heads, hh = bh % heads;
+    int bx, bh;
+    focus_xcd_group(bx, bh);                                   // the (frame, key tile) workgroups of one (b, h) share an L2
+    const int f = bx / NT, jt = bx - f * NT, b = bh / heads, hh = bh % heads;
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
     const bf16_t* base = qkv + (int64_t)b * N * tok + hh * HD;

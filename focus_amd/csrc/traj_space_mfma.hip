@@ -66,11 +66,13 @@ __global__ __launch_bounds__(256, 2) void traj_space_fwd_kernel(const bf16_t* __
 
     const int S = F * P, N = S + 1, C = heads * HD;
     const int64_t tok = 3 * (int64_t)C;
-    const int bh = blockIdx.y, b = bh / heads, hh = bh % heads;
+    int bx, bh;
+    focus_xcd_group(bx, bh);                                   // the query tiles of one (b, h) share an XCD's L2
+    const int b = bh / heads, hh = bh % heads;
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
-    const int s_q = min(blockIdx.x * QT + w * 32 + r, S - 1);  // this lane's query (clamped)
-    const bool q_valid = blockIdx.x * QT + w * 32 + r < S;
+    const int s_q = min(bx * QT + w * 32 + r, S - 1);  // this lane's query (clamped)
+    const bool q_valid = bx * QT + w * 32 + r < S;
     const bf16_t* base = qkv + (int64_t)b * N * tok + hh * HD;
     const float c2 = rsqrtf((float)HD) * 1.44269504088896341f;   // scale * log2(e)
     const int NT = MULTI ? NTarg : 1;                            // key tiles per frame
@@ -230,7 +232,7 @@ __global__ __launch_bounds__(256, 2) void traj_space_fwd_kernel(const bf16_t* __
             const int row = p4 * 8 + (lane >> 3), q8 = lane & 7;
             uint4 raw = *reinterpret_cast<const uint4*>(slab + row * 128 + ((q8 ^ ((row & 15) >> 1)) << 4));
             if (row & 1) { const uint32_t a0 = raw.x, a1 = raw.y; raw.x = raw.z; raw.y = raw.w; raw.z = a0; raw.w = a1; }
-            const int s_row = blockIdx.x * QT + w * 32 + row;
+            const int s_row = bx * QT + w * 32 + row;
             if (s_row < S) {
                 *reinterpret_cast<uint4*>(xt + (((int64_t)b * S + s_row) * F + f) * C + hh * HD + q8 * 8) = raw;
                 if (s_row / P == f)

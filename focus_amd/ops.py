@@ -205,6 +205,11 @@ def cast(x, dtype):
 # version counter changes (optimizer steps are in-place).
 _shadow_cache = {}
 _shadow_gen = 0
+_shadow_epoch = 0         # bumped whenever a shadow TENSOR is created or dropped (the fused optimizer caches their pointers)
+
+
+def shadow_epoch():
+    return _shadow_epoch
 
 
 def invalidate_shadows():
@@ -255,8 +260,34 @@ def _refresh_shadows_batched():
                     _shadow_cache[key] = (_shadow_cache[key][0], (w._version, w.data_ptr(), _shadow_gen), out)
 
 
+def cached_shadow(w, dtype, transposed):
+    """The existing shadow tensor of `w` (stale or not), or None: the fused optimizer step (optimizer.FusedAdamW)
+    rewrites these in the same pass that updates the masters."""
+    hit = _shadow_cache.get((id(w), dtype, transposed))
+    if hit is not None and hit[0]() is w:
+        return hit[2]
+    return None
+
+
+def shadows_written(entries):
+    """entries: [(w, dst or None, dstT or None)] -- the bf16 shadows the optimizer step has just rewritten from the
+    updated masters.  Starts a new shadow generation (every other cached copy is stale now) and stamps these as fresh."""
+    global _shadow_gen
+    _shadow_gen += 1
+    for w, dst, dstT in entries:
+        for out, tr in ((dst, False), (dstT, True)):
+            if out is None:
+                continue
+            key = (id(w), torch.bfloat16, tr)
+            hit = _shadow_cache.get(key)
+            if hit is not None and hit[2] is out:
+                _shadow_cache[key] = (hit[0], (w._version, w.data_ptr(), _shadow_gen), out)
+
+
 def drop_caches():
     """Forget every bf16 weight shadow (frees their memory when a model is dropped between workloads)."""
+    global _shadow_epoch
+    _shadow_epoch += 1
     _shadow_cache.clear()
     _shadow_tables.clear()
     _stacked.clear()
@@ -277,6 +308,8 @@ def shadow(w, dtype, transposed=False):
                    "shadow^T")
     else:
         out = cast(wd, dtype)
+    global _shadow_epoch
+    _shadow_epoch += 1
     _shadow_cache[key] = (weakref.ref(w, lambda _r, k=key: _shadow_cache.pop(k, None)),
                           (w._version, w.data_ptr(), _shadow_gen), out)
     return out
@@ -294,26 +327,38 @@ def _dx_from(dy, w, dtype, aux=None, epilogue=EPI_NONE, alpha=1.0):
 # GRU / MLP / LayerNorm parameters) applies every weight dozens of times per step; autograd would run one tiny
 # weight-gradient GEMM, one bias column-sum and one accumulation add per application (~2000 launches of 5-13 us
 # per STEVE step).  Inside `with deferred_wgrads():` the Linear / MLP / LayerNorm nodes recorded by the forward
-# only STASH (dY, X) in their backward; one callback at the end of the backward pass concatenates the stashes and
-# runs ONE weight-gradient GEMM per parameter (the reduction over the applications becomes part of the GEMM's
-# reduction dimension) and adds the result to .grad.  Same sums, different association order.
-# Not used under DistributedDataParallel (its reducer wants every gradient to arrive through autograd).
+# count their applications per parameter; in the backward every application only STASHES its (dY, X), and the node
+# whose backward runs LAST (the count reaches zero) runs ONE weight-gradient GEMM over the stacked applications (the
+# reduction over the applications becomes part of the GEMM's reduction dimension) and RETURNS it as its parameter
+# gradient -- the others return None.  The sum reaches the parameter through autograd's own AccumulateGrad, so
+# DistributedDataParallel's reducer hooks fire as for any other gradient.  Same sums, different association order.
+# Valid when every application recorded by the forward takes part in the backward (true for the slot loop: the slots
+# chain through all of them).  If some never run (loss on a subset of frames), the count never reaches zero: a
+# callback at the end of the backward pass finds such leftovers and adds them to .grad directly (single process) or
+# raises (multi-rank DDP, where a gradient must not bypass the reducer).
 # --------------------------------------------------------------------------------------------------
 _DEFER_ON = False
 _DEFER_MAX_ROWS = 8192            # applications larger than this keep the immediate path (their GEMMs are efficient)
-_deferred_lin = {}                # id(w) -> [w, b, alpha, [dy...], [x...]]
-_deferred_vec = {}                # id(p) -> [p, [g...]]
-_deferred_ln = {}                 # id(gamma) -> [gamma, beta, [partial [2, nblk, D] ...]]
-_flush_queued = False
+_defer_stashes = {}               # key -> _Stash, for the forward passes recorded since the last deferred_wgrads().__enter__
+_leftover_queued = False
+
+
+class _Stash:
+    __slots__ = ("kind", "params", "alpha", "pending", "items")
+
+    def __init__(self, kind, params, alpha):
+        self.kind, self.params, self.alpha, self.pending, self.items = kind, params, alpha, 0, []
 
 
 class deferred_wgrads:
     def __enter__(self):
-        global _DEFER_ON
+        global _DEFER_ON, _defer_stashes, _leftover_queued
         self.prev = _DEFER_ON
-        import torch.distributed as dist
-        multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
-        _DEFER_ON = not multi and _os.environ.get("FOCUS_DEFER_WGRAD", "1") != "0"
+        # a fresh table: stashes of an earlier forward whose backward never ran (or raised half way) are orphaned with
+        # their graph instead of swallowing this step's gradients
+        _defer_stashes = {}
+        _leftover_queued = False
+        _DEFER_ON = _os.environ.get("FOCUS_DEFER_WGRAD", "1") != "0"
         return self
 
     def __exit__(self, *exc):
@@ -322,37 +367,52 @@ class deferred_wgrads:
         return False
 
 
-def _queue_flush():
-    global _flush_queued
-    if not _flush_queued:
-        _flush_queued = True
-        torch.autograd.Variable._execution_engine.queue_callback(_flush_deferred)
+def _defer_open(kind, params, rows, needed, alpha=1.0):
+    """Forward side: the stash shared by all applications of `params` (a tuple of leaf parameters / None), or None when
+    this application keeps the immediate path.  needed: ctx.needs_input_grad of the weight (False under no_grad and for
+    frozen parameters: nothing is counted then, and nothing is written to a frozen parameter's .grad)."""
+    if not _DEFER_ON or not needed or rows > _DEFER_MAX_ROWS:
+        return None
+    live = [p for p in params if p is not None]
+    if not live or not all(p.is_leaf and p.requires_grad for p in live):
+        return None
+    key = (kind, alpha) + tuple(id(p) if p is not None else 0 for p in params)
+    st = _defer_stashes.get(key)
+    if st is None:
+        st = _defer_stashes[key] = _Stash(kind, params, alpha)
+    st.pending += 1
+    return st
 
 
-def _defer_linear(w, b, alpha, dy2, x2):
-    e = _deferred_lin.get(id(w))
-    if e is None:
-        e = _deferred_lin[id(w)] = [w, b, alpha, [], []]
-    e[3].append(dy2)
-    e[4].append(x2)
-    _queue_flush()
+def _defer_finish(st):
+    """The gradients of a complete stash: linear -> (dw, db or None); sum -> tuple of summed vectors; ln -> (dg, db)."""
+    items, st.items = st.items, []
+    if st.kind == "linear":
+        dy = items[0][0] if len(items) == 1 else torch.cat([i[0] for i in items], 0)
+        x = items[0][1] if len(items) == 1 else torch.cat([i[1] for i in items], 0)
+        dw, db = linear_wgrad(dy, x, st.params[1] is not None)
+        if st.alpha != 1.0:
+            dw = dw * st.alpha
+        return dw, db
+    if st.kind == "ln":
+        both = (items[0] if len(items) == 1 else torch.cat(items, 1)).sum(1)              # [2, D]
+        return both[0], both[1]
+    n = len(items[0])                                                                      # "sum": tuples of vectors
+    return tuple(items[0][j] if len(items) == 1 else torch.stack([i[j] for i in items], 0).sum(0) for j in range(n))
 
 
-def _defer_ln(gamma, beta, partial):
-    """partial [2, nblk, D]: block partial sums of one LayerNorm application (focus_layernorm_bwd without its finish)."""
-    e = _deferred_ln.get(id(gamma))
-    if e is None:
-        e = _deferred_ln[id(gamma)] = [gamma, beta, []]
-    e[2].append(partial)
-    _queue_flush()
-
-
-def _defer_vec(p, g):
-    e = _deferred_vec.get(id(p))
-    if e is None:
-        e = _deferred_vec[id(p)] = [p, []]
-    e[1].append(g)
-    _queue_flush()
+def _defer_close(st, item):
+    """Backward side: stash this application's contribution; the last one returns the finished gradients (a tuple, see
+    _defer_finish), the others None."""
+    global _leftover_queued
+    st.items.append(item)
+    st.pending -= 1
+    if st.pending > 0:
+        if not _leftover_queued:
+            _leftover_queued = True
+            torch.autograd.Variable._execution_engine.queue_callback(_deferred_leftovers)
+        return None
+    return _defer_finish(st)
 
 
 def _acc_grad(p, g):
@@ -363,29 +423,24 @@ def _acc_grad(p, g):
         p.grad.add_(g)
 
 
-def _flush_deferred():
-    global _flush_queued
-    _flush_queued = False
-    lin, vec, lns = list(_deferred_lin.values()), list(_deferred_vec.values()), list(_deferred_ln.values())
-    _deferred_lin.clear()
-    _deferred_vec.clear()
-    _deferred_ln.clear()
+def _deferred_leftovers():
+    """End of a backward pass: stashes that hold contributions but whose count never reached zero (some application of
+    the parameter took no part in this backward)."""
+    global _leftover_queued
+    _leftover_queued = False
+    left = [st for st in _defer_stashes.values() if st.items]
+    if not left:
+        return
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        raise RuntimeError("focus_amd.ops.deferred_wgrads: %d parameter(s) were applied more often in the forward than in this "
+                           "backward; under DistributedDataParallel their gradient would bypass the reducer "
+                           "(set FOCUS_DEFER_WGRAD=0 for this loss)" % len(left))
     with torch.no_grad():
-        for w, b, alpha, dys, xs in lin:
-            dy = dys[0] if len(dys) == 1 else torch.cat(dys, 0)
-            x = xs[0] if len(xs) == 1 else torch.cat(xs, 0)
-            dw, db = linear_wgrad(dy, x, b is not None)
-            if alpha != 1.0:
-                dw = dw * alpha
-            _acc_grad(w, dw)
-            if b is not None:
-                _acc_grad(b, db)
-        for p, gs in vec:
-            _acc_grad(p, gs[0] if len(gs) == 1 else torch.stack(gs, 0).sum(0))
-        for gamma, beta, parts in lns:
-            both = (parts[0] if len(parts) == 1 else torch.cat(parts, 1)).sum(1)          # [2, D]
-            _acc_grad(gamma, both[0])
-            _acc_grad(beta, both[1])
+        for st in left:
+            st.pending = 0
+            for p, g in zip([q for q in st.params if q is not None], [g for g in _defer_finish(st) if g is not None]):
+                _acc_grad(p, g)
 
 
 # --------------------------------------------------------------------------------------------------
@@ -403,7 +458,7 @@ class _LinearFn(torch.autograd.Function):
         y = mm_nt(x2, shadow(w, x.dtype), bias=b, residual=r2, alpha=alpha)
         ctx.save_for_backward(x2, w)
         ctx.has_b, ctx.has_r, ctx.shp, ctx.alpha = b is not None, residual is not None, shp, alpha
-        ctx.defer = (w, b) if (_DEFER_ON and x2.shape[0] <= _DEFER_MAX_ROWS and w.is_leaf) else None
+        ctx.defer = _defer_open("linear", (w, b), x2.shape[0], ctx.needs_input_grad[1], alpha)
         return y.reshape(*shp[:-1], w.shape[0])
 
     @staticmethod
@@ -415,9 +470,10 @@ class _LinearFn(torch.autograd.Function):
         dx = dw = db = None
         join = None
         want_b = ctx.has_b and ctx.needs_input_grad[2]
-        if ctx.defer is not None and (ctx.needs_input_grad[1] or want_b):
-            pw, pb = ctx.defer
-            _defer_linear(pw, pb if want_b else None, ctx.alpha, dy2, x2)
+        if ctx.defer is not None:
+            done = _defer_close(ctx.defer, (dy2, x2))
+            if done is not None:
+                dw, db = done
         elif ctx.needs_input_grad[1]:
             dw, db, join = wgrad_async(dy2, x2, want_b)
             if ctx.alpha != 1.0:
@@ -533,7 +589,12 @@ class _MlpFn(torch.autograd.Function):
         ctx.save_for_backward(x2, w1, w2, a, z)
         ctx.act, ctx.shp = act, shp
         ctx.has = (b1 is not None, b2 is not None, residual is not None)
-        ctx.defer = (w1, b1, w2, b2) if (_DEFER_ON and M <= _DEFER_MAX_ROWS and w1.is_leaf and w2.is_leaf) else None
+        d1 = _defer_open("linear", (w1, b1), M, ctx.needs_input_grad[1])
+        d2 = _defer_open("linear", (w2, b2), M, ctx.needs_input_grad[3]) if d1 is not None else None
+        if d1 is not None and d2 is None:
+            d1.pending -= 1
+            d1 = None
+        ctx.defer = (d1, d2) if d1 is not None else None
         return y.reshape(*shp[:-1], w2.shape[0])
 
     @staticmethod
@@ -546,7 +607,9 @@ class _MlpFn(torch.autograd.Function):
         dfr = ctx.defer
         if dfr is not None:
             dw2 = db2 = None
-            _defer_linear(dfr[2], dfr[3] if ctx.has[1] else None, 1.0, dy2, a)
+            done = _defer_close(dfr[1], (dy2, a))
+            if done is not None:
+                dw2, db2 = done
         elif ctx.needs_input_grad[3]:
             dw2, db2, join2 = wgrad_async(dy2, a, ctx.has[1])
         else:
@@ -555,7 +618,9 @@ class _MlpFn(torch.autograd.Function):
         dz = _dx_from(dy2, w2, dy2.dtype, aux=(z if ctx.act == EPI_GELU else a), epilogue=_DEPI[ctx.act])
         if dfr is not None:
             dw1 = db1 = None
-            _defer_linear(dfr[0], dfr[1] if ctx.has[0] else None, 1.0, dz, x2)
+            done = _defer_close(dfr[0], (dz, x2))
+            if done is not None:
+                dw1, db1 = done
         elif ctx.needs_input_grad[1]:
             dw1, db1, join1 = wgrad_async(dz, x2, ctx.has[0])
         else:
@@ -625,7 +690,7 @@ def _ln_forward(ctx, x, gamma, beta, eps):
                                               eps, _dt(x2), _stream()), "layernorm_fwd")
     ctx.save_for_backward(x2, gamma, mean, rstd)
     ctx.shp = x.shape
-    ctx.defer = (gamma, beta) if (_DEFER_ON and rows <= _DEFER_MAX_ROWS and gamma.is_leaf and beta.is_leaf) else None
+    ctx.defer = _defer_open("ln", (gamma, beta), rows, ctx.needs_input_grad[1])
     return y.reshape(x.shape)
 
 
@@ -650,8 +715,8 @@ def _ln_backward(ctx, dy, dres):
         # one pass at the end of the backward (no per-application finish launch)
         _lib.check(L.focus_layernorm_bwd(_p(dy2), _p(x2), _p(gamma), _p(mean), _p(rstd), _p(r2) if r2 is not None else None,
                                          _p(dx), None, None, _p(partial), rows, D, _dt(x2), _stream()), "layernorm_bwd")
-        _defer_ln(ctx.defer[0], ctx.defer[1], partial)
-        return dx.reshape(ctx.shp), None, None
+        done = _defer_close(ctx.defer, partial)
+        return (dx.reshape(ctx.shp),) + (done if done is not None else (None, None))
     dg = torch.empty(D, device=x2.device, dtype=torch.float32)
     db = torch.empty(D, device=x2.device, dtype=torch.float32)
     _lib.check(L.focus_layernorm_bwd(_p(dy2), _p(x2), _p(gamma), _p(mean), _p(rstd), _p(r2) if r2 is not None else None,
@@ -742,7 +807,7 @@ class _FrameLayerNormFn(torch.autograd.Function):
                    "layernorm_fwd_blocks")
         ctx.save_for_backward(video, gamma, mean, rstd)
         ctx.t, ctx.shared = t, shared
-        ctx.defer = (gamma, beta) if (_DEFER_ON and gamma.is_leaf and beta.is_leaf) else None
+        ctx.defer = _defer_open("sum", (gamma, beta), 0, ctx.needs_input_grad[2])
         shared.pending += 1
         shared.frames |= 1 << t
         return y
@@ -771,9 +836,8 @@ class _FrameLayerNormFn(torch.autograd.Function):
         if sh.pending == 0:
             out, sh.buf, sh.frames = sh.buf, None, 0
         if ctx.defer is not None:
-            _defer_vec(ctx.defer[0], dg)
-            _defer_vec(ctx.defer[1], db)
-            dg = db = None
+            done = _defer_close(ctx.defer, (dg, db))
+            dg, db = done if done is not None else (None, None)
         return out, None, dg, db, None, None
 
 
@@ -1547,7 +1611,13 @@ class _LinearQKVFn(torch.autograd.Function):
         y = mm_nt(x2, _stacked_cat((wq, wk, wv), x.dtype, False)).view(*shp[:-1], 3 * C)
         ctx.save_for_backward(x2, wq, wk, wv)
         ctx.shp = shp
-        ctx.defer = _DEFER_ON and x2.shape[0] <= _DEFER_MAX_ROWS and wq.is_leaf and wk.is_leaf and wv.is_leaf
+        ds = [_defer_open("linear", (w, None), x2.shape[0], ctx.needs_input_grad[1 + i]) for i, w in enumerate((wq, wk, wv))]
+        if any(d is None for d in ds):
+            for d in ds:
+                if d is not None:
+                    d.pending -= 1
+            ds = None
+        ctx.defer = ds
         return y[..., :C], y[..., C:2 * C], y[..., 2 * C:]
 
     @staticmethod
@@ -1569,7 +1639,9 @@ class _LinearQKVFn(torch.autograd.Function):
         dws = [None, None, None]
         for i, (t, w) in enumerate(zip(ds, (wq, wk, wv))):
             if ctx.defer:
-                _defer_linear(w, None, 1.0, t, x2)
+                done = _defer_close(ctx.defer[i], (t, x2))
+                if done is not None:
+                    dws[i] = done[0]
             else:
                 dws[i] = linear_wgrad(t if t.stride(0) % 8 == 0 else t.contiguous(), x2, False)[0]
         return dx.reshape(ctx.shp), dws[0], dws[1], dws[2]
@@ -1609,7 +1681,12 @@ class _GruCellFn(torch.autograd.Function):
         _lib.check(_lib.lib().focus_gru_gates_fwd(_p(g[0]), _p(g[1]), _p(h), _p(hn), _p(b_ih), _p(b_hh), R, D, _dt(h),
                                                   _stream()), "gru_fwd")
         ctx.save_for_backward(x, h, g, w_ih, w_hh, b_ih, b_hh)
-        ctx.defer = _DEFER_ON and R <= _DEFER_MAX_ROWS and w_ih.is_leaf and w_hh.is_leaf
+        di = _defer_open("linear", (w_ih, b_ih), R, ctx.needs_input_grad[2])
+        dh = _defer_open("linear", (w_hh, b_hh), R, ctx.needs_input_grad[3]) if di is not None else None
+        if di is not None and dh is None:
+            di.pending -= 1
+            di = None
+        ctx.defer = (di, dh) if di is not None else None
         return hn
 
     @staticmethod
@@ -1627,8 +1704,12 @@ class _GruCellFn(torch.autograd.Function):
              (dxh, 0), (D, 1, 0, R * D), batch=(1, 2), residual=(res, 0))
         dws = [None, None, None, None]
         if ctx.defer:
-            _defer_linear(w_ih, b_ih, 1.0, dg[0], x)
-            _defer_linear(w_hh, b_hh, 1.0, dg[1], h)
+            done = _defer_close(ctx.defer[0], (dg[0], x))
+            if done is not None:
+                dws[0], dws[2] = done
+            done = _defer_close(ctx.defer[1], (dg[1], h))
+            if done is not None:
+                dws[1], dws[3] = done
         else:
             dws[0], dws[2] = linear_wgrad(dg[0], x, True)
             dws[1], dws[3] = linear_wgrad(dg[1], h, True)

@@ -8,6 +8,40 @@ key, default False) compresses the buckets to bf16 on the wire (295 MB instead o
 import torch
 import torch.distributed as dist
 
+# Streams that produce gradients besides the one DDP's hook happens to fire on (the ORViT motion stream runs on a side
+# stream, ORViT/orvit.py): device -> set of torch.cuda.Stream.  The reducer orders a bucket's all-reduce after the
+# CURRENT stream of the hook that completes the bucket only; joined_hook() widens that to every stream listed here.
+GRAD_STREAMS = {}
+_JOIN_STREAMS = {}
+
+
+def note_grad_stream(stream):
+    GRAD_STREAMS.setdefault(stream.device, set()).add(stream)
+
+
+def joined_hook(inner):
+    """DDP communication hook that starts `inner` (an all-reduce hook) on a dedicated stream which first waits for the
+    hook's current stream AND every stream in GRAD_STREAMS: gradients produced on a side stream are complete before the
+    collective reads the bucket, and neither compute stream is made to wait for the other."""
+    def hook(state, bucket):
+        buf = bucket.buffer()
+        if not buf.is_cuda:
+            return inner(state, bucket)
+        dev = buf.device
+        j = _JOIN_STREAMS.get(dev)
+        if j is None:
+            j = _JOIN_STREAMS[dev] = torch.cuda.Stream(device=dev)
+        cur = torch.cuda.current_stream(dev)
+        j.wait_stream(cur)
+        for s in GRAD_STREAMS.get(dev, ()):
+            if s != cur:
+                j.wait_stream(s)
+        buf.record_stream(j)
+        with torch.cuda.stream(j):
+            fut = inner(state, bucket)
+        return fut
+    return hook
+
 
 def wrap_ddp(model, device, cfg=None, bucket_cap_mb=64, compress=None):
     on_gpu = device is not None and device != "cpu" and torch.cuda.is_available()
@@ -19,7 +53,8 @@ def wrap_ddp(model, device, cfg=None, bucket_cap_mb=64, compress=None):
     backend = getattr(cfg, "DIST_BACKEND", "nccl") if cfg is not None else "nccl"
     if compress is None:
         compress = bool(cfg.get("DDP_BF16_GRADS", False)) if cfg is not None else False
-    if compress and on_gpu and backend == "nccl":      # gloo has no bf16 reductions
+    if on_gpu:
         from torch.distributed.algorithms.ddp_comm_hooks import default_hooks
-        ddp.register_comm_hook(dist.group.WORLD, default_hooks.bf16_compress_hook)
+        inner = default_hooks.bf16_compress_hook if (compress and backend == "nccl") else default_hooks.allreduce_hook
+        ddp.register_comm_hook(dist.group.WORLD, joined_hook(inner))      # gloo has no bf16 reductions
     return ddp

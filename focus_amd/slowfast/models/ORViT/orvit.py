@@ -15,8 +15,9 @@ import os
 # that occupy a handful of CUs for 20-60 us each (1.3 ms per bench step when serialised with the main branch).  It is
 # issued on a second HIP stream, forked before the RoI / attention work of the block and joined before motion_mlp, so
 # those launches run beside the block's large kernels; autograd replays the same fork / join for its backward
-# (33.3 vs 34.3 ms per bench step).  Not under DistributedDataParallel: its reducer orders a bucket's all-reduce after
-# the stream of the LAST gradient hook only, which does not cover gradients produced on another stream.
+# (33.3 vs 34.3 ms per bench step).  Under DistributedDataParallel the reducer orders a bucket's all-reduce after the
+# stream of the LAST gradient hook only, which does not cover gradients produced on another stream: both streams are
+# registered with focus_amd.parallel, whose communication hook joins them before every bucket's collective.
 _SIDE_STREAMS = {}
 _USE_SIDE_STREAM = os.environ.get("FOCUS_MOTION_SIDE_STREAM", "1") != "0"
 _COMMUTE_PATCH_TO_D = os.environ.get("FOCUS_ORVIT_COMMUTE", "1") != "0"      # patch_to_d[0] before RoIAlign (see forward)
@@ -98,10 +99,12 @@ class ORViT(nn.Module):
 
         motion_emb, side = None, None
         if self.with_motion_stream:
-            multi_rank = torch.distributed.is_available() and torch.distributed.is_initialized() and \
-                torch.distributed.get_world_size() > 1
-            if x.is_cuda and _USE_SIDE_STREAM and not multi_rank:
+            if x.is_cuda and _USE_SIDE_STREAM:
                 main, side = torch.cuda.current_stream(), _side_stream(x.device)
+                if torch.distributed.is_available() and torch.distributed.is_initialized():
+                    from focus_amd import parallel
+                    parallel.note_grad_stream(main)
+                    parallel.note_grad_stream(side)
                 side.wait_stream(main)
                 box_tensors.record_stream(side)
                 with torch.cuda.stream(side):

@@ -28,6 +28,10 @@ def train_step(model, optimizer, loss_fun, inputs, labels, meta, cfg, check_nan=
     loss.backward()                                               # :106
     if cfg.SOLVER.CLIP_GRAD_VAL:
         torch.nn.utils.clip_grad_value_(model.parameters(), cfg.SOLVER.CLIP_GRAD_VAL)      # :108-111
+    elif cfg.SOLVER.CLIP_GRAD_L2NORM and hasattr(optimizer, "step_clipped"):
+        # :112-120 as one multi-tensor pass (optimizer.FusedAdamW: norm, clip, AdamW, bf16 shadows; csrc/optim.hip)
+        optimizer.step_clipped(cfg.SOLVER.CLIP_GRAD_L2NORM)
+        return preds, loss
     elif cfg.SOLVER.CLIP_GRAD_L2NORM:
         torch.nn.utils.clip_grad_norm_(model.parameters(), cfg.SOLVER.CLIP_GRAD_L2NORM)    # :112-117
     optimizer.step()                                              # :120
@@ -125,30 +129,77 @@ def perform_test(test_loader, model, test_meter, cfg):
     return test_meter.finalize_metrics()
 
 
-class GraphedStep:
-    """One HIP graph for a launch-bound step (the STEVE slot update issues ~2900 kernels of 3-30 us per step: the host,
-    not the GPU, sets its eager time).  `fn` takes no arguments, reads its inputs from tensors that stay in place, and
-    runs forward + backward (gradients it leaves in .grad are rewritten by every replay).  Warm-up runs on a side stream
-    as torch.cuda.graphs requires; `replay()` re-issues the whole step with one launch.
-    Constraint found the hard way: no output of an EARLIER eager run of `fn` may still be referenced when the capture
-    starts -- a live output keeps that run's autograd graph alive, and ending the capture then crashes inside the HIP
-    runtime (ROCm 7.2).  Warm-up outputs are dropped here; callers drop theirs (bench.py: `del slots, attn`)."""
+def _tensors(obj):
+    if isinstance(obj, torch.Tensor):
+        yield obj
+    elif isinstance(obj, (tuple, list)):
+        for o in obj:
+            yield from _tensors(o)
+    elif isinstance(obj, dict):
+        for o in obj.values():
+            yield from _tensors(o)
 
-    def __init__(self, fn, warmup=2, reset=None):
+
+def live_autograd_tensors(device=None):
+    """CUDA tensors that still hang on an autograd graph (grad_fn is not None), found through the garbage collector's
+    object list: the outputs of an earlier forward that somebody still references."""
+    import gc
+    found = []
+    for o in gc.get_objects():
+        try:
+            if isinstance(o, torch.Tensor) and o.is_cuda and o.grad_fn is not None and (device is None or o.device == device):
+                found.append(o)
+        except Exception:       # objects in odd states while being torn down
+            pass
+    return found
+
+
+class GraphedStep:
+    """One HIP graph for a launch-bound step (the STEVE slot update issues ~2000 kernels of 3-30 us per step: the host,
+    not the GPU, sets its eager time).  `fn` takes no arguments, reads its inputs from tensors that stay in place, and
+    runs forward + backward (gradients it leaves in .grad are rewritten by every replay).  The class owns the warm-up
+    runs (on a side stream, as torch.cuda.graphs requires) and drops their outputs; `replay()` re-issues the whole
+    step with one launch.
+
+    Failure this class guards against (gpurun_out/r2_b42.log: `Segmentation fault in torch/cuda/graphs.py capture_end`
+    on ROCm 7.2): an output of an EARLIER run of the step that is still referenced keeps that run's autograd graph --
+    and the buffers it saved -- alive across the capture, and ending the capture then crashes inside the HIP runtime.
+    The cause sits with whoever holds the reference, so the guard sits here, before the capture starts: after the
+    warm-up the collector runs, the device is synchronised, and if ANY CUDA tensor with a grad_fn is still reachable
+    (the caller's outputs of an earlier eager step, or outputs `fn` stores somewhere itself) the constructor raises
+    instead of capturing.  `allow_live` names tensors the caller knows about and vouches for."""
+
+    def __init__(self, fn, warmup=2, reset=None, allow_live=()):
         """reset: called before every warm-up run and before the capture (e.g. set .grad to None, so that the captured
         backward ASSIGNS gradients instead of accumulating into tensors from outside the graph)."""
+        import gc
+        import weakref
+        cur = torch.cuda.current_stream()
         side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
+        side.wait_stream(cur)
+        refs = []
         with torch.cuda.stream(side):
             for _ in range(warmup):
                 if reset is not None:
                     reset()
-                fn()
-        torch.cuda.current_stream().wait_stream(side)
+                out = fn()
+                refs.extend(weakref.ref(t) for t in _tensors(out))
+                del out
+        cur.wait_stream(side)
         if reset is not None:
             reset()
-        import gc
         gc.collect()
+        torch.cuda.synchronize()
+        if any(r() is not None for r in refs):
+            raise RuntimeError("GraphedStep: fn keeps its own outputs alive between calls (a warm-up output is still referenced "
+                               "after `del`); capturing now would crash in hipStreamEndCapture")
+        ok = {id(t) for t in allow_live}
+        live = [t for t in live_autograd_tensors(torch.device("cuda", torch.cuda.current_device())) if id(t) not in ok]
+        if live:
+            raise RuntimeError("GraphedStep: %d CUDA tensor(s) of an earlier forward are still referenced (shapes %s); their "
+                               "autograd graph would be alive across the capture (crash in hipStreamEndCapture on ROCm 7.2). "
+                               "Drop them (del / detach) before building the graph" %
+                               (len(live), [tuple(t.shape) for t in live[:4]]))
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             self.outputs = fn()

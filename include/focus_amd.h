@@ -363,6 +363,26 @@ typedef struct focus_shadow_item {
 } focus_shadow_item;
 int focus_shadow_refresh(const focus_shadow_item* items, int n_items, int max_rows, int max_cols, void* stream);
 
+/* The optimizer step of train_net.py:108-120 for ALL parameters of a model in two launches (optim.hip): global gradient
+ * norm (clip_grad_norm_, train_net.py:112-117; max_norm <= 0: no clipping), AdamW update (torch.optim.AdamW as built by
+ * optimizer.py:137-145: decoupled weight decay, bias correction, no amsgrad) of the fp32 masters and moments, and the bf16
+ * working copies of the updated weights (dst row-major, dstT transposed; either may be NULL).
+ * `items`: DEVICE array; `grads`: DEVICE array of the n_items fp32 gradient pointers (kept apart from `items`: they are
+ * the only pointers that change from step to step); unit0 = first work unit of the item (prefix sum of focus_adamw_units over the items);
+ * tile_mode 1 needs rows % 4 == 0, cols % 4 == 0 and 16-byte aligned tensors (dstT only in tile mode).
+ * `groups`: DEVICE [n_groups][2] = (lr, weight_decay).  `steps`: DEVICE [n_items] fp32 step counters, incremented here.
+ * `total_norm`: DEVICE scalar receiving the gradient norm before clipping, or NULL.
+ * write_clipped_grads: g *= clip coefficient is stored back (what clip_grad_norm_ leaves in .grad). */
+typedef struct focus_adamw_item {
+    float* p; float* m; float* v; void* dst; void* dstT;
+    int32_t rows, cols, group, unit0, tile_mode, pad_;
+} focus_adamw_item;
+int focus_adamw_units(int rows, int cols, int tile_mode);
+size_t focus_adamw_workspace_bytes(void);
+int focus_adamw_step(const focus_adamw_item* items, float* const* grads, int n_items, int n_units, const float* groups, float* steps,
+                     void* workspace, size_t workspace_bytes, float* total_norm, double beta1, double beta2, float eps,
+                     float max_norm, int write_clipped_grads, void* stream);
+
 /* xdiag[b,s,:] = xt[b,s,s/P,:] (attention.py:533-535) and its adjoint dxt[b,s,s/P,:] += dxdiag[b,s,:]. */
 int focus_diag_gather(const void* xt, void* xdiag, int B, int S, int F, int C, int dtype, void* stream);
 int focus_diag_scatter_add(const void* dxdiag, void* dxt, int B, int S, int F, int C, int dtype, void* stream);

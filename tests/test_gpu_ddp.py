@@ -24,3 +24,22 @@ def test_bench_two_ranks_same_device_gloo():
     assert rec["n_gpus"] == 2 and rec["config"]["global_batch"] == 2 and rec["config"]["parallelism"] == "dp2"
     assert rec["value"] > 0 and rec["final_loss"] == rec["final_loss"]
     assert "exposed_allreduce_ms" in rec and rec["ms_per_step_no_allreduce"] > 0
+
+
+@pytest.mark.parametrize("mixed", [0, 1])
+def test_ddp_gradients_equal_single_process(mixed, tmp_path):
+    """with the motion side stream ON and the gradients flowing through DDP's reducer (communication
+    hook joining the side stream, focus_amd/parallel.py), the 2-rank gradients (one clip each, averaged by the reducer)
+    equal the single-process gradients of the 2-clip batch.  fp32 mode: 1e-5; bf16 mode: the per-clip activations are
+    bit-identical, only the weight-gradient reduction order over rows differs (fp32 sums of bf16 products): 2e-3."""
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    outs = [str(tmp_path / ("r%d.json" % r)) for r in range(2)]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_ddp_grad_worker.py"), str(r), str(port), str(mixed),
+                               outs[r]], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    logs = [p.communicate(timeout=600)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(l[-3000:] for l in logs)
+    rec = json.load(open(outs[0]))
+    assert rec["n"] > 50
+    assert rec["worst"] < (2e-3 if mixed else 1e-5), rec

@@ -248,6 +248,65 @@ def test_layer_norm_deferred_affine_gradients():
         assert _rel(xg.grad, xr.grad) < 2 ** -6
 
 
+def _three_linear_applications(ops, d, w, b, xs, cs, use=(0, 1, 2)):
+    with ops.deferred_wgrads():
+        ys = [ops.linear(x, w, b) for x in xs]
+        sum((ys[i].float() * cs[i].to(d)).sum() for i in use).backward()
+
+
+def test_deferred_wgrads_survive_failed_backward_frozen_params_and_partial_backward():
+    """ADVICE r2: (1) a backward that raises after some applications were stashed must not poison the next step;
+    (2) a frozen parameter gets no .grad from the deferred path; (3) a loss that reaches only some applications of a
+    weight still yields their (partial) gradient -- the end-of-backward callback adds the leftovers."""
+    from focus_amd import ops
+    d = dev()
+    g = torch.Generator().manual_seed(21)
+    R, Din, Dout = 96, 192, 128
+    w0, b0 = 0.1 * torch.randn(Dout, Din, generator=g), 0.1 * torch.randn(Dout, generator=g)
+    xs = [torch.randn(R, Din, generator=g).bfloat16() for _ in range(3)]
+    cs = [torch.randn(R, Dout, generator=g) for _ in range(3)]
+
+    def reference(use):
+        wr = w0.bfloat16().double().requires_grad_()
+        br = b0.double().requires_grad_()
+        sum(((x.double() @ wr.t() + br) * cs[i].double()).sum() for i, x in enumerate(xs) if i in use).backward()
+        return wr.grad, br.grad
+
+    w, b = w0.to(d).requires_grad_(), b0.to(d).requires_grad_()
+    xg = [x.to(d) for x in xs]
+
+    # (1) a backward that dies half way: the hook on the second application's output raises after the third was stashed
+    class Boom(RuntimeError):
+        pass
+
+    def boom(_g):
+        raise Boom()
+    with ops.deferred_wgrads():
+        ys = [ops.linear(x, w, b) for x in xg]
+        ys[1].register_hook(boom)
+        with pytest.raises(Boom):
+            sum((y.float() * c.to(d)).sum() for y, c in zip(ys, cs)).backward()
+    w.grad = b.grad = None
+    _three_linear_applications(ops, d, w, b, xg, cs)
+    torch.cuda.synchronize()
+    gw, gb = reference((0, 1, 2))
+    assert w.grad is not None and _rel(w.grad, gw) < 2 ** -6 and _rel(b.grad, gb) < 2 ** -6
+
+    # (2) frozen weight: no gradient appears on it, the bias still gets its own
+    w.grad = b.grad = None
+    w.requires_grad_(False)
+    _three_linear_applications(ops, d, w, b, xg, cs)
+    assert w.grad is None and b.grad is not None and _rel(b.grad, gb) < 2 ** -6
+    w.requires_grad_(True)
+
+    # (3) only applications 0 and 2 reach the loss
+    w.grad = b.grad = None
+    _three_linear_applications(ops, d, w, b, xg, cs, use=(0, 2))
+    torch.cuda.synchronize()
+    gw, gb = reference((0, 2))
+    assert w.grad is not None and _rel(w.grad, gw) < 2 ** -6 and _rel(b.grad, gb) < 2 ** -6
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("B,heads,N,M,d", [(32, 4, 11, 11, 48), (3, 3, 5, 16, 64), (2, 1, 16, 1, 8)])
 def test_small_attention_one_launch(dtype, B, heads, N, M, d):
@@ -321,3 +380,35 @@ def test_linear_qkv_feeds_the_one_launch_attention_in_place(defer):
     assert _rel(xg.grad, xr.grad) < 2 ** -5
     for got, want in zip(wg, wr):
         assert got.grad is not None and _rel(got.grad, want.grad) < 2 ** -5
+
+
+def test_graphed_step_refuses_live_outputs_and_replays_bit_exact():
+    """GraphedStep (focus_amd/train.py): the r2 crash came from capturing while an output of an earlier eager step was
+    still referenced.  The constructor now refuses that state (raises BEFORE the capture starts); with the reference
+    dropped it captures, and a replay reproduces the eager step bit for bit."""
+    from focus_amd import ops
+    from focus_amd.train import GraphedStep
+    d = dev()
+    g = torch.Generator().manual_seed(5)
+    w = (0.1 * torch.randn(128, 192, generator=g)).to(d).requires_grad_()
+    b = torch.zeros(128, device=d, requires_grad=True)
+    x = torch.randn(256, 192, generator=g).bfloat16().to(d)
+
+    def reset():
+        w.grad = b.grad = None
+
+    def fn():
+        y = ops.linear(x, w, b)
+        y.float().square().mean().backward()
+        return y
+
+    reset()
+    y_eager = fn()
+    ref_y, ref_g = y_eager.detach().clone(), w.grad.detach().clone()
+    with pytest.raises(RuntimeError, match="still referenced"):
+        GraphedStep(fn, reset=reset)                    # y_eager (grad_fn alive) is still held by this frame
+    del y_eager
+    gs = GraphedStep(fn, reset=reset)
+    y = gs.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(y, ref_y) and torch.equal(w.grad, ref_g)
