@@ -79,16 +79,15 @@ def host_cores():
     return len(allowed), (len(phys) or len(allowed))
 
 
-def cpu_baseline(model, cfg, seconds_budget=25.0):
-    """the CPU oracle, fp32, B=2 clips fwd+bwd on the physical cores of this host (1 warm-up + up to 3
-    timed iterations inside a bounded budget), plus a 1-thread figure on one TrajectoryAttentionBlock of the same
-    sample (the whole model on one thread would take minutes)."""
+def cpu_baseline(model, cfg, seconds_budget=75.0):
+    """the CPU oracle, fp32, B=2 clips fwd+bwd on this host: 1 warm-up + 3 timed iterations with 32 threads
+    (the setting that was fastest on the shared GPU-box host) AND, budget permitting, 1 warm-up + 3 timed with one thread
+    per physical core; `value` is the better of the two, both are reported.  Plus a 1-thread figure on one
+    TrajectoryAttentionBlock of the same sample (the whole model on one thread would take minutes)."""
     import torch
     from focus_amd.train import synthetic_batch
     from oracle import focus_oracle as fo
     nthreads, phys = host_cores()
-    cores = max(1, min(phys, nthreads, 32))          # more threads than this made the oracle SLOWER on the shared host
-    torch.set_num_threads(cores)
     base = model.module if hasattr(model, "module") else model
     params = {k: v.detach().float().cpu().clone().requires_grad_(v.is_floating_point())
               for k, v in base.state_dict().items()}
@@ -97,17 +96,37 @@ def cpu_baseline(model, cfg, seconds_budget=25.0):
     ocfg = dict(depth=cfg.MF.DEPTH, heads=cfg.MF.NUM_HEADS, orvit_layers=list(cfg.ORVIT.LAYERS),
                 temporal_resolution=cfg.MF.TEMPORAL_RESOLUTION,
                 patch=(cfg.MF.PATCH_SIZE_TEMP, cfg.MF.PATCH_SIZE, cfg.MF.PATCH_SIZE), crop=cfg.DATA.TRAIN_CROP_SIZE)
-    times, logits = [], None
     t_all = time.time()
-    for it in range(4):
-        t0 = time.time()
-        logits = fo.motionformer_forward(params, inputs[0], meta["orvit_bboxes"], ocfg, training=True)
-        fo.label_smoothing_ce(logits, labels).backward()
-        times.append(time.time() - t0)
-        if time.time() - t_all + times[-1] > seconds_budget:
-            break
-    timed = times[1:] if len(times) > 1 else times
-    t = sum(timed) / len(timed)
+    state = {"logits": None}
+
+    def run(threads, budget_left):
+        """-> (mean seconds of the timed iterations, how many were timed) with `threads` threads; 1 warm-up first."""
+        torch.set_num_threads(threads)
+        times = []
+        for it in range(4):
+            t0 = time.time()
+            for p in params.values():
+                p.grad = None
+            state["logits"] = fo.motionformer_forward(params, inputs[0], meta["orvit_bboxes"], ocfg, training=True)
+            fo.label_smoothing_ce(state["logits"], labels).backward()
+            times.append(time.time() - t0)
+            if it >= 1 and time.time() - t_all + times[-1] > budget_left:
+                break
+        timed = times[1:] if len(times) > 1 else times
+        return sum(timed) / len(timed), len(timed)
+
+    c32 = max(1, min(phys, nthreads, 32))
+    t32, n32 = run(c32, seconds_budget * 0.55)
+    runs = {"threads_%d" % c32: {"clips_per_s": round(Bc / t32, 4), "timed_iterations": n32}}
+    best_t, best_c = t32, c32
+    call = max(1, min(phys, nthreads))
+    if call != c32 and time.time() - t_all + 2.5 * t32 < seconds_budget:
+        tp, npn = run(call, seconds_budget)
+        runs["threads_%d" % call] = {"clips_per_s": round(Bc / tp, 4), "timed_iterations": npn}
+        if tp < best_t:
+            best_t, best_c = tp, call
+    cores, t, logits = best_c, best_t, state["logits"]
+    torch.set_num_threads(cores)
     # one block, same sample size, all cores vs one thread (thread-scaling normalisation)
     D = cfg.MF.EMBED_DIM
     N = 1 + cfg.MF.TEMPORAL_RESOLUTION * (cfg.DATA.TRAIN_CROP_SIZE // cfg.MF.PATCH_SIZE) ** 2
@@ -143,26 +162,43 @@ def cpu_baseline(model, cfg, seconds_budget=25.0):
     base.train(was_training)
     ref = torch.softmax(logits.detach(), dim=-1)
     err = float((probs - ref).abs().max() / ref.abs().max())
-    return {"value": round(Bc / t, 4), "unit": "clips/s", "cores": cores, "kind": "port",
-            "sample": "B=2 clips ORViT-MF 16x224 O=4 fwd+bwd fp32 through oracle/focus_oracle.py, 1 warm-up + %d timed "
-                      "iteration(s), mean; %d physical cores of %d usable threads" % (len(timed), phys, nthreads),
-            "one_thread": one, "hip_vs_oracle_rel_err_bf16": round(err, 5)}
+    return {"value": round(Bc / t, 4), "unit": "clips/s", "cores": cores, "cores_physical": phys, "threads_usable": nthreads,
+            "kind": "port",
+            "sample": "B=2 clips ORViT-MF 16x224 O=4 fwd+bwd fp32 through oracle/focus_oracle.py; 1 warm-up + up to 3 timed "
+                      "iterations per thread count, mean; value = the faster thread count",
+            "runs": runs, "one_thread": one, "hip_vs_oracle_rel_err_bf16": round(err, 5)}
 
 
-def pmc_traffic():
-    """HBM-side bytes per NT-GEMM launch from the newest committed PMC pass (bench.py cannot run rocprofv3 on itself):
-    profiles/r*_pmc_hbm_traffic.txt, last line `... = <MB> MB @ <git head>`.  Returns (bytes, source) or (None, None):
-    the figure is a recorded constant, so its source commit travels with it."""
+def pmc_record(workload):
+    """The newest committed PMC pass of `workload` (profiles/r*_pmc_hbm_traffic_<workload>.txt, last line `#json {...}`,
+    written by tools/pmc_traffic.py) IF it was taken on the kernel sources this process runs (focus_amd.build.source_hash);
+    otherwise None: a traffic figure measured on other kernels is not quoted (bench.py cannot run rocprofv3 on itself)."""
     import glob
     try:
-        files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm_traffic.txt")))
-        path = files[-1]
-        last = open(path).read().strip().splitlines()[-1]
-        mb = float(last.rsplit("=", 1)[1].split("MB")[0])
-        head = last.split("@", 1)[1].strip() if "@" in last else "8b61332 (round 1)"
-        return round(mb * 1e6), "%s @ %s" % (os.path.basename(path), head)
+        from focus_amd.build import source_hash
+        files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm_traffic_%s.txt" % workload)))
+        for path in reversed(files):
+            last = open(path).read().strip().splitlines()[-1]
+            if not last.startswith("#json "):
+                continue
+            rec = json.loads(last[6:])
+            if rec.get("src") == source_hash():
+                rec["file"] = os.path.basename(path)
+                return rec
     except Exception:
-        return None, None
+        pass
+    return None
+
+
+def pmc_traffic(family="gemm_nt_ws_kernel", workload="orvit"):
+    """(HBM-side bytes per launch of a kernel family, source string) or (None, reason)."""
+    rec = pmc_record(workload)
+    if rec is None:
+        return None, "no PMC pass committed for the running kernel sources"
+    fam = rec.get("families", {}).get(family)
+    if not fam:
+        return None, "%s: family %s not in the pass" % (rec["file"], family)
+    return fam["bytes_per_launch"], "%s @ build %s" % (rec["file"], rec.get("head"))
 
 
 # ----------------------------------------------------------------------------------------------------------------
@@ -249,7 +285,7 @@ def bench_job(cfg):
                 train_step(model, optimizer, loss_fun, inputs, labels, meta, cfg)
             torch.cuda.synchronize()
             allrecs, ops.GEMM_TIMING = ops.GEMM_TIMING, None
-            recs = [r for r in allrecs if r[3] == "nt_ws"]       # the dominant kernel: gemm_nt_ws_kernel (forward / dX GEMMs)
+            recs = [r for r in allrecs if r[3] in ("nt_ws", "nt_ws8")]   # the dominant kernel: gemm_nt_ws_kernel (forward / dX GEMMs)
             other = [r for r in allrecs if r[3] == "nt"]         # uniform 128x128 kernel: skinny (M = 256) products
             other_ms = sum(r[1].elapsed_time(r[2]) for r in other)
             tn = [r for r in allrecs if r[3] == "tn"]            # weight-gradient kernel, reported beside it
@@ -268,8 +304,10 @@ def bench_job(cfg):
                     print("%-44s %5.1f %8.1f %7.0f %7.3f" % (k, e[0] / a.steps, 1e3 * e[1] / e[0], e[2] / e[1] / 1e9,
                                                              e[1] / a.steps), file=sys.stderr)
             tn_tf = sum(r[0] for r in tn) / (tn_ms * 1e-3) / 1e12 if tn_ms > 0 else 0.0
-            # algorithmic HBM bytes of the same launches: A + B + C (+ aux, residual are not known here: lower bound)
-            alg = sum(2.0 * r[4][3] * (r[4][0] * r[4][2] + r[4][1] * r[4][2] + r[4][0] * r[4][1]) for r in recs)
+            # algorithmic HBM bytes of the same launches: A + B + C, + one more C-sized tensor for the GELU forms (the saved
+            # pre-activation written / read); residual operands are not known here (lower bound)
+            alg = sum(2.0 * r[4][3] * (r[4][0] * r[4][2] + r[4][1] * r[4][2] + r[4][0] * r[4][1] * (2 if r[4][4] in (1, 4) else 1))
+                      for r in recs)
             traffic, traffic_src = pmc_traffic()
             out["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                                "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
@@ -384,55 +422,97 @@ def bench_steve(a, dev):
     fwd_bytes = (B * T * N * D * 2) * (1 + 2 + 2) + B * T * N * K * 2         # inputs, write k/v, read k/v, attn out
     alg = 3.0 * fwd_bytes
     ach = alg / (ms * 1e-3) / 1e9
-    rowsum = float(attn.float().sum(-1).sub(1).abs().max())
+    rowsum = float(attn.detach().float().sum(-1).sub(1).abs().max())
     ops.drop_caches()
+    prec = pmc_record("steve")          # whole-step HBM-side bytes from the PMC passes of the SAME kernel sources, or None
+    traffic = round(prec["trace_total_bytes"] / max(prec.get("executions", 4), 1)) if prec else None
     return {"workload": "STEVE slot-attention update, movi_e 24x128x128 (N=4096 tokens/frame), 11 slots, 3 iters, "
                         "batch=%d, fwd+bwd bf16 (BASELINE configs[2])" % B,
             "ms_per_step": round(ms, 3), "clips_per_s": round(B / (ms * 1e-3), 2),
             "slot_updates_per_s": round(B * T * IT * K / (ms * 1e-3), 1), "steps": n,
             "launch": "one HIP graph replay per step" if graphed else "eager", "eager_ms_per_step": round(eager_ms, 3),
             "roofline": {"bound": "hbm", "achieved": round(ach, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                         "frac": round(ach / PEAK_HBM_GBS, 4), "traffic": None,
+                         "frac": round(ach / PEAK_HBM_GBS, 4), "traffic": traffic,
+                         "traffic_unit": "bytes/step (PMC: 2*FETCH_SIZE + WRITE_SIZE over every kernel of the step, separate "
+                                         "rocprofv3 passes)" if traffic else None,
+                         "traffic_source": ("%s @ build %s" % (prec["file"], prec.get("head"))) if prec else None,
                          "algorithmic_bytes_per_step": int(alg),
                          "note": "6.11 GB forward (SURVEY 8d) x3 for forward+backward"},
             "attn_rowsum_max_err": round(rowsum, 5), "finite": bool(torch.isfinite(slots.float()).all())}
 
 
 def bench_hr(a, dev):
-    """BASELINE configs[4] shape on one GPU: ORViT-Motionformer-HR 16x336, 6 objects, EK verb+noun heads, bf16,
-    batch 4 per GPU, fwd+bwd+clip+AdamW.  (fp8 weights: not built; bf16 roofline is used.)"""
+    """BASELINE configs[4] on one GPU: ORViT-Motionformer-HR 16x336, 6 objects, EK verb+noun heads, fp8 (OCP e4m3) Linear
+    weights with bf16 activations (TRAIN.FP8_WEIGHTS; the weights are widened to bf16 between LDS and the MFMA, so the
+    bf16 dense MFMA peak is the one that applies), fwd+bwd+clip+AdamW, at batch 4 per GPU and at a
+    large batch; the same step with bf16 weights beside it."""
     import torch
     from focus_amd import ops
     from focus_amd.slowfast.models import build_model
     from focus_amd.slowfast.models.losses import get_loss_func
     from focus_amd.slowfast.models.optimizer import construct_optimizer
     from focus_amd.train import synthetic_batch, train_step
+
+    def run(batch, fp8):
+        cfg = make_cfg(1, batch, hr=True)
+        cfg.merge_from_list(["TRAIN.FP8_WEIGHTS", bool(fp8)])
+        torch.manual_seed(0)
+        model = build_model(cfg, gpu_id=dev.index)
+        model.train()
+        opt = construct_optimizer(model, cfg)
+        loss_fun = get_loss_func(cfg)(reduction="mean")
+        inputs, labels, meta = synthetic_batch(cfg, batch, dev, seed=77)
+        for _ in range(max(1, min(a.warmup, 2))):
+            train_step(model, opt, loss_fun, inputs, labels, meta, cfg)
+        torch.cuda.synchronize()
+        n = max(2, min(a.steps, 5))
+        t0 = time.perf_counter()
+        for _ in range(n):
+            _, loss = train_step(model, opt, loss_fun, inputs, labels, meta, cfg)
+        torch.cuda.synchronize()
+        ms = 1e3 * (time.perf_counter() - t0) / n
+        rec = {"batch": batch, "ms_per_step": round(ms, 3), "clips_per_s": round(batch / (ms * 1e-3), 3), "steps": n,
+               "final_loss": round(float(loss.detach()), 4)}
+        gemm = None
+        if fp8 and not a.no_roofline:
+            ops.GEMM_TIMING = []
+            train_step(model, opt, loss_fun, inputs, labels, meta, cfg)
+            torch.cuda.synchronize()
+            recs, ops.GEMM_TIMING = ops.GEMM_TIMING, None
+            r8 = [r for r in recs if r[3] == "nt_ws8"]
+            fl, t8 = sum(r[0] for r in r8), sum(r[1].elapsed_time(r[2]) for r in r8)
+            if t8 > 0:
+                gemm = {"kernel": "gemm_nt_ws_kernel<..., BFP8>: e4m3 weights widened to bf16 on the LDS->register path",
+                        "launches_per_step": len(r8), "achieved": round(fl / (t8 * 1e-3) / 1e12, 2), "unit": "TFLOP/s",
+                        "ms_per_step": round(t8, 3)}
+        del model, opt
+        ops.drop_caches()
+        torch.cuda.empty_cache()
+        return rec, gemm
+
     Bh = a.hr_batch
-    cfg = make_cfg(1, Bh, hr=True)
-    torch.manual_seed(0)
-    model = build_model(cfg, gpu_id=dev.index)
-    model.train()
-    opt = construct_optimizer(model, cfg)
-    loss_fun = get_loss_func(cfg)(reduction="mean")
-    inputs, labels, meta = synthetic_batch(cfg, Bh, dev, seed=77)
-    for _ in range(max(1, min(a.warmup, 2))):
-        train_step(model, opt, loss_fun, inputs, labels, meta, cfg)
-    torch.cuda.synchronize()
-    n = max(2, min(a.steps, 5))
-    t0 = time.perf_counter()
-    for _ in range(n):
-        _, loss = train_step(model, opt, loss_fun, inputs, labels, meta, cfg)
-    torch.cuda.synchronize()
-    ms = 1e3 * (time.perf_counter() - t0) / n
-    cps = Bh / (ms * 1e-3)
-    del model, opt
-    ops.drop_caches()
-    torch.cuda.empty_cache()
-    return {"workload": "ORViT-Motionformer-HR 16x336, 6 objects, EK heads (97+300), batch=%d, bf16 "
-                        "(BASELINE configs[4] shape on 1 GPU; fp8 weights not built)" % Bh,
-            "ms_per_step": round(ms, 3), "clips_per_s": round(cps, 3), "steps": n,
-            "model_mfma_frac_algorithmic": round(cps * ALG_GF_PER_CLIP_HR * 1e9 / (PEAK_BF16_TFLOPS * 1e12), 5),
-            "final_loss": round(float(loss.detach()), 4)}
+    f8, gemm = run(Bh, True)
+    out = {"workload": "ORViT-Motionformer-HR 16x336, 6 objects, EK heads (97+300), fp8 (OCP e4m3) Linear weights, bf16 "
+                       "activations, batch=%d (BASELINE configs[4] on 1 GPU)" % Bh,
+           "dtype": "fp8w", "ms_per_step": f8["ms_per_step"], "clips_per_s": f8["clips_per_s"], "steps": f8["steps"],
+           "final_loss": f8["final_loss"]}
+    frac = f8["clips_per_s"] * ALG_GF_PER_CLIP_HR * 1e9 / (PEAK_BF16_TFLOPS * 1e12)
+    out["roofline"] = {"bound": "mfma", "achieved": round(f8["clips_per_s"] * ALG_GF_PER_CLIP_HR / 1e3, 2), "peak": PEAK_BF16_TFLOPS,
+                       "unit": "TFLOP/s", "frac": round(frac, 5), "traffic": None,
+                       "note": "model-level: clips/s x 5099 GF (BASELINE.md) vs the bf16 dense MFMA peak -- the e4m3 weights are "
+                               "widened to bf16 before the MFMA (non-scaled fp8 MFMA runs at the bf16 rate; the 5 PF/s scaled form "
+                               "needs fp8 activations too)", "fp8_gemm": gemm}
+    if a.hr_large_batch and a.hr_large_batch != Bh:
+        try:
+            out["large_batch"] = run(a.hr_large_batch, True)[0]
+        except Exception as e:          # e.g. out of memory: the batch-4 record stands
+            out["large_batch"] = {"batch": a.hr_large_batch, "failed": repr(e)[:200]}
+            ops.drop_caches()
+            torch.cuda.empty_cache()
+    bf, _ = run(Bh, False)
+    out["bf16_weights"] = bf
+    out["model_mfma_frac_algorithmic"] = round(frac, 5)
+    return out
 
 
 def _free_port():
@@ -455,6 +535,7 @@ def main(argv=None, job=None):
                     help="all = the headline ORViT-MF line with the steve / hr sub-records (N == 1)")
     ap.add_argument("--steve-batch", type=int, default=32)
     ap.add_argument("--hr-batch", type=int, default=4)
+    ap.add_argument("--hr-large-batch", type=int, default=16, help="second HR fp8 record at this batch (0: skip)")
     ap.add_argument("--fp32", action="store_true", help="TRAIN.MIXED_PRECISION False (precision path)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--gemm-shapes", action="store_true", help="print per-shape GEMM timings to stderr")

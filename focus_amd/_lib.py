@@ -9,7 +9,7 @@ HEADER = os.path.join(_HERE, "..", "include", "focus_amd.h")
 DEBUG_HEADER = os.path.join(_HERE, "csrc", "focus_debug.h")     # test-suite probes, not part of the operator ABI
 LIB_PATH = os.path.join(_HERE, "lib", "libfocus_amd.so")
 
-F32, BF16 = 0, 1
+F32, BF16, FP8_E4M3 = 0, 1, 2
 EPI_NONE, EPI_GELU, EPI_RELU, EPI_TANH, EPI_DGELU, EPI_DRELU, EPI_DTANH = range(7)
 
 
@@ -26,6 +26,7 @@ class GemmDesc(ctypes.Structure):
         ("bias", ctypes.c_void_p), ("residual", ctypes.c_void_p), ("aux", ctypes.c_void_p),
         ("alpha", ctypes.c_float), ("accumulate", ctypes.c_int32), ("epilogue", ctypes.c_int32),
         ("dtype_ab", ctypes.c_int32), ("dtype_c", ctypes.c_int32),
+        ("dtype_b", ctypes.c_int32), ("pad_", ctypes.c_int32), ("b_scale", ctypes.c_void_p),
     ]
 
 
@@ -83,7 +84,7 @@ def lib():
             fn = getattr(L, name)          # AttributeError here = header/library mismatch
             fn.restype = restype
             fn.argtypes = argtypes
-        if L.focus_abi_version() != 1:
+        if L.focus_abi_version() != 2:
             raise RuntimeError("focus_amd: ABI version mismatch")
         _lib = L
     return _lib

@@ -451,6 +451,15 @@ extern "C" int focus_gemm(const focus_gemm_desc* desc, void* stream) {
     if (d.accumulate && d.dtype_c != FOCUS_F32) return FOCUS_ERR_DTYPE;
     if (d.epilogue >= FOCUS_EPI_DGELU && !d.aux) return FOCUS_ERR_NULL;
     hipStream_t s = static_cast<hipStream_t>(stream);
+    if (d.dtype_b == FOCUS_FP8_E4M3) {
+        // e4m3 weights (B) with bf16 activations (A): the wave-specialised NT kernel is the only consumer; anything it
+        // cannot take is an error, not a silent bf16 detour
+        if (d.aux && d.epilogue == FOCUS_EPI_NONE) d.aux = nullptr;
+        if (!focus_gemm_mfma_ws_ok(d)) return d.dtype_ab != FOCUS_BF16 ? FOCUS_ERR_DTYPE : FOCUS_ERR_ALIGN;
+        g_last_kernel = FOCUS_GEMM_KERNEL_NT_WS;
+        return focus_gemm_mfma_ws(d, s);
+    }
+    if (d.dtype_b != 0 && d.dtype_b != d.dtype_ab) return FOCUS_ERR_DTYPE;
     if (focus_gemm_mfma_tn_ok(d)) {                                    // checked first: in this form aux is its slab workspace
         g_last_kernel = FOCUS_GEMM_KERNEL_TN;
         return focus_gemm_mfma_tn(d, s);

@@ -30,24 +30,32 @@ __device__ __forceinline__ int swz(int row, int chunk) { return row * 128 + ((ch
 
 struct Unit { int m0, n0, nk; };
 
-// 128x256 / 256x128: 8 consumer waves (64x64 each) + 4 loaders, 3-stage 144 KiB ring (85 flop per LDS-filled byte;
-//           the loaders run two K-steps ahead).
-// 192x256: 12 consumer waves + 4 loaders = 1024 threads, 2-stage 112 KiB ring (110 flop per LDS-filled byte: the
-//           kernel is bound by the L2 -> LDS fill rate of a CU, ~22 B/clk, so bytes per flop is the lever; and
-//           M = 12552 x N = 768 becomes 198 tiles = ONE round of the 256 CUs instead of 297 = two).  With two
-//           stages the loaders run one K-step ahead (s_waitcnt vmcnt(0) per step).
-template <int BM, int BN, int EPI, int NLOAD, int NSTAGE>
-__global__ __launch_bounds__(64 * (BM * BN / 4096 + NLOAD)) void gemm_nt_ws_kernel(const focus_gemm_desc d, int tiles_m, int tiles_n, int GM) {
-    constexpr int NCONS = BM * BN / 4096;                        // consumer waves (64x64 each)
-    constexpr int WN = BN / 64;                                  // consumer grid is (BM/64) x WN
-    constexpr int A_BYTES = BM * 128, STAGE = (BM + BN) * 128;   // bytes per ring stage
-    constexpr int GA = BM / 8 / NLOAD, GB = BN / 8 / NLOAD;      // DMA pieces per loader wave per K-step
+// Consumer grid WM x WN waves, each wave a (16 MI) x 64 output tile (MI fragments of 16 rows, 4 of 16 columns):
+//   128x256 / 256x128 (MI 4): 8 consumers + 4 loaders, 3-stage 144 KiB ring (85 flop per LDS-filled byte; the loaders
+//           run two K-steps ahead).
+//   160x256 (MI 5), 192x256 (MI 6): 8 consumers + 4 loaders.  [r3] The tile height is a free parameter in steps of 32
+//           rows, chosen per shape so that the tiles fill whole rounds of the 256 CUs: M = 12552 x N = 768 is 237 tiles
+//           of 160 rows = ONE round at 92 % (198 tiles of 192 rows: 77 %; 297 of 128: two rounds at 58 %), N = 2304 three
+//           rounds of 160 instead of four of 128.  160x256 keeps a 3-stage ring (156 KiB).
+//   192x256 with 12 consumers of 64x64 (MI 4, WM 3): the round-2 form, kept for A/B (FOCUS_GEMM_TILE=193).
+// BFP8: the B operand (the weights) is stored as OCP e4m3 codes, 64 bytes per row and K-step: half the B bytes through
+//           the LDS ring; consumers read 8 codes per fragment (ds_read_b64) and widen them to bf16 with
+//           v_cvt_scalef32_pk_bf16_fp8 (exact: every e4m3 value is a bf16 value); the per-tensor scale multiplies the
+//           fp32 accumulator in the epilogue.  "fp8 weights, bf16 activations" (BASELINE configs[4]).
+template <int WM, int WN, int MI, int EPI, int NLOAD, int NSTAGE, bool BFP8>
+__global__ __launch_bounds__(64 * (WM * WN + NLOAD)) void gemm_nt_ws_kernel(const focus_gemm_desc d, int tiles_m, int tiles_n, int GM) {
+    constexpr int BM = WM * MI * 16, BN = WN * 64;
+    constexpr int NCONS = WM * WN;                               // consumer waves
+    constexpr int BROW = BFP8 ? 64 : 128;                        // bytes of one B row per K-step
+    constexpr int A_BYTES = BM * 128, STAGE = BM * 128 + BN * BROW;   // bytes per ring stage
+    constexpr int GA = BM / 8 / NLOAD, GB = BN * BROW / 1024 / NLOAD; // DMA pieces (1 KiB) per loader wave per K-step
+    static_assert(GA * 8 * NLOAD == BM && GB * 1024 * NLOAD == BN * BROW, "pieces must divide among the loader waves");
     constexpr int PIECES = GA + GB;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int z = blockIdx.y;
     const int b0 = z / d.batch1, b1 = z % d.batch1;
     const bf16_t* A = static_cast<const bf16_t*>(d.A) + b0 * d.bsA0 + b1 * d.bsA1;
-    const bf16_t* B = static_cast<const bf16_t*>(d.B) + b0 * d.bsB0 + b1 * d.bsB1;
+    const char* B = static_cast<const char*>(d.B) + (b0 * d.bsB0 + b1 * d.bsB1) * (BFP8 ? 1 : 2);
     const int64_t coff = b0 * d.bsC0 + b1 * d.bsC1;
     bf16_t* C = static_cast<bf16_t*>(d.C) + coff;
     const bf16_t* R = d.residual ? static_cast<const bf16_t*>(d.residual) + coff : nullptr;
@@ -82,8 +90,12 @@ __global__ __launch_bounds__(64 * (BM * BN / 4096 + NLOAD)) void gemm_nt_ws_kern
         // =============================== loader waves ===============================
         const int L = w - NCONS;
         const int lrow = lane >> 3, cpos = lane & 7, csrc = (cpos ^ lrow) * 8;
+        // fp8 B: a 1 KiB piece is 16 rows of 64 bytes; lane -> (row lane>>2, 16-byte chunk lane&3), the chunk a row keeps at
+        // position p is chunk p ^ ((row >> 2) & 3): the consumers' ds_read_b64 (16 rows x 2 halves per 32-lane group) then
+        // touch every bank once
+        const int brow8 = lane >> 2, bsrc8 = ((lane & 3) ^ ((lane >> 4) & 3)) * 16;
         const bf16_t* a_src[GA];
-        const bf16_t* b_src[GB];
+        const char* b_src[GB];
         int iu = 0, ikt = 0;
         auto setup = [&](int i) __attribute__((always_inline)) {
             const Unit t = unit_of(i);
@@ -91,8 +103,10 @@ __global__ __launch_bounds__(64 * (BM * BN / 4096 + NLOAD)) void gemm_nt_ws_kern
             for (int g = 0; g < GA; ++g)
                 a_src[g] = A + (int64_t)min(t.m0 + (L * GA + g) * 8 + lrow, d.M - 1) * lda + csrc;
 #pragma unroll
-            for (int g = 0; g < GB; ++g)
-                b_src[g] = B + (int64_t)min(t.n0 + (L * GB + g) * 8 + lrow, d.N - 1) * ldb + csrc;
+            for (int g = 0; g < GB; ++g) {
+                if constexpr (BFP8) b_src[g] = B + (int64_t)min(t.n0 + (L * GB + g) * 16 + brow8, d.N - 1) * ldb + bsrc8;
+                else b_src[g] = B + ((int64_t)min(t.n0 + (L * GB + g) * 8 + lrow, d.N - 1) * ldb + csrc) * 2;
+            }
         };
         auto issue = [&](int st) __attribute__((always_inline)) {
             char* sa = smem + st * STAGE;
@@ -102,7 +116,7 @@ __global__ __launch_bounds__(64 * (BM * BN / 4096 + NLOAD)) void gemm_nt_ws_kern
                 __builtin_amdgcn_global_load_lds((gvoid_t*)(a_src[g] + ikt * BK), (lvoid_t*)(sa + (L * GA + g) * 1024), 16, 0, 0);
 #pragma unroll
             for (int g = 0; g < GB; ++g)
-                __builtin_amdgcn_global_load_lds((gvoid_t*)(b_src[g] + ikt * BK), (lvoid_t*)(sb + (L * GB + g) * 1024), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((gvoid_t*)(b_src[g] + ikt * (BFP8 ? BK : 2 * BK)), (lvoid_t*)(sb + (L * GB + g) * 1024), 16, 0, 0);
             if (++ikt == nk) { ikt = 0; if (++iu < my_units) setup(iu); }
         };
         constexpr int AHEAD = NSTAGE - 1;                  // K-steps the loaders run ahead of the consumers
@@ -139,20 +153,35 @@ __global__ __launch_bounds__(64 * (BM * BN / 4096 + NLOAD)) void gemm_nt_ws_kern
     // =============================== consumer waves ===============================
     const int wm = w / WN, wn = w % WN;
     const int frow = lane & 15, fq = lane >> 4;
-    f32x4 acc[4][4];
+    const float alpha = BFP8 ? d.alpha * *d.b_scale : d.alpha;
+    f32x4 acc[MI][4];
     auto compute = [&](const char* sa) __attribute__((always_inline)) {
         const char* sb = sa + A_BYTES;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            bf16x8 fa[4], fb[4];
+            bf16x8 fa[MI], fb[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
-                fa[i] = *reinterpret_cast<const bf16x8*>(sa + swz(wm * 64 + i * 16 + frow, ks * 4 + fq));
+            for (int jj = 0; jj < 4; ++jj) {
+                if constexpr (BFP8) {
+                    // 8 e4m3 codes k = 32 ks + 8 fq .. +7 of row n: 16-byte chunk 2 ks + (fq >> 1), half fq & 1
+                    const int row = wn * 64 + jj * 16 + frow;
+                    const uint2 raw = *reinterpret_cast<const uint2*>(sb + row * 64 + (((2 * ks + (fq >> 1)) ^ ((row >> 2) & 3)) << 4) + (fq & 1) * 8);
+                    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+                    union { bf16x2 p[4]; bf16x8 v; } u;
+                    u.p[0] = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(raw.x, 1.0f, false);
+                    u.p[1] = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(raw.x, 1.0f, true);
+                    u.p[2] = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(raw.y, 1.0f, false);
+                    u.p[3] = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(raw.y, 1.0f, true);
+                    fb[jj] = u.v;
+                } else {
+                    fb[jj] = *reinterpret_cast<const bf16x8*>(sb + swz(wn * 64 + jj * 16 + frow, ks * 4 + fq));
+                }
+            }
 #pragma unroll
-            for (int jj = 0; jj < 4; ++jj)
-                fb[jj] = *reinterpret_cast<const bf16x8*>(sb + swz(wn * 64 + jj * 16 + frow, ks * 4 + fq));
+            for (int i = 0; i < MI; ++i)
+                fa[i] = *reinterpret_cast<const bf16x8*>(sa + swz(wm * (16 * MI) + i * 16 + frow, ks * 4 + fq));
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < MI; ++i)
 #pragma unroll
                 for (int jj = 0; jj < 4; ++jj)
                     acc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[jj], fa[i], acc[i][jj], 0, 0, 0);
@@ -163,9 +192,12 @@ __global__ __launch_bounds__(64 * (BM * BN / 4096 + NLOAD)) void gemm_nt_ws_kern
         // ([32 rows][16 chunks of 8 B], chunk ^= row & 15) inside the just-consumed stage
         char* slab = stage + w * 4096;
 #pragma unroll
-        for (int half = 0; half < 2; ++half) {
+        for (int half = 0; half < (MI + 1) / 2; ++half) {
+            constexpr int LASTN = (MI & 1) ? 1 : 2;                 // fragment rows in the last pass (odd MI: one)
+            const int nfr = (half == (MI + 1) / 2 - 1) ? LASTN : 2;
 #pragma unroll
             for (int i2 = 0; i2 < 2; ++i2) {
+                if (i2 >= nfr) break;
                 const int i = half * 2 + i2, row = i2 * 16 + frow;
 #pragma unroll
                 for (int jj = 0; jj < 4; ++jj) {
@@ -173,7 +205,7 @@ __global__ __launch_bounds__(64 * (BM * BN / 4096 + NLOAD)) void gemm_nt_ws_kern
                     float t[4];
 #pragma unroll
                     for (int r4 = 0; r4 < 4; ++r4) {
-                        t[r4] = d.alpha * acc[i][jj][r4];
+                        t[r4] = alpha * acc[i][jj][r4];
                         if (d.bias && gn + r4 < d.N) t[r4] += d.bias[gn + r4];
                     }
                     uint2 pk;
@@ -186,8 +218,9 @@ __global__ __launch_bounds__(64 * (BM * BN / 4096 + NLOAD)) void gemm_nt_ws_kern
             const int q8 = lane & 7;
 #pragma unroll
             for (int p8 = 0; p8 < 4; ++p8) {
+                if (p8 >= 2 * nfr) break;
                 const int row = p8 * 8 + (lane >> 3);
-                const int gm = m0 + wm * 64 + half * 32 + row, gn = n0 + wn * 64 + q8 * 8;
+                const int gm = m0 + wm * (16 * MI) + half * 32 + row, gn = n0 + wn * 64 + q8 * 8;
                 uint4 raw = *reinterpret_cast<const uint4*>(slab + row * 128 + ((q8 ^ ((row & 15) >> 1)) << 4));
                 if (row & 1) { const uint32_t a0 = raw.x, a1 = raw.y; raw.x = raw.z; raw.y = raw.w; raw.z = a0; raw.w = a1; }
                 if (gm >= d.M || gn >= d.N) continue;
@@ -241,7 +274,7 @@ __global__ __launch_bounds__(64 * (BM * BN / 4096 + NLOAD)) void gemm_nt_ws_kern
     for (int cu = 0; cu < my_units; ++cu) {
         const Unit cur = unit_of(cu);
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < MI; ++i)
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj) acc[i][jj] = (f32x4){0.f, 0.f, 0.f, 0.f};
         char* last_stage = smem;
@@ -262,7 +295,14 @@ __global__ __launch_bounds__(64 * (BM * BN / 4096 + NLOAD)) void gemm_nt_ws_kern
 
 bool focus_gemm_mfma_ws_ok(const focus_gemm_desc& d) {
     static const bool enabled = !(getenv("FOCUS_GEMM_WS") && atoi(getenv("FOCUS_GEMM_WS")) == 0);
-    if (!enabled || !focus_gemm_mfma_nt_ok(d)) return false;
+    if (d.dtype_b == FOCUS_FP8_E4M3) {
+        // e4m3 weights: only this kernel consumes them (no env switch: there is no other path to fall back to)
+        if (d.dtype_ab != FOCUS_BF16 || !d.b_scale || d.csA != 1 || d.rsB != 1 || d.K <= 0 || (d.K % BK) != 0) return false;
+        if ((d.rsA & 7) || (d.bsA0 & 7) || (d.bsA1 & 7) || (d.csB & 15) || (d.bsB0 & 15) || (d.bsB1 & 15)) return false;
+        if (!focus_aligned(d.A, 16) || !focus_aligned(d.B, 16)) return false;
+    } else if (!enabled || !focus_gemm_mfma_nt_ok(d)) {
+        return false;
+    }
     if (d.dtype_c != FOCUS_BF16 || d.accumulate || d.csC != 1 || (d.rsC & 7) || (d.N & 7)) return false;
     if ((d.bsC0 & 7) || (d.bsC1 & 7)) return false;
     if (!focus_aligned(d.C, 16) || (d.residual && !focus_aligned(d.residual, 16)) || (d.aux && !focus_aligned(d.aux, 16)))
@@ -270,14 +310,18 @@ bool focus_gemm_mfma_ws_ok(const focus_gemm_desc& d) {
     return true;
 }
 
-template <int BM, int BN, int EPI, int NLOAD>
-static int launch_ws_n(const focus_gemm_desc& d, hipStream_t s) {
-    constexpr int FIT = 160 * 1024 / ((BM + BN) * 128);
+template <int WM, int WN, int MI, int EPI, bool BFP8>
+static int launch_ws(const focus_gemm_desc& d, hipStream_t s) {
+    // 4 loader waves: the LDS-DMA issue rate of the loaders, not the MFMA rate, bounds a K-step (~2.2k clocks per K-step
+    // with 4 loaders x 12 pieces against 1k clocks of MFMA)
+    constexpr int NLOAD = 4, BM = WM * MI * 16, BN = WN * 64;
+    constexpr int STAGE = BM * 128 + BN * (BFP8 ? 64 : 128);
+    constexpr int FIT = 160 * 1024 / STAGE;
     constexpr int NSTAGE = FIT >= 4 ? 4 : FIT;                    // ring depth: what fits the 160 KiB of LDS, at most 4
     const int tiles_m = (d.M + BM - 1) / BM, tiles_n = (d.N + BN - 1) / BN;
     const int nbatch = d.batch0 * d.batch1;
-    const size_t lds = (size_t)NSTAGE * (BM + BN) * 128;
-    auto k = gemm_nt_ws_kernel<BM, BN, EPI, NLOAD, NSTAGE>;
+    const size_t lds = (size_t)NSTAGE * STAGE;
+    auto k = gemm_nt_ws_kernel<WM, WN, MI, EPI, NLOAD, NSTAGE, BFP8>;
     static bool once = (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds) == hipSuccess);
     (void)once;
     const int nunits = tiles_m * tiles_n;
@@ -288,60 +332,75 @@ static int launch_ws_n(const focus_gemm_desc& d, hipStream_t s) {
     // wide outputs use 8-row-tile-deep groups so an XCD's resident tiles share A and B panels in its L2.
     static const int gm_env = getenv("FOCUS_GEMM_GM") ? std::max(1, atoi(getenv("FOCUS_GEMM_GM"))) : 0;
     const int gm = gm_env ? gm_env : (tiles_n <= 4 ? 1 : 8);
-    hipLaunchKernelGGL(k, grid, dim3(64 * (BM * BN / 4096 + NLOAD)), lds, s, d, tiles_m, tiles_n, gm);
+    hipLaunchKernelGGL(k, grid, dim3(64 * (WM * WN + NLOAD)), lds, s, d, tiles_m, tiles_n, gm);
     FOCUS_CHECK_LAUNCH();
     return FOCUS_OK;
 }
 
-template <int BM, int BN, int EPI>
-static int launch_ws(const focus_gemm_desc& d, hipStream_t s) {
-    // loader waves per workgroup: the LDS-DMA issue rate of the loaders, not the MFMA rate, bounds a K-step
-    // (~2.2k clocks per K-step with 4 loaders x 12 pieces against 1k clocks of MFMA); FOCUS_GEMM_NLOAD=4|8 for tuning
-    return launch_ws_n<BM, BN, EPI, 4>(d, s);
-}
-
-template <int BM, int BN>
+template <int WM, int WN, int MI, bool BFP8>
 static int launch_ws_epi(const focus_gemm_desc& d, hipStream_t s) {
     switch (d.epilogue) {
-        case FOCUS_EPI_NONE: return launch_ws<BM, BN, FOCUS_EPI_NONE>(d, s);
-        case FOCUS_EPI_GELU: return launch_ws<BM, BN, FOCUS_EPI_GELU>(d, s);
-        case FOCUS_EPI_RELU: return launch_ws<BM, BN, FOCUS_EPI_RELU>(d, s);
-        case FOCUS_EPI_TANH: return launch_ws<BM, BN, FOCUS_EPI_TANH>(d, s);
-        case FOCUS_EPI_DGELU: return launch_ws<BM, BN, FOCUS_EPI_DGELU>(d, s);
-        case FOCUS_EPI_DRELU: return launch_ws<BM, BN, FOCUS_EPI_DRELU>(d, s);
-        case FOCUS_EPI_DTANH: return launch_ws<BM, BN, FOCUS_EPI_DTANH>(d, s);
+        case FOCUS_EPI_NONE: return launch_ws<WM, WN, MI, FOCUS_EPI_NONE, BFP8>(d, s);
+        case FOCUS_EPI_GELU: return launch_ws<WM, WN, MI, FOCUS_EPI_GELU, BFP8>(d, s);
+        case FOCUS_EPI_RELU: return launch_ws<WM, WN, MI, FOCUS_EPI_RELU, BFP8>(d, s);
+        case FOCUS_EPI_TANH: return launch_ws<WM, WN, MI, FOCUS_EPI_TANH, BFP8>(d, s);
+        case FOCUS_EPI_DGELU: return launch_ws<WM, WN, MI, FOCUS_EPI_DGELU, BFP8>(d, s);
+        case FOCUS_EPI_DRELU: return launch_ws<WM, WN, MI, FOCUS_EPI_DRELU, BFP8>(d, s);
+        case FOCUS_EPI_DTANH: return launch_ws<WM, WN, MI, FOCUS_EPI_DTANH, BFP8>(d, s);
         default: return FOCUS_ERR_SHAPE;
     }
 }
 
 static int g_tile_override = 0;
 extern "C" int focus_gemm_tile_override(int bm) {
-    if (bm != 0 && bm != 128 && bm != 192) return FOCUS_ERR_SHAPE;
+    if (bm != 0 && bm != 128 && bm != 160 && bm != 192 && bm != 193) return FOCUS_ERR_SHAPE;
     g_tile_override = bm;
     return FOCUS_OK;
 }
 
-int focus_gemm_mfma_ws(const focus_gemm_desc& d, hipStream_t s) {
-    if (d.batch0 * d.batch1 > 65535) return FOCUS_ERR_SHAPE;
-    const int64_t t256 = (int64_t)((d.M + 255) / 256) * ((d.N + 127) / 128);
-    const int64_t tw = (int64_t)((d.M + 127) / 128) * ((d.N + 255) / 256);
-    const int64_t t192 = (int64_t)((d.M + 191) / 192) * ((d.N + 255) / 256);
-    // tile choice by modelled time = rounds of the 256 persistent workgroups x time per tile; a 192x256 tile measures
-    // 1.40-1.45x the time of a 128x256 tile for 1.5x its work (tools/gemm_tile_ab.py), so it wins where it saves a
-    // round: 12552 x 768 is 198 tiles = one round instead of 297 = two (1.31-1.38x faster at K = 768 .. 3072).
-    // FOCUS_GEMM_TILE=128|192 or focus_gemm_tile_override() force a shape (tuning).
+template <bool BFP8>
+static int dispatch_ws(const focus_gemm_desc& d, hipStream_t s) {
+    const int nbatch = d.batch0 * d.batch1;
+    // FOCUS_GEMM_TILE=128|160|192 or focus_gemm_tile_override() force a tile height (tuning); 193 = the round-2 192x256
+    // form with 12 consumer waves
     static const int env_force = getenv("FOCUS_GEMM_TILE") ? atoi(getenv("FOCUS_GEMM_TILE")) : 0;
     const int force = g_tile_override ? g_tile_override : env_force;
-    if (d.N >= 256 && d.batch0 * d.batch1 == 1) {
-        const double c128 = (double)((tw + 255) / 256) * 1.0, c192 = (double)((t192 + 255) / 256) * 1.42;
-        const bool use192 = force ? force == 192 : (t192 >= 128 && c192 < c128);
-        if (use192 && t192 >= 128) return launch_ws_epi<192, 256>(d, s);
+    const int64_t tn256 = (d.N + 255) / 256;
+    if (d.N >= 256 && nbatch == 1) {
+        // tile height by modelled time = rounds of the 256 persistent workgroups x (rows per tile + a fixed cost per tile:
+        // prologue, epilogue, ring refill ~ 40 rows' worth): 12552 x 768 -> 160 rows (237 tiles, one round),
+        // 12552 x 2304 -> 160 (711 tiles, three rounds; 128: four), 12552 x 3072 -> 160 (four rounds; 128: five)
+        int best = 0;
+        double best_cost = 0;
+        for (int bm = 128; bm <= 192; bm += 32) {
+            const int64_t tiles = (int64_t)((d.M + bm - 1) / bm) * tn256;
+            if (tiles < 128) continue;
+            const double cost = (double)((tiles + 255) / 256) * (bm + 40);
+            if (force ? bm == force : (!best || cost < best_cost - 1e-9)) { best = bm; best_cost = cost; }
+        }
+        if (force == 193 && !BFP8 && (int64_t)((d.M + 191) / 192) * tn256 >= 128) return launch_ws_epi<3, 4, 4, false>(d, s);
+        if (best == 192) return launch_ws_epi<2, 4, 6, BFP8>(d, s);
+        if (best == 160) return launch_ws_epi<2, 4, 5, BFP8>(d, s);
+        if (best == 128 && (int64_t)((d.M + 127) / 128) * tn256 >= 192) return launch_ws_epi<2, 4, 4, BFP8>(d, s);
     }
+    const int64_t t256 = (int64_t)((d.M + 255) / 256) * ((d.N + 127) / 128);
+    const int64_t tw = (int64_t)((d.M + 127) / 128) * tn256;
     // narrow outputs (per-head products: N = head dim, batched over the heads): 4 consumers on a 256 x 64 tile, no MFMA
     // work on padding columns, and the 3-stage ring instead of the uniform kernel's one K-step in flight
-    if (d.N <= 64 && d.M >= 2048 && d.epilogue == FOCUS_EPI_NONE && (int64_t)((d.M + 255) / 256) * d.batch0 * d.batch1 >= 192)
-        return launch_ws<256, 64, FOCUS_EPI_NONE>(d, s);
-    if (d.N >= 256 && tw >= 192) return launch_ws_epi<128, 256>(d, s);   // 512-byte row segments of C
-    if (d.M >= 256 && t256 >= 192) return launch_ws_epi<256, 128>(d, s);
+    if (d.N <= 64 && d.M >= 2048 && d.epilogue == FOCUS_EPI_NONE && (int64_t)((d.M + 255) / 256) * nbatch >= 192)
+        return launch_ws<4, 1, 4, FOCUS_EPI_NONE, BFP8>(d, s);
+    if (d.N >= 256 && tw >= 192) return launch_ws_epi<2, 4, 4, BFP8>(d, s);   // 512-byte row segments of C
+    if (d.M >= 256 && t256 >= 192) return launch_ws_epi<4, 2, 4, BFP8>(d, s);
     return FOCUS_ERR_SHAPE;   // too few tiles for one 8-consumer workgroup per CU: the caller uses the uniform kernel
+}
+
+int focus_gemm_mfma_ws(const focus_gemm_desc& d, hipStream_t s) {
+    if (d.batch0 * d.batch1 > 65535) return FOCUS_ERR_SHAPE;
+    if (d.dtype_b == FOCUS_FP8_E4M3) {
+        // few tiles: the 128x256 instance still runs (under-filled); there is no uniform fp8 kernel
+        const int rc = dispatch_ws<true>(d, s);
+        if (rc != FOCUS_ERR_SHAPE) return rc;
+        return d.N >= 256 ? launch_ws_epi<2, 4, 4, true>(d, s) : launch_ws_epi<4, 2, 4, true>(d, s);
+    }
+    return dispatch_ws<false>(d, s);
 }

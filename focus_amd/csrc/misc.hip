@@ -598,4 +598,4 @@ extern "C" const char* focus_strerror(int status) {
     const int i = -status;
     return (i >= 0 && i <= 6) ? kErr[i] : "unknown focus status";
 }
-extern "C" int focus_abi_version(void) { return 1; }
+extern "C" int focus_abi_version(void) { return 2; }

@@ -5,8 +5,12 @@
 //     dV_{f,p} = sum_s P * dX[s,f,:]          dP = dX[s,f,:].v_{f,p}       dL = P * (dP - delta) * scale
 //     dK_{f,p} = sum_s dL * q_s               dQ_s = sum_{f,p} dL * k_{f,p}
 // Three kernels, no atomics, every output written exactly once:
-//   traj_delta_kernel : delta [B,h,S,F] and dxsum [B,S,C]                 (HBM-bound, reads dx~ and x~ once)
-//   traj_dq_kernel    : workgroup = 128 queries of one (b,h), walks the (frame, 32-key block) stream; keys on the
+//   traj_dxsum_kernel : dxsum [B,S,C] = the dX rows of each query's own frame (dx~ + dx_diag): 3 x 19 MB
+//   traj_dq_kernel    : [r3] also forms delta: it streams its queries' dX rows anyway, the matching x~ rows come beside
+//                       them (one more 4 KiB tile per wave and frame) and delta = rowsum(dX . x~) is 32 FMAs and one
+//                       cross-half add per lane and frame; written to [B,h,S,F] for the dK/dV kernel.  The separate
+//                       traj_delta_kernel (a full pass over dx~ AND x~: 408 MB of HBM traffic per launch, 76 us) is gone.
+//                       workgroup = 128 queries of one (b,h), walks the (frame, 32-key block) stream; keys on the
 //                       accumulator rows (swapped products), dL feeds  dQ^T += K^T.dL  straight from the accumulator
 //                       registers; K^T fragments come from the row-major K block through ds_read_b64_tr_b16.
 //   traj_dkv_kernel   : workgroup = the <=224 keys of one (b,h,frame), one wave per 32 keys, walks all queries in
@@ -62,55 +66,23 @@ __device__ __forceinline__ bf16x8 pack_acc(const f32x16& a, int s2) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// delta[b,h,s,f] = scale * sum_d (dxt[b,s,f,h,d] + [f == s/P] dxdiag[b,s,h,d]) * xt[b,s,f,h,d]
-// lse2[b,h,s,f]  = lse[b,h,s,f] * log2(e)
-// dxsum[b,s,:]   = dxt[b,s,s/P,:] + dxdiag[b,s,:]      (so the kernels below can DMA dX rows without an add)
-// one thread per 16-byte chunk; a head's 64 channels sit on 8 adjacent lanes
+// dxsum[b,s,:] = dxt[b,s,s/P,:] + dxdiag[b,s,:]      (so the kernels below can DMA dX rows without an add)
+// one thread per 16-byte chunk of a [B*S, C] row
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void traj_delta_kernel(const bf16_t* __restrict__ dxt, const bf16_t* __restrict__ dxdiag,
-                                                         const bf16_t* __restrict__ xt, const float* __restrict__ lse,
-                                                         float* __restrict__ delta, float* __restrict__ lse2,
-                                                         bf16_t* __restrict__ dxsum, int64_t nchunks, int S, int F, int P,
-                                                         int heads) {
-    // one thread per 16-byte chunk (8 channels) of dx~ / x~, in memory order: both streams are read perfectly
-    // coalesced with no loop (the previous row-per-wave form issued 8-byte loads one frame at a time: 3.1 TB/s);
-    // a head's 64 channels = 8 adjacent lanes
+__global__ __launch_bounds__(256) void traj_dxsum_kernel(const bf16_t* __restrict__ dxt, const bf16_t* __restrict__ dxdiag,
+                                                         bf16_t* __restrict__ dxsum, int64_t nchunks, int S, int F, int P, int C) {
     const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    const bool act = g < nchunks;
-    const int cpr = heads * (HD / 8);                      // chunks per (row, frame)
-    const int64_t gc = act ? g : nchunks - 1;
-    const int64_t rf = gc / cpr;
-    const int ch = (int)(gc - rf * cpr);
-    const int64_t row = rf / F;
-    const int f = (int)(rf - row * F);
+    if (g >= nchunks) return;
+    const int cpr = C / 8;
+    const int64_t row = g / cpr;
+    const int ch = (int)(g - row * cpr);
     const int s = (int)(row % S), fs = s / P;
-    Pack8 a, x;
-    a.u = *reinterpret_cast<const uint4*>(dxt + gc * 8);
-    x.u = *reinterpret_cast<const uint4*>(xt + gc * 8);
-    float gv[8];
+    Pack8 a, d2, o;
+    a.u = *reinterpret_cast<const uint4*>(dxt + ((row * F + fs) * cpr + ch) * 8);
+    d2.u = *reinterpret_cast<const uint4*>(dxdiag + g * 8);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) gv[j] = bf16_to_f32(a.e[j]);
-    if (f == fs) {
-        Pack8 d2;
-        d2.u = *reinterpret_cast<const uint4*>(dxdiag + (row * cpr + ch) * 8);
-        Pack8 o;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) { gv[j] += bf16_to_f32(d2.e[j]); o.e[j] = f32_to_bf16(gv[j]); }
-        if (act) *reinterpret_cast<uint4*>(dxsum + (row * cpr + ch) * 8) = o.u;   // dX row of the query's own frame
-    }
-    float p = 0.f;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) p = fmaf(gv[j], bf16_to_f32(x.e[j]), p);
-    p += __shfl_xor(p, 1, 64);
-    p += __shfl_xor(p, 2, 64);
-    p += __shfl_xor(p, 4, 64);
-    if (act && (ch & 7) == 0) {
-        // pre-scaled for the MFMA kernels: delta * scale, and the forward's lse in base-2 units
-        const int64_t b = row / S;
-        const int64_t o = ((b * heads + (ch >> 3)) * S + s) * F + f;
-        delta[o] = p * 0.125f;                             // scale = 1/sqrt(64)
-        lse2[o] = lse[o] * LOG2E;
-    }
+    for (int j = 0; j < 8; ++j) o.e[j] = f32_to_bf16(bf16_to_f32(a.e[j]) + bf16_to_f32(d2.e[j]));
+    *reinterpret_cast<uint4*>(dxsum + g * 8) = o.u;
 }
 
 constexpr int MAXF = 16;     // frames the per-wave lse / delta tables are sized for
@@ -124,13 +96,13 @@ constexpr int MAXF = 16;     // frames the per-wave lse / delta tables are sized
 // ------------------------------------------------------------------------------------------------
 template <int NKB>
 __global__ __launch_bounds__(256, 2) void traj_dq_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dxt,
-                                                         const bf16_t* __restrict__ dxsum, const float* __restrict__ lse,
-                                                         const float* __restrict__ delta, bf16_t* __restrict__ dqkv,
-                                                         int B, int F, int P, int heads) {
+                                                         const bf16_t* __restrict__ dxsum, const bf16_t* __restrict__ xt,
+                                                         const float* __restrict__ lse, float* __restrict__ delta,
+                                                         bf16_t* __restrict__ dqkv, int B, int F, int P, int heads) {
     __shared__ __attribute__((aligned(1024))) char ring[4 * 8192];       // after the loop: the 4 output slabs
     __shared__ __attribute__((aligned(1024))) char sDX[4 * 4096];        // per wave: [32 q][128 B] dX rows, swizzled
+    __shared__ __attribute__((aligned(1024))) char sXT[4 * 4096];        // per wave: the same rows of x~ (for delta)
     __shared__ float sLse[4][MAXF * 32];
-    __shared__ float sDel[4][MAXF * 32];
 
     const int S = F * P, N = S + 1, C = heads * HD;
     const int64_t tok = 3 * (int64_t)C;
@@ -148,7 +120,7 @@ __global__ __launch_bounds__(256, 2) void traj_dq_kernel(const bf16_t* __restric
 
     // ---- DMA helpers ----
     const int drow = lane >> 3, dkey = ((drow & 2) << 1) | ((drow >> 1) & 2), dchunk = lane & 7;
-    const uint32_t ring_a = lds_addr_of(ring), dx_a = lds_addr_of(sDX) + w * 4096;
+    const uint32_t ring_a = lds_addr_of(ring), dx_a = lds_addr_of(sDX) + w * 4096, xt_a = lds_addr_of(sXT) + w * 4096;
     auto dma_step = [&](int t) __attribute__((always_inline)) {          // K and V rows 8w..8w+7 of block (f, kb)
         const int f = t / NKB, kb = t - f * NKB;
         const int row = min(kb * 32 + w * 8 + drow, P - 1);              // padded keys: a copy of the last real row
@@ -157,22 +129,23 @@ __global__ __launch_bounds__(256, 2) void traj_dq_kernel(const bf16_t* __restric
         glds16(src, dst);
         glds16(src + C, dst + 4096);
     };
-    auto dma_dx = [&](int f) __attribute__((always_inline)) {            // this wave's 32 dX rows of frame f
+    auto dma_dx = [&](int f) __attribute__((always_inline)) {            // this wave's 32 dX rows and x~ rows of frame f
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const int s = min(bx * QT + w * 32 + g * 8 + drow, S - 1);
             const bool own = s >= f * P && s < (f + 1) * P;
-            const bf16_t* rowp = own ? dxsum + ((int64_t)b * S + s) * C : dxt + (((int64_t)b * S + s) * F + f) * C;
-            glds16(rowp + hh * HD + ((dchunk ^ (dkey | (g & 1))) << 3), __builtin_amdgcn_readfirstlane(dx_a + g * 1024));
+            const int64_t rf = (((int64_t)b * S + s) * F + f) * C;
+            const bf16_t* rowp = own ? dxsum + ((int64_t)b * S + s) * C : dxt + rf;
+            const int cofs = hh * HD + ((dchunk ^ (dkey | (g & 1))) << 3);
+            glds16(rowp + cofs, __builtin_amdgcn_readfirstlane(dx_a + g * 1024));
+            glds16(xt + rf + cofs, __builtin_amdgcn_readfirstlane(xt_a + g * 1024));
         }
     };
 
     // ---- prologue: tables, Q fragments, first DMAs ----
-    for (int f2 = h; f2 < F; f2 += 2) {
-        const int64_t sf = (((int64_t)b * heads + hh) * S + s_q) * F + f2;
-        sLse[w][f2 * 32 + r] = q_valid ? lse[sf] : INFINITY;             // (base-2 lse) +inf -> P = 0 for padded queries
-        sDel[w][f2 * 32 + r] = delta[sf];                                // (already times scale)
-    }
+    const int64_t sf0 = (((int64_t)b * heads + hh) * S + s_q) * F;
+    for (int f2 = h; f2 < F; f2 += 2)
+        sLse[w][f2 * 32 + r] = q_valid ? lse[sf0 + f2] * LOG2E : INFINITY;   // base-2 units; +inf -> P = 0 for padded queries
     bf16x8 qf[4];
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks)
@@ -191,6 +164,7 @@ __global__ __launch_bounds__(256, 2) void traj_dq_kernel(const bf16_t* __restric
     if (T > 2) dma_step(2);
 
     const char* mydx = sDX + w * 4096;
+    const char* myxt = sXT + w * 4096;
     bf16x8 df[4];
     float lse2 = 0.f, dels = 0.f;
     int t = 0;
@@ -199,11 +173,11 @@ __global__ __launch_bounds__(256, 2) void traj_dq_kernel(const bf16_t* __restric
 #pragma unroll
         for (int kb = 0; kb < NKB; ++kb, ++t) {
             // ---- step t landed?  instructions issued after it: steps t+1, t+2 (2 each) and, for kb = 1..3, the
-            // 4 dX instructions of frame f+1 issued at kb = 0 ----
+            // 8 dX / x~ instructions of frame f+1 issued at kb = 0 ----
             // (spelled out as compile-time counts: a run-time switch here cost a maze of ~100 scalar instructions per step)
             if (t + 2 < T) {
                 if (kb == 0) { if (NKB >= 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-                else if (kb <= 3 && more) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                else if (kb <= 3 && more) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
                 else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
             } else if (t + 1 < T && NKB >= 4) {
                 asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
@@ -217,8 +191,20 @@ __global__ __launch_bounds__(256, 2) void traj_dq_kernel(const bf16_t* __restric
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks) df[ks] = *reinterpret_cast<const bf16x8*>(mydx + swz(r, ks * 2 + h));
                 lse2 = sLse[w][f * 32 + r];
-                dels = sDel[w][f * 32 + r];
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // the dX tile is free for frame f+1
+                // delta[q, f] = scale * sum_d dX[q,d] x~[q,d]: this lane holds 32 of the 64 channels of query r
+                float dsum = 0.f;
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    Pack8 xa, da;
+                    xa.v = *reinterpret_cast<const bf16x8*>(myxt + swz(r, ks * 2 + h));
+                    da.v = df[ks];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) dsum = fmaf(bf16_to_f32(da.e[j]), bf16_to_f32(xa.e[j]), dsum);
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // the dX / x~ tiles are free for frame f+1
+                dsum += __shfl_xor(dsum, 32, 64);
+                dels = dsum * scale;
+                if (h == 0 && q_valid) delta[sf0 + f] = dels;            // for the dK / dV kernel (already times scale)
             }
             if (t + 3 < T) dma_step(t + 3);
             if (kb == 0 && more) dma_dx(f + 1);
@@ -349,7 +335,7 @@ __global__ __launch_bounds__(64 * NKB) void traj_dkv_kernel(const bf16_t* __rest
             } else if (i == 8) {
                 // lanes 0-31: lse of the chunk's queries, lanes 32-63: delta (4 B per lane, 256-B piece)
                 const int s = min(ch * QC + r, S - 1);
-                const float* src = (h ? delta : lse) + (((int64_t)b * heads + hh) * S + s) * F + f;   // lse: base-2 copy
+                const float* src = (h ? delta : lse) + (((int64_t)b * heads + hh) * S + s) * F + f;
                 glds4(src, __builtin_amdgcn_readfirstlane(ring_a + 4 * 8192 + (ch & 3) * 256));
             }
         }
@@ -382,13 +368,13 @@ __global__ __launch_bounds__(64 * NKB) void traj_dkv_kernel(const bf16_t* __rest
             dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da, vf[ks], dp, 0, 0, 0);
         }
         // rows of the tile: q = (i&3) + 8*(i>>2) + 4*h  -> 4 consecutive floats per group of 4 registers.
-        // lse arrives in base-2 units and delta times scale (traj_delta_kernel).  Keys past P need no mask: they only
-        // reach accumulator rows that are never stored.
+        // lse arrives in natural-log units (the forward's), delta times scale (traj_dq_kernel).  Keys past P need no mask:
+        // they only reach accumulator rows that are never stored.
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const float4 l4 = *reinterpret_cast<const float4*>(sl + 8 * g + 4 * h);
             const float4 d4 = *reinterpret_cast<const float4*>(sl + 32 + 8 * g + 4 * h);
-            const float ls[4] = {l4.x, l4.y, l4.z, l4.w}, de[4] = {d4.x, d4.y, d4.z, d4.w};
+            const float ls[4] = {l4.x * LOG2E, l4.y * LOG2E, l4.z * LOG2E, l4.w * LOG2E}, de[4] = {d4.x, d4.y, d4.z, d4.w};
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int i = 4 * g + e;
@@ -431,11 +417,11 @@ __global__ __launch_bounds__(64 * NKB) void traj_dkv_kernel(const bf16_t* __rest
 }
 
 template <int NB>
-int launch_dq(const void* qkv, const void* dxt, const void* dxsum, const float* lse, const float* delta, void* dqkv,
+int launch_dq(const void* qkv, const void* dxt, const void* dxsum, const void* xt, const float* lse, float* delta, void* dqkv,
               int B, int F, int P, int heads, hipStream_t s) {
     const int S = F * P;
     hipLaunchKernelGGL((traj_dq_kernel<NB>), dim3((S + QT - 1) / QT, B * heads), dim3(256), 0, s, (const bf16_t*)qkv,
-                       (const bf16_t*)dxt, (const bf16_t*)dxsum, lse, delta, (bf16_t*)dqkv, B, F, P, heads);
+                       (const bf16_t*)dxt, (const bf16_t*)dxsum, (const bf16_t*)xt, lse, delta, (bf16_t*)dqkv, B, F, P, heads);
     FOCUS_CHECK_LAUNCH();
     return FOCUS_OK;
 }
@@ -452,20 +438,21 @@ int launch_dkv(const void* qkv, const void* dxt, const void* dxsum, const float*
 }  // namespace
 
 // Patch-token rows of dqkv (q, k and v parts of tokens 1..N-1) are fully written; the cls row/parts are the caller's.
-// delta, lse2: [B,h,S,F] fp32 scratch each; dxsum: [B,S,C] bf16 scratch.
+// delta: [B,h,S,F] fp32 scratch (written by the dQ kernel, read by the dK/dV kernel); dxsum: [B,S,C] bf16 scratch;
+// lse2 is unused since round 3 (kept in the signature: the workspace layout of focus_traj_space_bwd is unchanged).
 int focus_traj_space_bwd_mfma(const void* qkv, const void* xt, const float* lse, const void* dxt, const void* dxdiag,
                               float* delta, float* lse2, void* dxsum, void* dqkv, int B, int F, int P, int heads,
                               hipStream_t s) {
+    (void)lse2;
     if (B * heads > 65535 || F > MAXF || P > 32 * FOCUS_TRAJ_MAX_KEY_BLOCKS) return FOCUS_ERR_SHAPE;
-    const int S = F * P;
-    const int64_t rows = (int64_t)B * S;
-    const int64_t nchunks = rows * F * heads * (HD / 8);
-    hipLaunchKernelGGL(traj_delta_kernel, dim3((unsigned)cdiv64(nchunks, 256)), dim3(256), 0, s, (const bf16_t*)dxt,
-                       (const bf16_t*)dxdiag, (const bf16_t*)xt, lse, delta, lse2, (bf16_t*)dxsum, nchunks, S, F, P, heads);
+    const int S = F * P, C = heads * HD;
+    const int64_t nchunks = (int64_t)B * S * (C / 8);
+    hipLaunchKernelGGL(traj_dxsum_kernel, dim3((unsigned)cdiv64(nchunks, 256)), dim3(256), 0, s, (const bf16_t*)dxt,
+                       (const bf16_t*)dxdiag, (bf16_t*)dxsum, nchunks, S, F, P, C);
     FOCUS_CHECK_LAUNCH();
     int rc = FOCUS_ERR_SHAPE;
-    // dQ streams the frame's ceil(P/32) key blocks (exact count: the tail mask sits in the last one)
-#define DQ(K) case K: rc = launch_dq<K>(qkv, dxt, dxsum, lse2, delta, dqkv, B, F, P, heads, s); break
+    // dQ streams the frame's ceil(P/32) key blocks (exact count: the tail mask sits in the last one) and writes delta
+#define DQ(K) case K: rc = launch_dq<K>(qkv, dxt, dxsum, xt, lse, delta, dqkv, B, F, P, heads, s); break
     switch ((P + 31) / 32) {
         DQ(1); DQ(2); DQ(3); DQ(4); DQ(5); DQ(6); DQ(7); DQ(8); DQ(9); DQ(10); DQ(11); DQ(12); DQ(13); DQ(14);
         default: break;
@@ -475,7 +462,7 @@ int focus_traj_space_bwd_mfma(const void* qkv, const void* xt, const float* lse,
     // dK/dV: one workgroup per (frame, key tile of NKB blocks), one wave per block
     int nkb, nt;
     focus_traj_space_tiling(P, &nkb, &nt);
-#define DKV(K) case K: return launch_dkv<K>(qkv, dxt, dxsum, lse2, delta, dqkv, B, F, P, heads, nt, s)
+#define DKV(K) case K: return launch_dkv<K>(qkv, dxt, dxsum, lse, delta, dqkv, B, F, P, heads, nt, s)
     switch (nkb) {
         DKV(1); DKV(2); DKV(3); DKV(4); DKV(5); DKV(6); DKV(7);
         default: break;

@@ -54,6 +54,8 @@ def _mfma_path(ta, sA, sB, K):
     """'nt' / 'tn' when the C dispatcher will take that MFMA kernel for this descriptor, else None."""
     if ta.dtype != torch.bfloat16:
         return None
+    if sA[1] == 1 and sB[0] == 1 and K > 0 and K % 64 == 0 and sA[0] % 8 == 0 and sB[1] % 16 == 0:
+        return "nt"
     if sA[1] == 1 and sB[0] == 1 and K > 0 and K % 64 == 0 and sA[0] % 8 == 0 and sB[1] % 8 == 0:
         return "nt"
     if sA[0] == 1 and sB[1] == 1 and sA[1] % 8 == 0 and sB[0] % 8 == 0:
@@ -62,8 +64,9 @@ def _mfma_path(ta, sA, sB, K):
 
 
 def gemm(M, N, K, A, sA, B, sB, C, sC, batch=(1, 1), bias=None, residual=None, aux=None, alpha=1.0,
-         accumulate=False, epilogue=EPI_NONE):
-    """C = epi(alpha*A.B + bias) + residual.  A/B/C are (tensor, element_offset); s* = (rs, cs, bs0, bs1)."""
+         accumulate=False, epilogue=EPI_NONE, b_scale=None):
+    """C = epi(alpha*A.B + bias) + residual.  A/B/C are (tensor, element_offset); s* = (rs, cs, bs0, bs1).
+    b_scale: B holds OCP e4m3 codes (a uint8 tensor) with this per-tensor fp32 scale (device scalar); A is bf16."""
     d = GemmDesc()
     d.M, d.N, d.K = M, N, K
     d.batch0, d.batch1 = batch
@@ -80,7 +83,12 @@ def gemm(M, N, K, A, sA, B, sB, C, sC, batch=(1, 1), bias=None, residual=None, a
     d.epilogue = epilogue
     d.dtype_ab = _dt(ta)
     d.dtype_c = _dt(tc)
-    assert ta.dtype == tb.dtype
+    if b_scale is not None:
+        assert tb.dtype == torch.uint8 and ta.dtype == torch.bfloat16, "fp8 weights go with bf16 activations"
+        d.dtype_b = _lib.FP8_E4M3
+        d.b_scale = b_scale.data_ptr()
+    else:
+        assert ta.dtype == tb.dtype
     kind = _mfma_path(ta, sA, sB, K) if GEMM_TIMING is not None else None
     if kind:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -88,20 +96,20 @@ def gemm(M, N, K, A, sA, B, sB, C, sC, batch=(1, 1), bias=None, residual=None, a
         _lib.check(_lib.lib().focus_gemm(ctypes.byref(d), _stream()), "gemm")
         e1.record()
         if kind == "nt" and _lib.lib().focus_gemm_last_kernel() == 2:
-            kind = "nt_ws"                                        # the wave-specialised kernel (gemm_mfma_ws.hip)
+            kind = "nt_ws8" if b_scale is not None else "nt_ws"   # the wave-specialised kernel (gemm_mfma_ws.hip)
         GEMM_TIMING.append((2.0 * M * N * K * batch[0] * batch[1], e0, e1, kind, (M, N, K, batch[0] * batch[1], epilogue)))
         return
     _lib.check(_lib.lib().focus_gemm(ctypes.byref(d), _stream()), "gemm")
 
 
-def mm_nt(a, b, bias=None, residual=None, aux=None, epilogue=EPI_NONE, out_dtype=None, alpha=1.0, out=None):
-    """a [M,K] . b[N,K]^T -> [M,N]  (both K-contiguous: the MFMA layout)."""
+def mm_nt(a, b, bias=None, residual=None, aux=None, epilogue=EPI_NONE, out_dtype=None, alpha=1.0, out=None, b_scale=None):
+    """a [M,K] . b[N,K]^T -> [M,N]  (both K-contiguous: the MFMA layout).  b_scale: b holds e4m3 codes (see gemm)."""
     M, K = a.shape
     N = b.shape[0]
     c = out if out is not None else torch.empty(M, N, device=a.device, dtype=out_dtype or a.dtype)
     gemm(M, N, K, (a, 0), (a.stride(0), 1, 0, 0), (b, 0), (1, b.stride(0), 0, 0), (c, 0), (N, 1, 0, 0),
          bias=bias, residual=(residual, 0) if residual is not None else None,
-         aux=(aux, 0) if aux is not None else None, alpha=alpha, epilogue=epilogue)
+         aux=(aux, 0) if aux is not None else None, alpha=alpha, epilogue=epilogue, b_scale=b_scale)
     return c
 
 
@@ -221,6 +229,8 @@ def invalidate_shadows():
     global _shadow_gen
     _shadow_gen += 1
     _refresh_shadows_batched()
+    if _fp8_cache:
+        refresh_fp8_shadows()
 
 
 _shadow_tables = {}      # device -> (signature, items tensor, max_rows, max_cols, [(key, weakref)])
@@ -282,6 +292,8 @@ def shadows_written(entries):
             hit = _shadow_cache.get(key)
             if hit is not None and hit[2] is out:
                 _shadow_cache[key] = (hit[0], (w._version, w.data_ptr(), _shadow_gen), out)
+    if _fp8_cache:
+        refresh_fp8_shadows()
 
 
 def drop_caches():
@@ -291,6 +303,8 @@ def drop_caches():
     _shadow_cache.clear()
     _shadow_tables.clear()
     _stacked.clear()
+    _fp8_cache.clear()
+    _fp8_tables.clear()
 
 
 def shadow(w, dtype, transposed=False):
@@ -315,8 +329,96 @@ def shadow(w, dtype, transposed=False):
     return out
 
 
-def _dx_from(dy, w, dtype, aux=None, epilogue=EPI_NONE, alpha=1.0):
-    """alpha * dy [M,N] . w[N,K] -> [M,K]."""
+# --------------------------------------------------------------------------------------------------
+# fp8 (OCP e4m3) working copies of the Linear weights: BASELINE configs[4] "fp8 MFMA weights", SURVEY 8(d) config 5
+# "fp8 weights for the Linear GEMMs, bf16 activations".  One scale per tensor (amax / 448), the SAME codes in both
+# orientations: the forward reads W_q [N,K], the dX GEMM its transpose [K,N]; the fp32 masters, the weight gradients
+# (activations x activations) and everything else are untouched.  `with ops.fp8_weights(True):` around a forward makes
+# its Linear / MLP nodes take the fp8 B operand (their backward follows what the forward used).
+# --------------------------------------------------------------------------------------------------
+FP8_WEIGHTS = False
+_FP8_MIN_ROWS = 1024          # fewer activation rows: the bf16 small-row kernels (the fp8 instances are the large tiles)
+_fp8_cache = {}               # id(w) -> [weakref, stamp, codes [N,K] uint8, codesT [K,N] uint8, scale [1] fp32]
+_fp8_tables = {}              # device -> (signature, items tensor, max_rows, max_cols, amax scratch)
+
+
+class fp8_weights:
+    def __init__(self, on=True):
+        self.on = bool(on)
+
+    def __enter__(self):
+        global FP8_WEIGHTS
+        self.prev = FP8_WEIGHTS
+        FP8_WEIGHTS = self.on
+        return self
+
+    def __exit__(self, *exc):
+        global FP8_WEIGHTS
+        FP8_WEIGHTS = self.prev
+        return False
+
+
+def fp8_ok(w, rows, dtype):
+    return (FP8_WEIGHTS and dtype == torch.bfloat16 and w.dim() == 2 and w.dtype == torch.float32 and w.is_cuda
+            and rows >= _FP8_MIN_ROWS and w.shape[0] % 64 == 0 and w.shape[1] % 64 == 0 and w.is_contiguous()
+            and w.data_ptr() % 16 == 0)
+
+
+def _fp8_run(dev, entries):
+    import numpy as np
+    sig = tuple((e[2].data_ptr(), e[3].data_ptr(), e[4].data_ptr(), w.data_ptr()) for w, e in entries)
+    tab = _fp8_tables.get(dev)
+    if tab is None or tab[0] != sig:
+        rec = np.zeros((len(entries), 5), dtype=np.int64)          # focus_fp8_item: 4 pointers + (rows, cols)
+        mr = mc = 0
+        for n, (w, e) in enumerate(entries):
+            rec[n, 0], rec[n, 1], rec[n, 2], rec[n, 3] = w.data_ptr(), e[2].data_ptr(), e[3].data_ptr(), e[4].data_ptr()
+            rec[n, 4] = int(w.shape[0]) | (int(w.shape[1]) << 32)
+            mr, mc = max(mr, w.shape[0]), max(mc, w.shape[1])
+        tab = (sig, torch.from_numpy(rec).to(dev), mr, mc, torch.empty(len(entries), dtype=torch.int32, device=dev))
+        if len(entries) > 1:
+            _fp8_tables[dev] = tab
+    with torch.cuda.device(dev):
+        _lib.check(_lib.lib().focus_fp8_refresh(_p(tab[1]), len(entries), tab[2], tab[3], _p(tab[4]), _stream()), "fp8_refresh")
+    for w, e in entries:
+        e[1] = (w._version, w.data_ptr(), _shadow_gen)
+
+
+def refresh_fp8_shadows():
+    """Requantise every cached fp8 weight copy from its fp32 master (one amax + one quantise launch per device): called
+    after an optimizer step, like the bf16 shadows."""
+    by_dev = {}
+    for key, e in list(_fp8_cache.items()):
+        w = e[0]()
+        if w is None:
+            _fp8_cache.pop(key, None)
+            continue
+        by_dev.setdefault(w.device, []).append((w, e))
+    for dev, entries in by_dev.items():
+        _fp8_run(dev, entries)
+
+
+def shadow_fp8(w, transposed=False):
+    """(e4m3 codes as a uint8 tensor -- [N,K], or [K,N] when transposed --, scale [1] fp32) of the 2-D weight w [N,K]."""
+    e = _fp8_cache.get(id(w))
+    if e is None or e[0]() is not w:
+        N, K = w.shape
+        e = _fp8_cache[id(w)] = [weakref.ref(w, lambda _r, k=id(w): _fp8_cache.pop(k, None)), None,
+                                 torch.empty(N, K, dtype=torch.uint8, device=w.device),
+                                 torch.empty(K, N, dtype=torch.uint8, device=w.device),
+                                 torch.empty(1, dtype=torch.float32, device=w.device)]
+        _fp8_tables.pop(w.device, None)
+    if e[1] != (w._version, w.data_ptr(), _shadow_gen):
+        _fp8_run(w.device, [(w.detach(), e)])
+        e[1] = (w._version, w.data_ptr(), _shadow_gen)
+    return (e[3] if transposed else e[2]), e[4]
+
+
+def _dx_from(dy, w, dtype, aux=None, epilogue=EPI_NONE, alpha=1.0, fp8=False):
+    """alpha * dy [M,N] . w[N,K] -> [M,K].  fp8: the forward multiplied by the e4m3 copy of w, so does this."""
+    if fp8:
+        wq, sc = shadow_fp8(w, transposed=True)
+        return mm_nt(dy, wq, aux=aux, epilogue=epilogue, alpha=alpha, b_scale=sc)
     if dtype == torch.bfloat16 and w.shape[0] % 64 == 0:
         return mm_nt(dy, shadow(w, dtype, transposed=True), aux=aux, epilogue=epilogue, alpha=alpha)
     return mm_nn(dy, shadow(w, dtype), aux=aux, epilogue=epilogue, alpha=alpha)
@@ -455,7 +557,12 @@ class _LinearFn(torch.autograd.Function):
         if not x2.is_contiguous():
             x2 = x2.contiguous()
         r2 = residual.reshape(-1, w.shape[0]).contiguous() if residual is not None else None
-        y = mm_nt(x2, shadow(w, x.dtype), bias=b, residual=r2, alpha=alpha)
+        ctx.fp8 = fp8_ok(w, x2.shape[0], x.dtype)
+        if ctx.fp8:
+            wq, sc = shadow_fp8(w)
+            y = mm_nt(x2, wq, bias=b, residual=r2, alpha=alpha, b_scale=sc)
+        else:
+            y = mm_nt(x2, shadow(w, x.dtype), bias=b, residual=r2, alpha=alpha)
         ctx.save_for_backward(x2, w)
         ctx.has_b, ctx.has_r, ctx.shp, ctx.alpha = b is not None, residual is not None, shp, alpha
         ctx.defer = _defer_open("linear", (w, b), x2.shape[0], ctx.needs_input_grad[1], alpha)
@@ -481,10 +588,7 @@ class _LinearFn(torch.autograd.Function):
         elif want_b:
             db = colsum(dy2)
         if ctx.needs_input_grad[0]:
-            if ctx.alpha == 1.0:
-                dx = _dx_from(dy2, w, dy2.dtype).reshape(ctx.shp)
-            else:
-                dx = _dx_from(dy2, w, dy2.dtype, alpha=ctx.alpha).reshape(ctx.shp)
+            dx = _dx_from(dy2, w, dy2.dtype, alpha=ctx.alpha, fp8=ctx.fp8).reshape(ctx.shp)
         if join is not None:
             join()
         return dx, dw, db, (dy if ctx.has_r else None), None
@@ -583,9 +687,15 @@ class _MlpFn(torch.autograd.Function):
         M = x2.shape[0]
         H = w1.shape[0]
         z = torch.empty(M, H, device=x.device, dtype=x.dtype) if act == EPI_GELU else None
-        a = mm_nt(x2, shadow(w1, x.dtype), bias=b1, aux=z, epilogue=act)
+        ctx.fp8 = fp8_ok(w1, M, x.dtype) and fp8_ok(w2, M, x.dtype)
         r2 = residual.reshape(-1, w2.shape[0]).contiguous() if residual is not None else None
-        y = mm_nt(a, shadow(w2, x.dtype), bias=b2, residual=r2)
+        if ctx.fp8:
+            (q1, s1), (q2, s2) = shadow_fp8(w1), shadow_fp8(w2)
+            a = mm_nt(x2, q1, bias=b1, aux=z, epilogue=act, b_scale=s1)
+            y = mm_nt(a, q2, bias=b2, residual=r2, b_scale=s2)
+        else:
+            a = mm_nt(x2, shadow(w1, x.dtype), bias=b1, aux=z, epilogue=act)
+            y = mm_nt(a, shadow(w2, x.dtype), bias=b2, residual=r2)
         ctx.save_for_backward(x2, w1, w2, a, z)
         ctx.act, ctx.shp = act, shp
         ctx.has = (b1 is not None, b2 is not None, residual is not None)
@@ -615,7 +725,7 @@ class _MlpFn(torch.autograd.Function):
         else:
             dw2, db2 = None, (colsum(dy2) if ctx.has[1] else None)
         # dz = (dy . w2) * act'(.) fused in the GEMM epilogue
-        dz = _dx_from(dy2, w2, dy2.dtype, aux=(z if ctx.act == EPI_GELU else a), epilogue=_DEPI[ctx.act])
+        dz = _dx_from(dy2, w2, dy2.dtype, aux=(z if ctx.act == EPI_GELU else a), epilogue=_DEPI[ctx.act], fp8=ctx.fp8)
         if dfr is not None:
             dw1 = db1 = None
             done = _defer_close(dfr[0], (dz, x2))
@@ -625,7 +735,7 @@ class _MlpFn(torch.autograd.Function):
             dw1, db1, join1 = wgrad_async(dz, x2, ctx.has[0])
         else:
             dw1, db1 = None, (colsum(dz) if ctx.has[0] else None)
-        dx = _dx_from(dz, w1, dz.dtype).reshape(ctx.shp) if ctx.needs_input_grad[0] else None
+        dx = _dx_from(dz, w1, dz.dtype, fp8=ctx.fp8).reshape(ctx.shp) if ctx.needs_input_grad[0] else None
         for j in (join2, join1):
             if j is not None:
                 j()

@@ -44,6 +44,9 @@ class Motionformer(nn.Module):
             raise NotImplementedError("hot path = video input with separate space/time position embeddings")
         # bf16 storage + fp32 accumulation when TRAIN.MIXED_PRECISION (the reference autocasts to fp16)
         self.compute_dtype = torch.bfloat16 if cfg.TRAIN.MIXED_PRECISION else torch.float32
+        # build-owned key (BASELINE configs[4]): the Linear weights of the blocks are multiplied as OCP e4m3 copies with one
+        # scale per tensor, activations stay bf16 (focus_amd.ops.fp8_weights); needs the bf16 compute dtype
+        self.fp8_weights = bool(cfg.TRAIN.get("FP8_WEIGHTS", False)) and cfg.TRAIN.MIXED_PRECISION
 
         k = [cfg.MF.PATCH_SIZE_TEMP, self.patch_size, self.patch_size]
         self.patch_embed_3d = stem_helper.PatchEmbed(dim_in=self.in_chans, dim_out=self.embed_dim, kernel=k, stride=k,
@@ -137,8 +140,9 @@ class Motionformer(nn.Module):
             x = self.pos_drop(x)
         side = int(npatch ** 0.5)
         thw = [self.temporal_resolution, side, side]
-        for blk in self.blocks:
-            x, _ = blk(x, metadata, thw)
+        with ops.fp8_weights(self.fp8_weights):
+            for blk in self.blocks:
+                x, _ = blk(x, metadata, thw)
         n = self.norm
         x = ops.layer_norm(x[:, 0].contiguous(), n.weight, n.bias, n.eps)    # LN is per token: only cls is needed
         if self.use_mlp:

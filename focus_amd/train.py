@@ -196,10 +196,16 @@ class GraphedStep:
         ok = {id(t) for t in allow_live}
         live = [t for t in live_autograd_tensors(torch.device("cuda", torch.cuda.current_device())) if id(t) not in ok]
         if live:
-            raise RuntimeError("GraphedStep: %d CUDA tensor(s) of an earlier forward are still referenced (shapes %s); their "
-                               "autograd graph would be alive across the capture (crash in hipStreamEndCapture on ROCm 7.2). "
-                               "Drop them (del / detach) before building the graph" %
-                               (len(live), [tuple(t.shape) for t in live[:4]]))
+            def who(t):
+                try:
+                    return [type(r).__name__ + (":" + ",".join(k for k, v in r.items() if v is t)[:60] if isinstance(r, dict) else "")
+                            for r in gc.get_referrers(t) if r is not live][:3]
+                except Exception:
+                    return []
+            raise RuntimeError("GraphedStep: %d CUDA tensor(s) of an earlier forward are still referenced (shape, grad_fn, held by: "
+                               "%s); their autograd graph would be alive across the capture (crash in hipStreamEndCapture on "
+                               "ROCm 7.2).  Drop them (del / detach) before building the graph" %
+                               (len(live), [(tuple(t.shape), type(t.grad_fn).__name__, who(t)) for t in live[:4]]))
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             self.outputs = fn()

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-enum focus_dtype { FOCUS_F32 = 0, FOCUS_BF16 = 1 };
+enum focus_dtype { FOCUS_F32 = 0, FOCUS_BF16 = 1, FOCUS_FP8_E4M3 = 2 /* OCP e4m3fn codes: weights (B operand) only */ };
 
 enum focus_status {
     FOCUS_OK = 0,
@@ -74,6 +74,10 @@ typedef struct focus_gemm_desc {
     int32_t epilogue;         /* enum focus_epilogue                                                */
     int32_t dtype_ab;         /* storage of A and B                                                 */
     int32_t dtype_c;          /* storage of C, residual and aux                                     */
+    int32_t dtype_b;          /* 0: B is stored like A.  FOCUS_FP8_E4M3: B holds e4m3 codes (1 byte per element,
+                                 strides in elements), A is bf16: the "fp8 weights, bf16 activations" GEMM     */
+    int32_t pad_;
+    const float* b_scale;     /* DEVICE scalar: the per-tensor scale of an fp8 B (C = epi(alpha * b_scale * A.B ...)) */
 } focus_gemm_desc;
 
 int focus_gemm(const focus_gemm_desc* desc, void* stream);
@@ -382,6 +386,17 @@ size_t focus_adamw_workspace_bytes(void);
 int focus_adamw_step(const focus_adamw_item* items, float* const* grads, int n_items, int n_units, const float* groups, float* steps,
                      void* workspace, size_t workspace_bytes, float* total_norm, double beta1, double beta2, float eps,
                      float max_norm, int write_clipped_grads, void* stream);
+
+/* OCP FP8 E4M3 working copies of fp32 master weights with one scale per tensor (BASELINE configs[4]; the reference's
+ * EK_ORVIT_MF_HR.yaml trains fp16-autocast: these replace autocast's per-use fp16 weight casts, train_net.py:84):
+ * scale = amax|w| / 448, dst[r,c] = e4m3(w[r,c] / scale) (row-major, optional), dstT[c,r] = the same code transposed
+ * (the K-contiguous B operand of the dX GEMM, optional), *scale = the fp32 scale (1 for an all-zero tensor).
+ * `items`: DEVICE array; rows % 4 == 0, cols % 4 == 0, 16-byte aligned src.  amax_scratch: n_items x 4 bytes. */
+typedef struct focus_fp8_item {
+    const float* src; void* dst; void* dstT; float* scale;
+    int32_t rows, cols;
+} focus_fp8_item;
+int focus_fp8_refresh(const focus_fp8_item* items, int n_items, int max_rows, int max_cols, void* amax_scratch, void* stream);
 
 /* xdiag[b,s,:] = xt[b,s,s/P,:] (attention.py:533-535) and its adjoint dxt[b,s,s/P,:] += dxdiag[b,s,:]. */
 int focus_diag_gather(const void* xt, void* xdiag, int B, int S, int F, int C, int dtype, void* stream);

@@ -9,6 +9,7 @@ absent: that one op stays "parity unpinned").
 import os
 import sys
 import types
+from collections import OrderedDict
 
 import numpy as np
 import torch
@@ -412,6 +413,79 @@ def main_metrics():
              multitask=np.array([float(x) for x in mt.multitask_topks_correct((scores, s2), (labels, l2), (1, 5))]))
     print("wrote metrics.npz")
 
+def main_ckpt():
+    """14. Checkpoint I/O: the reference's own slowfast/utils/checkpoint.py -- save_checkpoint (:112-159)
+    WRITES tests/golden/ckpt_small.pyth from its Motionformer carrying the motionformer_small fixture weights and a stepped
+    AdamW; its load_checkpoint (:201-394, split_qkv :586-597) then loads (a) that file for a resume and (b) a "pre-trained"
+    variant with a `module.` prefix, a 174-way head and the epoch_reset / clear_name_pattern / replace_name_pattern /
+    load_orvit_attn_from_bb switches; the resulting model states are the expected outputs (ckpt_small_expected.npz).
+    pathmgr (iopath) is plumbing: a stand-in over os / open."""
+    from oracle._ref_loader import _load, _ns
+    mods = load_motionformer(load_reference(_roi_align_tv))
+    env = _ns("slowfast.utils.env")
+
+    class _PM:
+        exists = staticmethod(os.path.exists)
+        mkdirs = staticmethod(lambda p: os.makedirs(p, exist_ok=True))
+        ls = staticmethod(os.listdir)
+        open = staticmethod(open)
+    env.checkpoint_pathmgr = _PM
+    env.pathmgr = _PM
+    _load("slowfast.utils.c2_model_loading", "slowfast/utils/c2_model_loading.py")
+    ck = _load("slowfast.utils.checkpoint", "slowfast/utils/checkpoint.py")
+    z = np.load(os.path.join(OUT, "motionformer_small.npz"))
+    params = {k[2:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("p.")}
+    cfg = small_cfg()
+    cfg.NUM_GPUS, cfg.NUM_SHARDS = 1, 1
+    cfg.dump = lambda: "MODEL:\n  MODEL_NAME: Motionformer\n"
+    torch.manual_seed(0)
+    m = mods["video_model_builder"].Motionformer(cfg)
+    m.load_state_dict(params)
+    opt = torch.optim.AdamW(m.parameters(), lr=1e-3)
+    g = torch.Generator().manual_seed(4)
+    for p_ in m.parameters():
+        p_.grad = torch.randn(p_.shape, generator=g) * 0.01
+    opt.step()                                            # a real optimizer state (step, exp_avg, exp_avg_sq) ...
+    m.load_state_dict(params)                             # ... around the fixture's weights
+    import tempfile
+    tmp = tempfile.mkdtemp()
+    path = ck.save_checkpoint(tmp, m, opt, 3, cfg, name="checkpoint_epoch_00004")
+    import shutil
+    shutil.copy(path, os.path.join(OUT, "ckpt_small.pyth"))
+    # (a) resume into a differently initialised model
+    torch.manual_seed(1)
+    m2 = mods["video_model_builder"].Motionformer(cfg)
+    opt2 = torch.optim.AdamW(m2.parameters(), lr=1e-3)
+    epoch = ck.load_checkpoint(path, m2, data_parallel=False, optimizer=opt2)
+    out = {"resume_epoch": np.int64(epoch)}
+    out.update(pack("resume.", m2.state_dict()))
+    out["resume_opt_step"] = np.float64(float(opt2.state_dict()["state"][0]["step"]))
+    out["resume_opt_exp_avg0"] = opt2.state_dict()["state"][0]["exp_avg"].numpy()
+    # (b) "pre-trained backbone" file: DDP prefix, a 174-way head, backbone attention to be copied into orvit_ names
+    sd = OrderedDict(("module." + k, v.clone()) for k, v in m.state_dict().items())
+    sd["module.head.weight"] = torch.zeros(174, 64)
+    sd["module.head.bias"] = torch.zeros(174)
+    sd["module.unknown.weight"] = torch.ones(3)
+    pre = os.path.join(tmp, "pretrained.pyth")
+    torch.save({"epoch": 9, "model_state": sd, "optimizer_state": {}, "cfg": ""}, pre)
+    shutil.copy(pre, os.path.join(OUT, "ckpt_small_pretrained.pyth"))
+    torch.manual_seed(2)
+    m3 = mods["video_model_builder"].Motionformer(cfg)
+    before = {k: v.clone() for k, v in m3.state_dict().items()}
+    epoch3 = ck.load_checkpoint(pre, m3, data_parallel=False, epoch_reset=True, clear_name_pattern=("module.",),
+                                replace_name_pattern=(("nonexistent_a", "nonexistent_b"),), load_orvit_attn_from_bb=True)
+    out["finetune_epoch"] = np.int64(epoch3)
+    out.update(pack("finetune.", m3.state_dict()))
+    out["finetune_untouched"] = np.array(sorted(k for k, v in m3.state_dict().items() if torch.equal(v, before[k])))
+    # split_qkv on its own (:586-597)
+    sq = ck.split_qkv(OrderedDict([("blocks.0.attn.qkv.weight", torch.arange(24.).reshape(6, 4)), ("x", torch.ones(2))]))
+    out["split_keys"] = np.array(list(sq.keys()))
+    out["split_q"] = sq["blocks.0.attn.q.weight"].numpy()
+    out["split_v"] = sq["blocks.0.attn.v.weight"].numpy()
+    np.savez(os.path.join(OUT, "ckpt_small_expected.npz"), **out)
+    print("wrote ckpt_small.pyth, ckpt_small_pretrained.pyth, ckpt_small_expected.npz")
+
+
 def _load_losses():
     """The reference's own slowfast/models/losses.py (plain torch + the stubbed logger)."""
     from oracle._ref_loader import _load
@@ -427,7 +501,9 @@ def mods_loss(logits, labels):
 
 
 if __name__ == "__main__":
-    if "--metrics-only" in sys.argv:
+    if "--ckpt-only" in sys.argv:
+        main_ckpt()
+    elif "--metrics-only" in sys.argv:
         main_metrics()
     elif "--data-only" in sys.argv:
         main_data()
@@ -440,3 +516,4 @@ if __name__ == "__main__":
         main_steve()
         main_data()
         main_metrics()
+        main_ckpt()

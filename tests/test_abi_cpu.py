@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol(built):
     for name in decl:
         assert hasattr(L, name), "missing export: " + name
     lib = _lib.lib()
-    assert lib.focus_abi_version() == 1
+    assert lib.focus_abi_version() == 2
     assert lib.focus_strerror(-1) == b"bad shape" and lib.focus_strerror(0) == b"ok"
     # pure host-side queries work without a GPU
     assert lib.focus_layernorm_bwd_blocks(10) == 3 and lib.focus_layernorm_bwd_blocks(10 ** 6) == 512
@@ -34,7 +34,7 @@ def test_library_exports_every_declared_symbol(built):
 
 def test_gemm_desc_layout_matches_header():
     from focus_amd._lib import GemmDesc
-    assert ctypes.sizeof(GemmDesc) == 192       # 5 int32 (+pad) | 3 x (ptr + 4 int64) | 3 ptr | f32 + 4 int32 (+pad)
+    assert ctypes.sizeof(GemmDesc) == 208       # 5 int32 (+pad) | 3 x (ptr + 4 int64) | 3 ptr | f32 + 4 int32 (+pad) | dtype_b, pad, b_scale ptr
     assert GemmDesc.A.offset == 24 and GemmDesc.bias.offset == 144 and GemmDesc.alpha.offset == 168
 
 

@@ -123,3 +123,68 @@ def test_checkpoint_epoch_schedule():
     assert [e for e in range(12) if cu.is_checkpoint_epoch(cfg, e)] == [4, 9, 11]
     cfg.TRAIN.VAL_ONLY = True
     assert not cu.is_checkpoint_epoch(cfg, 11)
+
+
+# ---- files WRITTEN by the reference's own checkpoint.py (oracle/make_golden.py main_ckpt) ------------------------------
+def _golden(name):
+    from conftest import GOLDEN
+    return os.path.join(GOLDEN, name)
+
+
+def _expected():
+    import numpy as np
+    return np.load(_golden("ckpt_small_expected.npz"), allow_pickle=False)
+
+
+def test_reference_written_checkpoint_resumes_like_the_reference(tmp_path):
+    """ckpt_small.pyth was written by the reference's save_checkpoint (checkpoint.py:112-159); loading it here must leave
+    the model, the optimizer state and the epoch exactly as the reference's load_checkpoint (:201-394) left its own."""
+    import numpy as np
+    e = _expected()
+    ck = torch.load(_golden("ckpt_small.pyth"), map_location="cpu", weights_only=True)     # nothing to unpickle but data
+    assert set(ck.keys()) == {"epoch", "model_state", "optimizer_state", "cfg"} and ck["epoch"] == 3
+    cfg = small_cfg(tmp_path)
+    m = build(cfg, 5)
+    opt = torch.optim.AdamW(m.parameters(), lr=1e-3)
+    epoch = cu.load_checkpoint(_golden("ckpt_small.pyth"), m, data_parallel=False, optimizer=opt)
+    assert epoch == int(e["resume_epoch"]) == 3
+    sd = m.state_dict()
+    names = [k[len("resume."):] for k in e.files if k.startswith("resume.")]
+    assert sorted(names) == sorted(sd.keys())
+    for k in names:
+        assert np.array_equal(sd[k].numpy(), e["resume." + k]), k
+    st = opt.state_dict()["state"][0]
+    assert float(st["step"]) == float(e["resume_opt_step"]) and np.array_equal(st["exp_avg"].numpy(), e["resume_opt_exp_avg0"])
+    # and our writer produces a file the same reader accepts, with the same keys
+    path = cu.save_checkpoint(str(tmp_path), m, opt, 3, cfg, name="again")
+    ck2 = torch.load(path, weights_only=True)
+    assert set(ck2.keys()) == set(ck.keys()) and list(ck2["model_state"].keys()) == list(ck["model_state"].keys())
+
+
+def test_reference_fine_tune_switches_match(tmp_path):
+    """epoch_reset + clear_name_pattern + replace_name_pattern + load_orvit_attn_from_bb on a `module.`-prefixed file with a
+    174-way head and an unknown entry: the loaded state equals what the reference's loader produced, entry by entry, and the
+    same entries stay untouched; split_qkv (:586-597) cuts the fused projection the same way."""
+    import numpy as np
+    from collections import OrderedDict
+    e = _expected()
+    cfg = small_cfg(tmp_path)
+    torch.manual_seed(2)
+    m = build(cfg, 7)
+    before = {k: v.clone() for k, v in m.state_dict().items()}
+    epoch = cu.load_checkpoint(_golden("ckpt_small_pretrained.pyth"), m, data_parallel=False, epoch_reset=True,
+                               clear_name_pattern=("module.",), replace_name_pattern=(("nonexistent_a", "nonexistent_b"),),
+                               load_orvit_attn_from_bb=True)
+    assert epoch == int(e["finetune_epoch"]) == -1
+    untouched_ref = set(e["finetune_untouched"].tolist())
+    sd = m.state_dict()
+    for k in sd:
+        if k in untouched_ref:
+            assert torch.equal(sd[k], before[k]), "%s should not have been loaded" % k
+        else:
+            assert np.array_equal(sd[k].numpy(), e["finetune." + k]), k
+    assert {"head.weight", "head.bias"} <= untouched_ref
+    sq = cu.split_qkv(OrderedDict([("blocks.0.attn.qkv.weight", torch.arange(24.).reshape(6, 4)), ("x", torch.ones(2))]))
+    assert list(sq.keys()) == e["split_keys"].tolist()
+    assert np.array_equal(sq["blocks.0.attn.q.weight"].numpy(), e["split_q"])
+    assert np.array_equal(sq["blocks.0.attn.v.weight"].numpy(), e["split_v"])

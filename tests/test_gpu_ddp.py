@@ -30,8 +30,10 @@ def test_bench_two_ranks_same_device_gloo():
 def test_ddp_gradients_equal_single_process(mixed, tmp_path):
     """with the motion side stream ON and the gradients flowing through DDP's reducer (communication
     hook joining the side stream, focus_amd/parallel.py), the 2-rank gradients (one clip each, averaged by the reducer)
-    equal the single-process gradients of the 2-clip batch.  fp32 mode: 1e-5; bf16 mode: the per-clip activations are
-    bit-identical, only the weight-gradient reduction order over rows differs (fp32 sums of bf16 products): 2e-3."""
+    equal the single-process gradients of the 2-clip batch.  fp32 mode: 1e-5.  bf16 mode: the per-clip activations are
+    bit-identical; what differs is where the sum over the two clips happens -- inside the single process some gradients are
+    summed over the batch in bf16 (autograd's expand / broadcast adjoints on bf16 tensors, e.g. box_categories: one bf16
+    rounding, 2^-8 = 3.9e-3), across ranks every clip's gradient is rounded first and averaged in fp32: 8e-3."""
     import socket
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     outs = [str(tmp_path / ("r%d.json" % r)) for r in range(2)]
@@ -42,4 +44,4 @@ def test_ddp_gradients_equal_single_process(mixed, tmp_path):
     assert all(p.returncode == 0 for p in procs), "\n".join(l[-3000:] for l in logs)
     rec = json.load(open(outs[0]))
     assert rec["n"] > 50
-    assert rec["worst"] < (2e-3 if mixed else 1e-5), rec
+    assert rec["worst"] < (8e-3 if mixed else 1e-5), rec

@@ -713,3 +713,34 @@ def test_layer_norm_fork_adds_residual_gradient(dtype, rows, D):
     close(xg.grad, xr.grad, TOL[dtype], "ln fork dx")
     close(wg.grad, wr.grad, TOL[dtype], "ln fork dgamma")
     close(bg.grad, br.grad, TOL[dtype], "ln fork dbeta")
+
+
+@pytest.mark.parametrize("mixed", [False, True])
+def test_reference_written_checkpoint_drives_the_hip_model(mixed):
+    """SURVEY 8(f) rank 2 on the GPU: tests/golden/ckpt_small.pyth was WRITTEN by the reference's save_checkpoint
+    (checkpoint.py:112-159, oracle/make_golden.py main_ckpt) around the motionformer_small weights; loaded through the
+    mirror's load_checkpoint into a differently initialised HIP model it must reproduce that fixture's logits (the
+    reference Motionformer's own output), and the resumed optimizer must step."""
+    import os
+    from conftest import GOLDEN
+    from focus_amd.slowfast.models import build_model
+    from focus_amd.slowfast.models.optimizer import construct_optimizer
+    from focus_amd.slowfast.utils import checkpoint as cu
+    a, _ = load_golden("motionformer_small")
+    cfg = _small_cfg(mixed)
+    cfg.merge_from_list(["SOLVER.OPTIMIZING_METHOD", "adamw", "SOLVER.BASE_LR", 1e-3])
+    torch.manual_seed(11)
+    m = build_model(cfg)
+    with torch.no_grad():
+        for p in m.parameters():
+            p.normal_(0, 0.3)                                     # nothing of the fixture survives by accident
+    opt = construct_optimizer(m, cfg)
+    epoch = cu.load_checkpoint(os.path.join(GOLDEN, "ckpt_small.pyth"), m, data_parallel=False, optimizer=None)
+    assert epoch == 3
+    m.train()
+    logits = m([T(a["x"]).to(dev())], {"orvit_bboxes": T(a["boxes"]).to(dev())})
+    close(logits, a["logits"], 3e-2 if mixed else 1e-3, "logits from the reference-written checkpoint")
+    logits.float().logsumexp(-1).sum().backward()
+    w0 = m.blocks[0].attn.qkv.weight.detach().clone()
+    opt.step()
+    assert float((m.blocks[0].attn.qkv.weight.detach() - w0).abs().max()) > 0

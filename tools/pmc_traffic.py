@@ -43,7 +43,8 @@ def main():
     for n in rows[:40]:
         c = max(fc[n], 1)
         print("%-62s %6d %16.0f %16.0f %16.0f" % (n, fc[n], fetch[n] / c, 2 * fetch[n] / c, write.get(n, 0.0) / max(wc.get(n, 1), 1)))
-    rec = {"src": source_hash(), "head": head, "workload": wl, "families": {}}
+    rec = {"src": source_hash(), "head": head, "workload": wl, "executions": int(sys.argv[5]) if len(sys.argv) > 5 else 4,
+           "families": {}}
     total = sum(2 * fetch[n] + write.get(n, 0.0) for n in fetch) * 1e3          # bytes over the whole trace
     rec["trace_total_bytes"] = round(total)
     for prefix in ("gemm_nt_ws_kernel", "gemm_nt8_kernel", "gemm_tn_ws_kernel", "traj_bwd_fused_kernel", "traj_dq_kernel", "traj_dkv_kernel",

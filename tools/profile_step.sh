@@ -11,6 +11,9 @@ export TMPDIR=/tmp
 HEAD=$(cat "$ROOT/focus_amd/lib/BUILD_HEAD" 2>/dev/null || echo unknown)
 STEPS=3; WARM=1
 ARGS="bench.py --workload $WL --steps $STEPS --warmup $WARM --no-cpu-baseline --no-roofline"
+# the STEVE record is traced eagerly: warm-up + timed steps = STEPS + WARM executions of the step, nothing else
+[ "$WL" = steve ] && ARGS="$ARGS --steve-eager"
+[ "$WL" = hr ] && ARGS="$ARGS --hr-large-batch 0"
 cd "$ROOT"
 if [ "$WHAT" = trace ] || [ "$WHAT" = all ]; then
   rm -rf /tmp/prof_trace
@@ -23,7 +26,7 @@ if [ "$WHAT" = pmc ] || [ "$WHAT" = all ]; then
     rm -rf /tmp/prof_$C
     rocprofv3 --kernel-trace --pmc $C -d /tmp/prof_$C --output-format csv -- python3 $ARGS > "$OUT/${TAG}_pmc_${C}.log" 2>&1
   done
-  python3 tools/pmc_traffic.py /tmp/prof_FETCH_SIZE /tmp/prof_WRITE_SIZE "$HEAD" "$WL" > "$OUT/${TAG}_pmc_hbm_traffic_${WL}.txt"
+  python3 tools/pmc_traffic.py /tmp/prof_FETCH_SIZE /tmp/prof_WRITE_SIZE "$HEAD" "$WL" $((STEPS + WARM)) > "$OUT/${TAG}_pmc_hbm_traffic_${WL}.txt"
   rm -rf /tmp/prof_sq
   rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_LDS SQ_WAVE_CYCLES -d /tmp/prof_sq --output-format csv \
       -- python3 $ARGS > "$OUT/${TAG}_pmc_sq.log" 2>&1
