@@ -272,6 +272,7 @@ def bench_job(cfg):
             "model_mfma_frac_algorithmic": round(value / world * ALG_GF_PER_CLIP * 1e9 / (PEAK_BF16_TFLOPS * 1e12), 5),
             "final_loss": round(float(loss.detach()), 4),
         }
+        del loss          # no autograd graph of this workload may outlive it (bench_steve captures a HIP graph later)
         if world > 1:
             # exposed (non-overlapped) all-reduce: the same K steps with DDP's reducer switched off
             dt_ns, _ = timed(a.steps, ctx=model.no_sync)
@@ -419,6 +420,32 @@ def bench_steve(a, dev):
         torch.cuda.synchronize()
         ms, graphed = 1e3 * (time.perf_counter() - t0) / n, True
         assert torch.equal(slots, ref_slots) and torch.equal(x.grad, ref_grad), "graph replay differs from the eager step"
+        # what the PRODUCT loop runs under SLOTS.GRAPH_SLOT_UPDATE (STEVE._slots): the module as a pair of captured graphs
+        # (forward / backward) called from an eager autograd step, the loss and everything around it eager
+        product_ms = None
+        try:
+            del slots, attn, gs
+            reset_grads()
+            gm = torch.cuda.make_graphed_callables(m, (x.detach().clone().requires_grad_(), noise), num_warmup_iters=2)
+
+            def prod():
+                reset_grads()
+                s_, a_ = gm(x, noise)
+                (s_.float().square().mean() + a_.float().mean()).backward()
+                return s_, a_
+            prod()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(n):
+                slots, attn = prod()
+            torch.cuda.synchronize()
+            product_ms = 1e3 * (time.perf_counter() - t0) / n
+            assert torch.equal(slots, ref_slots) and torch.equal(x.grad, ref_grad), "graphed callable differs from the eager step"
+        except Exception as e:
+            import traceback
+            traceback.print_exc(file=sys.stderr)
+            product_ms = "failed: %r" % (e,)
+            slots, attn = step()
     fwd_bytes = (B * T * N * D * 2) * (1 + 2 + 2) + B * T * N * K * 2         # inputs, write k/v, read k/v, attn out
     alg = 3.0 * fwd_bytes
     ach = alg / (ms * 1e-3) / 1e9
@@ -431,6 +458,9 @@ def bench_steve(a, dev):
             "ms_per_step": round(ms, 3), "clips_per_s": round(B / (ms * 1e-3), 2),
             "slot_updates_per_s": round(B * T * IT * K / (ms * 1e-3), 1), "steps": n,
             "launch": "one HIP graph replay per step" if graphed else "eager", "eager_ms_per_step": round(eager_ms, 3),
+            "product_loop_ms_per_step": (round(product_ms, 3) if isinstance(product_ms, float) else product_ms) if graphed else None,
+            "product_loop": "SLOTS.GRAPH_SLOT_UPDATE: forward and backward graphs (torch.cuda.make_graphed_callables) inside the "
+                            "eager training step (focus_amd/slowfast/models/STEVE/steve.py:_savi_graphed)",
             "roofline": {"bound": "hbm", "achieved": round(ach, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                          "frac": round(ach / PEAK_HBM_GBS, 4), "traffic": traffic,
                          "traffic_unit": "bytes/step (PMC: 2*FETCH_SIZE + WRITE_SIZE over every kernel of the step, separate "

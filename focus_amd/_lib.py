@@ -30,6 +30,12 @@ class GemmDesc(ctypes.Structure):
     ]
 
 
+class WgradItem(ctypes.Structure):
+    _fields_ = [("dy", ctypes.c_void_p), ("x", ctypes.c_void_p), ("dw", ctypes.c_void_p), ("db", ctypes.c_void_p),
+                ("ld_dy", ctypes.c_int64), ("ld_x", ctypes.c_int64),
+                ("M", ctypes.c_int32), ("N", ctypes.c_int32), ("K", ctypes.c_int32), ("pad_", ctypes.c_int32)]
+
+
 _CTYPE = {"int": ctypes.c_int, "int32_t": ctypes.c_int32, "int64_t": ctypes.c_int64,
           "size_t": ctypes.c_size_t, "float": ctypes.c_float, "double": ctypes.c_double}
 

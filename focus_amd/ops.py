@@ -229,6 +229,8 @@ def invalidate_shadows():
     global _shadow_gen
     _shadow_gen += 1
     _refresh_shadows_batched()
+    if _stacked:
+        refresh_stacked()
     if _fp8_cache:
         refresh_fp8_shadows()
 
@@ -292,6 +294,8 @@ def shadows_written(entries):
             hit = _shadow_cache.get(key)
             if hit is not None and hit[2] is out:
                 _shadow_cache[key] = (hit[0], (w._version, w.data_ptr(), _shadow_gen), out)
+    if _stacked:
+        refresh_stacked()
     if _fp8_cache:
         refresh_fp8_shadows()
 
@@ -308,6 +312,7 @@ def drop_caches():
 
 
 def shadow(w, dtype, transposed=False):
+    w = getattr(w, "_focus_base", w)          # a wgrad_group alias stands for its parameter
     if dtype == torch.float32 and not transposed:
         return w.detach()
     key = (id(w), dtype, transposed)
@@ -359,6 +364,7 @@ class fp8_weights:
 
 
 def fp8_ok(w, rows, dtype):
+    w = getattr(w, "_focus_base", w)
     return (FP8_WEIGHTS and dtype == torch.bfloat16 and w.dim() == 2 and w.dtype == torch.float32 and w.is_cuda
             and rows >= _FP8_MIN_ROWS and w.shape[0] % 64 == 0 and w.shape[1] % 64 == 0 and w.is_contiguous()
             and w.data_ptr() % 16 == 0)
@@ -400,6 +406,7 @@ def refresh_fp8_shadows():
 
 def shadow_fp8(w, transposed=False):
     """(e4m3 codes as a uint8 tensor -- [N,K], or [K,N] when transposed --, scale [1] fp32) of the 2-D weight w [N,K]."""
+    w = getattr(w, "_focus_base", w)
     e = _fp8_cache.get(id(w))
     if e is None or e[0]() is not w:
         N, K = w.shape
@@ -546,6 +553,178 @@ def _deferred_leftovers():
 
 
 # --------------------------------------------------------------------------------------------------
+# Grouped weight gradients.  The Linear layers of one Motionformer / ORViT block (qkv, proj_q, proj, fc1, fc2, ...) each
+# give 18-72 output tiles of dW with a 12552-row reduction: alone none of them fills the 256 CUs without splitting the
+# reduction into slabs that a second launch sums.  Together they are ~234 tiles = one round of the machine with no split.
+# `with ops.wgrad_group(params):` around a block's forward routes the parameters through ONE autograd node (_ParamGroupFn)
+# that sits upstream of every Linear / MLP node using them: those nodes stash (dY, X) instead of computing dW, and the
+# group node -- which autograd runs after all of them -- forms every dW and db of the block in one launch
+# (focus_linear_wgrad_group, csrc/gemm_tn_group.hip) and returns them as ITS gradients: they reach the parameters
+# through AccumulateGrad like any other gradient (DistributedDataParallel's hooks fire unchanged).
+# --------------------------------------------------------------------------------------------------
+_GROUP_ON = _os.environ.get("FOCUS_WGRAD_GROUP", "1") != "0"
+_GROUP_MIN_ROWS = 4096
+_GROUP_MIN_UNITS = 128
+_group_stack = []
+
+
+class _WgradGroup:
+    def __init__(self, params):
+        self.params = params
+        self.index = {id(p): i for i, p in enumerate(params)}
+        self.alias = {}                 # id(param) -> aliased tensor produced by the group node
+        self.stash = []                 # (index of w, index of b or -1, dy2, x2)
+
+
+class _ParamGroupFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, grp, *params):
+        ctx.set_materialize_grads(False)
+        ctx.grp = grp
+        return tuple(p.view_as(p) for p in params)
+
+    @staticmethod
+    def backward(ctx, *gs):
+        grp = ctx.grp
+        out = list(gs)
+        stash, grp.stash = grp.stash, []
+        if stash:
+            for i, g in _group_flush(grp, stash).items():
+                out[i] = g if out[i] is None else out[i] + g
+        return (None, *out)
+
+
+def _group_flush(grp, stash):
+    """All dW / db of the stashed (dY, X) pairs: one grouped launch per 8 problems when they fill the machine, the
+    per-Linear path otherwise.  -> {param index: gradient}."""
+    L = _lib.lib()
+    res = {}
+    # several applications of one weight inside the group (not the case in the blocks): stack them
+    by_w = {}
+    for wi, bi, dy2, x2 in stash:
+        by_w.setdefault((wi, bi), []).append((dy2, x2))
+    probs = []
+    for (wi, bi), lst in by_w.items():
+        dy2 = lst[0][0] if len(lst) == 1 else torch.cat([a for a, _ in lst], 0)
+        x2 = lst[0][1] if len(lst) == 1 else torch.cat([b for _, b in lst], 0)
+        probs.append((wi, bi, dy2, x2))
+    probs.sort(key=lambda t: -t[2].shape[0])
+    # one unit streams the WHOLE reduction of its tile: a problem whose reduction is much longer than the others' (ORViT's
+    # patch_to_d[2] on the 4x more RoI-cell rows) would hold a few CUs long after the rest has finished -- it keeps the
+    # per-Linear path, which splits its reduction over the machine
+    med = sorted(t[2].shape[0] for t in probs)[len(probs) // 2]
+    for t in [t for t in probs if t[2].shape[0] > 1.5 * med]:
+        probs.remove(t)
+        dw, db = linear_wgrad(t[2], t[3], t[1] >= 0)
+        res[t[0]] = dw
+        if t[1] >= 0:
+            res[t[1]] = db
+    Item = _lib.WgradItem
+    arr = (Item * len(probs))()
+    for n, (wi, bi, dy2, x2) in enumerate(probs):
+        arr[n].M, arr[n].N, arr[n].K = dy2.shape[0], dy2.shape[1], x2.shape[1]
+    units = L.focus_linear_wgrad_group_units(arr, len(probs))
+    if units < _GROUP_MIN_UNITS:
+        for wi, bi, dy2, x2 in probs:
+            dw, db = linear_wgrad(dy2, x2, bi >= 0)
+            res[wi] = dw
+            if bi >= 0:
+                res[bi] = db
+        return res
+    dev = probs[0][2].device
+    nw = sum(t[2].shape[1] * t[3].shape[1] for t in probs)
+    nb = sum(t[2].shape[1] for t in probs if t[1] >= 0)
+    flat = torch.empty(nw + nb, device=dev, dtype=torch.float32)
+    if nb:
+        flat[nw:].zero_()                                    # the bias sums are accumulated with atomics
+    ow, ob = 0, nw
+    for n, (wi, bi, dy2, x2) in enumerate(probs):
+        M, N = dy2.shape
+        K = x2.shape[1]
+        dw = flat[ow:ow + N * K].view(N, K)
+        ow += N * K
+        res[wi] = dw
+        arr[n].dy, arr[n].x, arr[n].dw = dy2.data_ptr(), x2.data_ptr(), dw.data_ptr()
+        arr[n].ld_dy, arr[n].ld_x = dy2.stride(0), x2.stride(0)
+        arr[n].db = None
+        if bi >= 0:
+            db = flat[ob:ob + N]
+            ob += N
+            res[bi] = db
+            arr[n].db = db.data_ptr()
+    if GEMM_TIMING is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    # at most 8 problems per launch: more are dealt to ceil(n/8) launches of about equal size (largest first)
+    nch = (len(probs) + 7) // 8
+    chunks = [[] for _ in range(nch)]
+    load = [0] * nch
+    per = [((arr[j].N + 255) // 256) * ((arr[j].K + 127) // 128) for j in range(len(probs))]
+    for j in sorted(range(len(probs)), key=lambda j: -per[j]):
+        c = min((c for c in range(nch) if len(chunks[c]) < 8), key=lambda c: load[c])
+        chunks[c].append(j)
+        load[c] += per[j]
+    for ch in chunks:
+        ch.sort()                                            # keeps the longest reductions first inside a launch
+        sub = (Item * len(ch))(*[arr[j] for j in ch])
+        _lib.check(L.focus_linear_wgrad_group(sub, len(ch), _stream()), "linear_wgrad_group")
+    if GEMM_TIMING is not None:
+        e1.record()
+        fl = sum(2.0 * t[2].shape[0] * t[2].shape[1] * t[3].shape[1] for t in probs)
+        GEMM_TIMING.append((fl, e0, e1, "tn", (len(probs), units, probs[0][2].shape[0], 1, 0)))
+    return res
+
+
+class wgrad_group:
+    """with ops.wgrad_group(parameters of one block): ... the block's forward ...   (see the section comment above)"""
+
+    def __init__(self, params):
+        self.params = [p for p in params if p is not None]
+
+    def __enter__(self):
+        self.grp = None
+        ps = self.params
+        if (_GROUP_ON and torch.is_grad_enabled() and ps and all(p.requires_grad and p.is_cuda for p in ps)):
+            self.grp = _WgradGroup(ps)
+            for p, a in zip(ps, _ParamGroupFn.apply(self.grp, *ps)):
+                a._focus_base = p
+                self.grp.alias[id(p)] = a
+            _group_stack.append(self.grp)
+        return self
+
+    def __exit__(self, *exc):
+        if self.grp is not None:
+            _group_stack.pop()
+        return False
+
+
+def _grouped(t):
+    """The active group's alias of a parameter (or the tensor itself)."""
+    if t is not None and _group_stack:
+        a = _group_stack[-1].alias.get(id(t))
+        if a is not None:
+            return a
+    return t
+
+
+def _group_of(w, b, rows, dtype):
+    """(group, index of w, index of b) when this Linear's weight gradient is left to the active group."""
+    if not _group_stack or dtype != torch.bfloat16 or rows < _GROUP_MIN_ROWS or not USE_TN_GEMM:
+        return None
+    grp = _group_stack[-1]
+    bw = getattr(w, "_focus_base", None)
+    if bw is None or id(bw) not in grp.index or w.dim() != 2 or w.shape[0] % 8 or w.shape[1] % 8:
+        return None
+    bi = -1
+    if b is not None:
+        bb = getattr(b, "_focus_base", None)
+        if bb is None or id(bb) not in grp.index:
+            return None
+        bi = grp.index[id(bb)]
+    return grp, grp.index[id(bw)], bi
+
+
+# --------------------------------------------------------------------------------------------------
 # Linear / MLP
 # --------------------------------------------------------------------------------------------------
 class _LinearFn(torch.autograd.Function):
@@ -566,6 +745,10 @@ class _LinearFn(torch.autograd.Function):
         ctx.save_for_backward(x2, w)
         ctx.has_b, ctx.has_r, ctx.shp, ctx.alpha = b is not None, residual is not None, shp, alpha
         ctx.defer = _defer_open("linear", (w, b), x2.shape[0], ctx.needs_input_grad[1], alpha)
+        ctx.group = None
+        ctx.wbase = getattr(w, "_focus_base", w)               # shadows are keyed by the parameter, not by a group alias
+        if ctx.defer is None and alpha == 1.0 and ctx.needs_input_grad[1] and x2.stride(0) % 8 == 0:
+            ctx.group = _group_of(w, b, x2.shape[0], x.dtype)
         return y.reshape(*shp[:-1], w.shape[0])
 
     @staticmethod
@@ -581,6 +764,9 @@ class _LinearFn(torch.autograd.Function):
             done = _defer_close(ctx.defer, (dy2, x2))
             if done is not None:
                 dw, db = done
+        elif ctx.group is not None:
+            grp, wi, bi = ctx.group
+            grp.stash.append((wi, bi if want_b else -1, dy2, x2))      # the group node forms dW / db for the whole block
         elif ctx.needs_input_grad[1]:
             dw, db, join = wgrad_async(dy2, x2, want_b)
             if ctx.alpha != 1.0:
@@ -588,7 +774,7 @@ class _LinearFn(torch.autograd.Function):
         elif want_b:
             db = colsum(dy2)
         if ctx.needs_input_grad[0]:
-            dx = _dx_from(dy2, w, dy2.dtype, alpha=ctx.alpha, fp8=ctx.fp8).reshape(ctx.shp)
+            dx = _dx_from(dy2, ctx.wbase, dy2.dtype, alpha=ctx.alpha, fp8=ctx.fp8).reshape(ctx.shp)
         if join is not None:
             join()
         return dx, dw, db, (dy if ctx.has_r else None), None
@@ -596,7 +782,7 @@ class _LinearFn(torch.autograd.Function):
 
 def linear(x, w, b=None, residual=None, alpha=1.0):
     """nn.Linear forward (+ fused residual add): y = alpha * x.w^T + b (+ residual)."""
-    return _LinearFn.apply(x, w, b, residual, float(alpha))
+    return _LinearFn.apply(x, _grouped(w), _grouped(b), residual, float(alpha))
 
 
 class _LinearKVFn(torch.autograd.Function):
@@ -656,19 +842,42 @@ class _LinearKVFn(torch.autograd.Function):
         return dx, dwk, dwv, None
 
 
-_stacked = {}
+_stacked = {}       # key -> [stamp, tensor, weak refs of the weights, build(out=None or the cached tensor) -> tensor]
+
+
+def _stacked_get(key, ws, extra, build):
+    """A weight-derived GEMM operand built from several bf16 shadows (concatenations / stacks), cached like the shadows
+    themselves: valid for (version, storage) of every weight and the shadow generation.  A stale entry of unchanged shape
+    is REBUILT IN PLACE (same storage): a captured HIP graph that reads the operand keeps reading the right address, and
+    refresh_stacked() -- called from the optimizer's post-step hook -- does that rebuild eagerly for every live entry."""
+    stamp = tuple(x for w in ws for x in (w._version, w.data_ptr())) + (extra, _shadow_gen)
+    e = _stacked.get(key)
+    if e is None or e[0] != stamp:
+        if e is not None and all(r() is w for r, w in zip(e[2], ws)):
+            t = build(e[1])
+        else:
+            t = build(None)
+        e = _stacked[key] = [stamp, t, [weakref.ref(w) for w in ws], build]
+    return e[1]
+
+
+def refresh_stacked():
+    """Rebuild every cached stacked operand in place from the (already refreshed) shadows."""
+    for key, e in list(_stacked.items()):
+        ws = [r() for r in e[2]]
+        if any(w is None for w in ws):
+            _stacked.pop(key, None)
+            continue
+        e[1] = e[3](e[1])
+        e[0] = tuple(x for w in ws for x in (w._version, w.data_ptr())) + (e[0][-2], _shadow_gen)
 
 
 def _stacked_wT(wk, wv, alpha, dtype):
-    """[alpha Wk; Wv]^T as an NT-GEMM B operand [Din, 2D] in `dtype`.  Cached like the bf16 weight shadows it is built
-    from: rebuilt when a weight's version, storage or the shadow generation (optimizer post-step hook) changes."""
-    key = (id(wk), id(wv), dtype)
-    stamp = (wk._version, wk.data_ptr(), wv._version, wv.data_ptr(), alpha, _shadow_gen)
-    e = _stacked.get(key)
-    if e is None or e[0] != stamp:
-        t = torch.cat([shadow(wk, dtype, transposed=True) * alpha, shadow(wv, dtype, transposed=True)], dim=1).contiguous()
-        e = _stacked[key] = (stamp, t)
-    return e[1]
+    """[alpha Wk; Wv]^T as an NT-GEMM B operand [Din, 2D] in `dtype`."""
+    def build(out):
+        parts = [shadow(wk, dtype, transposed=True) * alpha, shadow(wv, dtype, transposed=True)]
+        return torch.cat(parts, dim=1, out=out) if out is not None else torch.cat(parts, dim=1).contiguous()
+    return _stacked_get((id(wk), id(wv), dtype), (wk, wv), alpha, build)
 
 
 def linear_kv(x, wk, wv, alpha_k=1.0):
@@ -705,6 +914,12 @@ class _MlpFn(torch.autograd.Function):
             d1.pending -= 1
             d1 = None
         ctx.defer = (d1, d2) if d1 is not None else None
+        ctx.group = None
+        ctx.wbase = (getattr(w1, "_focus_base", w1), getattr(w2, "_focus_base", w2))
+        if ctx.defer is None and ctx.needs_input_grad[1] and ctx.needs_input_grad[3] and x2.stride(0) % 8 == 0:
+            g1, g2 = _group_of(w1, b1, M, x.dtype), _group_of(w2, b2, M, x.dtype)
+            if g1 is not None and g2 is not None:
+                ctx.group = (g1, g2)
         return y.reshape(*shp[:-1], w2.shape[0])
 
     @staticmethod
@@ -715,27 +930,34 @@ class _MlpFn(torch.autograd.Function):
             dy2 = dy2.contiguous()
         join2 = join1 = None
         dfr = ctx.defer
+        grp = ctx.group
         if dfr is not None:
             dw2 = db2 = None
             done = _defer_close(dfr[1], (dy2, a))
             if done is not None:
                 dw2, db2 = done
+        elif grp is not None:
+            dw2 = db2 = None
+            grp[1][0].stash.append((grp[1][1], grp[1][2] if ctx.has[1] else -1, dy2, a))
         elif ctx.needs_input_grad[3]:
             dw2, db2, join2 = wgrad_async(dy2, a, ctx.has[1])
         else:
             dw2, db2 = None, (colsum(dy2) if ctx.has[1] else None)
         # dz = (dy . w2) * act'(.) fused in the GEMM epilogue
-        dz = _dx_from(dy2, w2, dy2.dtype, aux=(z if ctx.act == EPI_GELU else a), epilogue=_DEPI[ctx.act], fp8=ctx.fp8)
+        dz = _dx_from(dy2, ctx.wbase[1], dy2.dtype, aux=(z if ctx.act == EPI_GELU else a), epilogue=_DEPI[ctx.act], fp8=ctx.fp8)
         if dfr is not None:
             dw1 = db1 = None
             done = _defer_close(dfr[0], (dz, x2))
             if done is not None:
                 dw1, db1 = done
+        elif grp is not None:
+            dw1 = db1 = None
+            grp[0][0].stash.append((grp[0][1], grp[0][2] if ctx.has[0] else -1, dz, x2))
         elif ctx.needs_input_grad[1]:
             dw1, db1, join1 = wgrad_async(dz, x2, ctx.has[0])
         else:
             dw1, db1 = None, (colsum(dz) if ctx.has[0] else None)
-        dx = _dx_from(dz, w1, dz.dtype, fp8=ctx.fp8).reshape(ctx.shp) if ctx.needs_input_grad[0] else None
+        dx = _dx_from(dz, ctx.wbase[0], dz.dtype, fp8=ctx.fp8).reshape(ctx.shp) if ctx.needs_input_grad[0] else None
         for j in (join2, join1):
             if j is not None:
                 j()
@@ -744,7 +966,7 @@ class _MlpFn(torch.autograd.Function):
 
 def mlp(x, w1, b1, w2, b2, residual=None, act=EPI_GELU):
     """Linear -> act -> Linear (+ residual): common.py:26-34 (GELU), steve.py:46-49 / transformer.py:62-66 (ReLU)."""
-    return _MlpFn.apply(x, w1, b1, w2, b2, residual, act)
+    return _MlpFn.apply(x, _grouped(w1), _grouped(b1), _grouped(w2), _grouped(b2), residual, act)
 
 
 class _ScaleAddFn(torch.autograd.Function):
@@ -1696,13 +1918,11 @@ class _GruGatesFn(torch.autograd.Function):
 def _stacked_cat(ws, dtype, transposed):
     """The bf16 shadows of several [C, Cin] weights concatenated into one NT-GEMM B operand: rows stacked [sum C, Cin]
     (forward), or the transposes side by side [Cin, sum C] (d(input)); cached like the shadows themselves."""
-    key = tuple(id(w) for w in ws) + (dtype, transposed, "cat")
-    stamp = tuple(x for w in ws for x in (w._version, w.data_ptr())) + (_shadow_gen,)
-    e = _stacked.get(key)
-    if e is None or e[0] != stamp:
-        t = torch.cat([shadow(w, dtype, transposed=transposed) for w in ws], dim=1 if transposed else 0).contiguous()
-        e = _stacked[key] = (stamp, t)
-    return e[1]
+    def build(out):
+        parts = [shadow(w, dtype, transposed=transposed) for w in ws]
+        dim = 1 if transposed else 0
+        return torch.cat(parts, dim=dim, out=out) if out is not None else torch.cat(parts, dim=dim).contiguous()
+    return _stacked_get(tuple(id(w) for w in ws) + (dtype, transposed, "cat"), tuple(ws), None, build)
 
 
 class _LinearQKVFn(torch.autograd.Function):
@@ -1765,13 +1985,10 @@ def linear_qkv(x, wq, wk, wv):
 def _stacked_pair(wa, wb, dtype, transposed):
     """The bf16 shadows of two equally shaped weights as one [2, ...] tensor (the B operands of a batch-2 product);
     cached like the shadows themselves (version, storage, shadow generation)."""
-    key = (id(wa), id(wb), dtype, transposed)
-    stamp = (wa._version, wa.data_ptr(), wb._version, wb.data_ptr(), _shadow_gen)
-    e = _stacked.get(key)
-    if e is None or e[0] != stamp:
-        t = torch.stack([shadow(wa, dtype, transposed=transposed), shadow(wb, dtype, transposed=transposed)], 0).contiguous()
-        e = _stacked[key] = (stamp, t)
-    return e[1]
+    def build(out):
+        parts = [shadow(wa, dtype, transposed=transposed), shadow(wb, dtype, transposed=transposed)]
+        return torch.stack(parts, 0, out=out) if out is not None else torch.stack(parts, 0).contiguous()
+    return _stacked_get((id(wa), id(wb), dtype, transposed), (wa, wb), None, build)
 
 
 class _GruCellFn(torch.autograd.Function):

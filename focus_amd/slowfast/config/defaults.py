@@ -152,6 +152,7 @@ def _defaults():
     C.LOG_MODEL_INFO = False
     C.DIST_BACKEND = "nccl"
     C.DDP_BF16_GRADS = False     # build-owned: bf16 gradient buckets on the wire (focus_amd/parallel.py)
+    C.SLOTS.GRAPH_SLOT_UPDATE = False   # build-owned: replay the slot update from captured HIP graphs inside the training step
     C.TRAIN.FP8_WEIGHTS = False  # build-owned (BASELINE configs[4]): OCP e4m3 working copies of the Linear weights, bf16 activations
     return C
 

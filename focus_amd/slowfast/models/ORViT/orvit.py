@@ -86,7 +86,20 @@ class ORViT(nn.Module):
             for p in m.parameters():
                 nn.init.normal_(p, std=0.02)
 
+    def _linear_params(self):
+        a, m, mm, p2d = self.attn, self.mlp, getattr(self, "motion_mlp", None), self.patch_to_d
+        ps = [a.qkv.weight, a.qkv.bias, a.proj_q.weight, a.proj_q.bias, a.proj.weight, a.proj.bias,
+              m.fc1.weight, m.fc1.bias, m.fc2.weight, m.fc2.bias, p2d[0].weight, p2d[2].weight]
+        if mm is not None:
+            ps += [mm.fc1.weight, mm.fc1.bias, mm.fc2.weight, mm.fc2.bias]
+        return ps
+
     def forward(self, x, metadata, thw):
+        # the Linear weight gradients of the block (attention, MLPs, patch_to_d) are formed in grouped launches
+        with ops.wgrad_group(self._linear_params()):
+            return self._forward(x, metadata, thw)
+
+    def _forward(self, x, metadata, thw):
         box_tensors = metadata["orvit_bboxes"]
         assert box_tensors is not None
         BS, _, d = x.shape

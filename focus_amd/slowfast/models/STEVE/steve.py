@@ -223,6 +223,10 @@ class STEVE(nn.Module):
         self.vocab_size = args.SLOTS.VOCAB_SIZE
         self.d_model = args.SLOTS.DECODER.DIM
         self.compute_dtype = torch.bfloat16 if args.TRAIN.MIXED_PRECISION else torch.float32
+        # build-owned key: the slot update (SlotAttentionVideo, ~2000 small launches forward + backward) is captured once
+        # into a pair of HIP graphs (torch.cuda.make_graphed_callables) and replayed inside the eager training step
+        self.graph_slot_update = bool(args.SLOTS.get("GRAPH_SLOT_UPDATE", False))
+        self._savi_graphs = {}
         self.dvae = dVAE(args.SLOTS.VOCAB_SIZE, args.SLOTS.IMG_CHANNELS)
         self.steve_encoder = STEVEEncoder(args)
         self.steve_decoder = STEVEDecoder(args)
@@ -238,10 +242,31 @@ class STEVE(nn.Module):
         emb_set = ops.mlp(ops.layer_norm(emb_set, ln.weight, ln.bias, ln.eps), enc.mlp[0].weight, enc.mlp[0].bias,
                           enc.mlp[2].weight, enc.mlp[2].bias, act=ops.EPI_RELU)
         emb_set = emb_set.reshape(B, T, H_enc * W_enc, self.d_model)
-        slots, attns = enc.savi(emb_set, noise=noise)                                     # [B,T,K,Ds], [B,T,N,K]
+        if self.graph_slot_update and self.training and emb_set.is_cuda and torch.is_grad_enabled() and emb_set.requires_grad:
+            slots, attns = self._savi_graphed(emb_set, noise)
+        else:
+            slots, attns = enc.savi(emb_set, noise=noise)                                 # [B,T,K,Ds], [B,T,N,K]
         attns = attns.float().transpose(-1, -2).reshape(B, T, self.num_slots, 1, H_enc, W_enc) \
             .repeat_interleave(H // H_enc, dim=-2).repeat_interleave(W // W_enc, dim=-1)  # B, T, K, 1, H, W
         return slots, attns
+
+    def _savi_graphed(self, emb_set, noise):
+        """The slot update through a captured forward graph and a captured backward graph (one replay each per step).
+        The N(0,1) slot initialisation is drawn OUTSIDE the graph with the call SlotAttentionVideo.forward would make
+        (steve.py:56), so the random stream of the step is the eager one.  The graphs read the weights through the bf16
+        shadows / stacked operands of focus_amd.ops, which the optimizer's post-step hook refreshes in place."""
+        savi = self.steve_encoder.savi
+        emb_set = emb_set.contiguous()
+        if noise is None:
+            noise = emb_set.new_empty(emb_set.shape[0], savi.num_slots, savi.slot_size).normal_()
+        key = (tuple(emb_set.shape), emb_set.dtype, noise.dtype)
+        g = self._savi_graphs.get(key)
+        if g is None:
+            state = torch.cuda.get_rng_state(emb_set.device)         # capture + warm-up must not move the random stream
+            sample = (torch.zeros_like(emb_set).normal_().requires_grad_(), torch.zeros_like(noise).normal_())
+            g = self._savi_graphs[key] = torch.cuda.make_graphed_callables(savi, sample, num_warmup_iters=2)
+            torch.cuda.set_rng_state(state, emb_set.device)
+        return g(emb_set, noise)
 
     def forward(self, video, tau, hard, noise=None):
         B, T, C, H, W = video.size()

@@ -109,7 +109,17 @@ class TrajectoryAttentionBlock(nn.Module):
         self.norm2 = norm_layer(dim)
         self.mlp = Mlp(in_features=dim, hidden_features=int(dim * mlp_ratio), act_layer=act_layer, drop=drop)
 
+    def _linear_params(self):
+        a, m = self.attn, self.mlp
+        return [a.qkv.weight, a.qkv.bias, a.proj_q.weight, a.proj_q.bias, a.proj.weight, a.proj.bias,
+                m.fc1.weight, m.fc1.bias, m.fc2.weight, m.fc2.bias]
+
     def forward(self, x, metadata, thw, with_cls_token=True):
+        # the five Linear weight gradients of the block are formed in one launch (ops.wgrad_group)
+        with ops.wgrad_group(self._linear_params()):
+            return self._forward(x, metadata, thw, with_cls_token)
+
+    def _forward(self, x, metadata, thw, with_cls_token=True):
         n1, n2 = self.norm1, self.norm2
         if isinstance(self.drop_path, nn.Identity) or not self.training:
             # residual adds ride in the proj / fc2 GEMM epilogues

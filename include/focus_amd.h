@@ -398,6 +398,18 @@ typedef struct focus_fp8_item {
 } focus_fp8_item;
 int focus_fp8_refresh(const focus_fp8_item* items, int n_items, int max_rows, int max_cols, void* amax_scratch, void* stream);
 
+/* Weight and bias gradients of up to 8 nn.Linear layers in ONE launch (gemm_tn_group.hip; autograd of attention.py:506,
+ * 536,555 and common.py:26-34 inside one block): dw_p[N,K] = dy_p[M,N]^T . x_p[M,K] (fp32, dense), db_p[N] += column sums
+ * of dy_p (fp32 atomics: the caller zeroes db; NULL = no bias).  bf16 operands, row strides ld_dy / ld_x in elements;
+ * N, K, strides multiples of 8; 16-byte aligned pointers.  `items` is a HOST array. */
+typedef struct focus_wgrad_item {
+    const void* dy; const void* x; float* dw; float* db;
+    int64_t ld_dy, ld_x;
+    int32_t M, N, K, pad_;
+} focus_wgrad_item;
+int focus_linear_wgrad_group_units(const focus_wgrad_item* items, int n_items);
+int focus_linear_wgrad_group(const focus_wgrad_item* items, int n_items, void* stream);
+
 /* xdiag[b,s,:] = xt[b,s,s/P,:] (attention.py:533-535) and its adjoint dxt[b,s,s/P,:] += dxdiag[b,s,:]. */
 int focus_diag_gather(const void* xt, void* xdiag, int B, int S, int F, int C, int dtype, void* stream);
 int focus_diag_scatter_add(const void* dxdiag, void* dxt, int B, int S, int F, int C, int dtype, void* stream);

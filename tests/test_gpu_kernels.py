@@ -399,3 +399,80 @@ def test_time2_kernels_tight(F_, heads, S):
     ck.done()
     assert float(dw[C:].abs().max()) == 0.0 and float(db.abs().max()) == 0.0      # dead v2 half, shift-invariant bias
     assert float(Bk.grad[:C].abs().max()) < 1e-9 * float(gw.abs().max()) + 1e-12   # (the reference agrees: ~0)
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# grouped weight gradients (csrc/gemm_tn_group.hip): every dW / db of a block's Linears from one launch
+# ----------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("rows", [12552, 4100])
+def test_grouped_weight_gradients_match_fp64(rows):
+    """Five Linears of a Motionformer block + a bias-free one with a longer reduction and ragged sizes: the grouped launch
+    against fp64 dY^T.X / column sums of the same bf16 values (fp32 accumulation of exact bf16 products: 1e-4)."""
+    import ctypes
+    from focus_amd import _lib
+    d = dev()
+    g = torch.Generator(device=d).manual_seed(rows)
+    shapes = [(rows, 2304, 768, True), (rows - 8, 768, 768, True), (rows, 768, 768, True), (rows, 3072, 768, True),
+              (rows, 768, 3072, True), (4 * rows + 24, 384, 200, False), (rows, 8, 264, True)]
+    L = _lib.lib()
+    Item = _lib.WgradItem
+    arr = (Item * len(shapes))()
+    keep = []
+    for n, (M, N, K, hb) in enumerate(shapes):
+        dy = bf(torch.randn(M, N + 8, device=d, generator=g))[:, :N]          # a strided view: ld_dy = N + 8
+        x = bf(torch.randn(M, K, device=d, generator=g))
+        dw = torch.full((N, K), float("nan"), device=d)
+        db = torch.zeros(N, device=d) if hb else None
+        keep.append((dy, x, dw, db))
+        arr[n].dy, arr[n].x, arr[n].dw = dy.data_ptr(), x.data_ptr(), dw.data_ptr()
+        arr[n].db = db.data_ptr() if hb else None
+        arr[n].ld_dy, arr[n].ld_x, arr[n].M, arr[n].N, arr[n].K = dy.stride(0), x.stride(0), M, N, K
+    assert L.focus_linear_wgrad_group_units(arr, len(shapes)) == 54 + 18 + 18 + 72 + 72 + 2 * 2 + 1 * 3
+    stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    _lib.check(L.focus_linear_wgrad_group(arr, len(shapes), stream), "linear_wgrad_group")
+    torch.cuda.synchronize()
+    ck = Check()
+    for n, (dy, x, dw, db) in enumerate(keep):
+        ck.tight(dw, dy.double().t() @ x.double(), "dW %d %s" % (n, shapes[n][:3]), rtol=1e-4, floor=1e-3)
+        if db is not None:
+            ck.tight(db, dy.double().sum(0), "db %d" % n, rtol=1e-4, floor=1e-3)
+    ck.done()
+
+
+def test_wgrad_group_context_equals_ungrouped():
+    """ops.wgrad_group around Linear + MLP nodes: same outputs and input gradients bit for bit, parameter gradients equal
+    to the per-Linear path up to the fp32 summation order (the per-Linear path splits the reduction over slabs)."""
+    from focus_amd import ops
+    d = dev()
+    g = torch.Generator().manual_seed(9)
+    M, D, H = 8192, 768, 3072
+    mk = lambda *s, sc=1.0: (torch.randn(*s, generator=g) * sc).to(d).requires_grad_()
+    P = [mk(3 * D, D, sc=D ** -0.5), mk(3 * D, sc=0.1), mk(H, D, sc=D ** -0.5), mk(H, sc=0.1), mk(D, H, sc=H ** -0.5), mk(D, sc=0.1)]
+    x = torch.randn(M, D, generator=g).bfloat16().to(d)
+    ct = torch.randn(M, D, generator=g).bfloat16().to(d)
+
+    def run(grouped):
+        for p in P:
+            p.grad = None
+        xg = x.clone().requires_grad_()
+
+        def body():
+            q = ops.linear(xg, P[0], P[1])
+            y = ops.mlp(q[:, :D].contiguous(), P[2], P[3], P[4], P[5], residual=q[:, D:2 * D].contiguous())
+            (y.float() * ct.float()).sum().backward()
+            return y
+        if grouped:
+            with ops.wgrad_group(P):
+                y = body()
+        else:
+            y = body()
+        torch.cuda.synchronize()
+        return y.detach(), xg.grad, [p.grad.clone() for p in P]
+
+    y0, dx0, g0 = run(False)
+    y1, dx1, g1 = run(True)
+    assert torch.equal(y0, y1) and torch.equal(dx0, dx1)
+    for a, b, name in zip(g0, g1, ("qkv.w", "qkv.b", "fc1.w", "fc1.b", "fc2.w", "fc2.b")):
+        assert a.shape == b.shape
+        e = float((a - b).abs().max() / a.abs().max())
+        assert e < 2e-5, (name, e)

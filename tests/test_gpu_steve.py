@@ -412,3 +412,42 @@ def test_graphed_step_refuses_live_outputs_and_replays_bit_exact():
     y = gs.replay()
     torch.cuda.synchronize()
     assert torch.equal(y, ref_y) and torch.equal(w.grad, ref_g)
+
+
+@pytest.mark.parametrize("dropout", [0.0, 0.1])
+def test_graphed_slot_update_training_steps_equal_eager_bit_for_bit(dropout):
+    """SLOTS.GRAPH_SLOT_UPDATE: slot_train_step with the slot update replayed from captured HIP graphs
+    (torch.cuda.make_graphed_callables inside STEVE._slots) against the eager step, from identical parameters, optimizer
+    state and random streams: three optimizer steps, every parameter bit for bit.  Covers what the r2 graph replay did not:
+    the optimizer moving the weights between replays (shadows and stacked operands refreshed in place)."""
+    from focus_amd import ops
+    from focus_amd.slowfast.models.optimizer import construct_optimizer_slot
+    from focus_amd.train import slot_train_step
+    results = []
+    g = torch.Generator().manual_seed(0)
+    video = torch.rand(2, 3, 3, 16, 16, generator=g).to(dev())
+    for graphed in (False, True):
+        ops.drop_caches()
+        cfg, m = _steve_small(True)
+        cfg.SOLVER.OPTIMIZING_METHOD = "adam"
+        cfg.SOLVER.CLIP_GRAD_L2NORM = 1.0
+        cfg.SLOTS.PREDICTOR_DROPOUT = dropout
+        cfg.SLOTS.GRAPH_SLOT_UPDATE = graphed
+        torch.manual_seed(3)
+        from focus_amd.slowfast.models import MODEL_REGISTRY
+        m = MODEL_REGISTRY.get("STEVE")(cfg).to(dev()).train()
+        assert m.graph_slot_update == graphed
+        opt = construct_optimizer_slot(m, cfg)
+        torch.manual_seed(11)
+        losses = []
+        for step in range(3):
+            loss, *_ = slot_train_step(m, opt, video, step, cfg)
+            losses.append(float(loss))
+        torch.cuda.synchronize()
+        results.append((losses, {n: p.detach().clone() for n, p in m.named_parameters()}))
+        if graphed:
+            assert len(m._savi_graphs) == 1
+    (l0, p0), (l1, p1) = results
+    assert l0 == l1, (l0, l1)
+    for n in p0:
+        assert torch.equal(p0[n], p1[n]), n
