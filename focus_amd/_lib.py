@@ -36,6 +36,14 @@ class WgradItem(ctypes.Structure):
                 ("M", ctypes.c_int32), ("N", ctypes.c_int32), ("K", ctypes.c_int32), ("pad_", ctypes.c_int32)]
 
 
+class SlotTailArgs(ctypes.Structure):
+    _fields_ = ([(n, ctypes.c_int32) for n in ("R", "D", "H", "do_gru", "do_mlp", "do_q")] +
+                [("ln1_eps", ctypes.c_float), ("ln2_eps", ctypes.c_float)] +
+                [(n, ctypes.c_void_p) for n in ("upd", "h", "w_ih", "w_hh", "b_ih", "b_hh", "ln1_g", "ln1_b", "w1", "b1", "w2", "b2",
+                                                "ln2_g", "ln2_b", "wq", "g", "hn", "y", "mean1", "rstd1", "a", "s", "sn", "mean2",
+                                                "rstd2", "q")])
+
+
 _CTYPE = {"int": ctypes.c_int, "int32_t": ctypes.c_int32, "int64_t": ctypes.c_int64,
           "size_t": ctypes.c_size_t, "float": ctypes.c_float, "double": ctypes.c_double}
 

@@ -9,9 +9,11 @@
 // reduce launch; every unit streams the whole reduction of its tile and stores its fp32 tile straight to dW.
 //
 // Same workgroup as gemm_tn_ws_kernel<256, 128> (gemm_mfma_tn_ws.hip: 8 consumer + 4 loader waves, 3-stage LDS ring,
-// transposed LDS reads for the reduction-major operands); the problem table (up to 8 Linears) travels as a kernel argument;
-// the logical unit list is (problem, tile_i, tile_j) with tile_j fastest and every XCD owns a contiguous band of it, so the
-// units that share a dY panel share an L2.  Bias gradients ride on the matrix pipe as ones^T . dY (unit
+// transposed LDS reads for the reduction-major operands); the problem table (up to 8 Linears) travels as a kernel argument.
+// The unit list (built once per shape signature by focus_linear_wgrad_group_plan, kept on the device by the caller) walks
+// every problem's tile grid in blocks of 4 x 8 tiles and every XCD owns a contiguous band of the list (~one block): the
+// ~29 units that share an L2 read 4 dY panels and 8 X panels between them.  (First version: tile_j fastest over whole
+// rows -- PMC FETCH 720 MB per launch against ~250 MB of operands: every XCD streamed most X panels.)  Bias gradients ride on the matrix pipe as ones^T . dY (unit
 // tile_j takes the K-steps kt = tile_j mod tiles_j) and are ADDED to db with fp32 atomics (a few thousand per launch);
 // db is zeroed by the caller's memset.
 #include "focus_common.h"
@@ -57,9 +59,10 @@ struct Prob {
     int32_t I, J, Mred, tiles_i, tiles_j, pad_;
 };
 constexpr int MAXP = 8;
-struct GroupArgs { Prob p[MAXP]; int32_t unit0[MAXP + 1]; int32_t nprob, nunits; };
+struct GroupArgs { Prob p[MAXP]; int32_t nprob, nunits; };
+struct UnitRec { int16_t prob, ti, tj, pad_; };     // 8 bytes
 
-__global__ __launch_bounds__(64 * (BI * BJ / 4096 + NLOAD)) void gemm_tn_group_kernel(const GroupArgs ga) {
+__global__ __launch_bounds__(64 * (BI * BJ / 4096 + NLOAD)) void gemm_tn_group_kernel(const GroupArgs ga, const UnitRec* __restrict__ units) {
     constexpr int NCONS = BI * BJ / 4096;
     constexpr int WJ = BJ / 64;
     constexpr int NSP = BI / 128, NSQ = BJ / 128, NSUBT = NSP + NSQ;
@@ -81,21 +84,17 @@ __global__ __launch_bounds__(64 * (BI * BJ / 4096 + NLOAD)) void gemm_tn_group_k
 
     struct Unit { const bf16_t* P; const bf16_t* Q; float* C; float* db; int64_t ldp, ldq; int I, J, Mred, i0, j0, nk, valid_last, tj, tiles_j; };
     auto unit_of = [&](int i) __attribute__((always_inline)) {
-        const int u = band0 + jwg + i * gx;
-        int pi = 0;
-#pragma unroll
-        for (int k = 1; k < MAXP; ++k)
-            if (k < ga.nprob && u >= ga.unit0[k]) pi = k;
+        const UnitRec ur = units[band0 + jwg + i * gx];
+        const int pi = __builtin_amdgcn_readfirstlane((int)ur.prob);
         Unit t;
         // (selected with a chain of compares on the argument registers: the table lives in SGPRs / constant memory)
         Prob p = ga.p[0];
 #pragma unroll
         for (int k = 1; k < MAXP; ++k)
             if (pi == k) p = ga.p[k];
-        const int tile = u - ga.unit0[pi];
         t.P = p.P; t.Q = p.Q; t.C = p.C; t.db = p.db; t.ldp = p.ldp; t.ldq = p.ldq; t.I = p.I; t.J = p.J; t.Mred = p.Mred;
-        t.i0 = (tile / p.tiles_j) * BI;
-        t.tj = tile % p.tiles_j;
+        t.i0 = __builtin_amdgcn_readfirstlane((int)ur.ti) * BI;
+        t.tj = __builtin_amdgcn_readfirstlane((int)ur.tj);
         t.j0 = t.tj * BJ;
         t.tiles_j = p.tiles_j;
         t.nk = (p.Mred + BKM - 1) / BKM;
@@ -253,10 +252,32 @@ extern "C" int focus_linear_wgrad_group_units(const focus_wgrad_item* items, int
     return t > 0x7fffffff ? -1 : (int)t;
 }
 
+// The unit list of a grouped launch (HOST memory, focus_linear_wgrad_group_units entries of 8 bytes): depends on the
+// (N, K) of the problems only.  The caller copies it to the device once per shape signature and passes it to every launch.
+extern "C" int focus_linear_wgrad_group_plan(const focus_wgrad_item* items, int n_items, void* host_units, size_t bytes) {
+    if (!items || !host_units) return FOCUS_ERR_NULL;
+    if (n_items <= 0 || n_items > MAXP) return FOCUS_ERR_SHAPE;
+    const int total = focus_linear_wgrad_group_units(items, n_items);
+    if (total <= 0 || bytes < (size_t)total * sizeof(UnitRec)) return FOCUS_ERR_WORKSPACE;
+    UnitRec* u = static_cast<UnitRec*>(host_units);
+    constexpr int BA = 4, BB = 8;               // tiles per block: 4 dY panels (256 columns) x 8 X panels (128 columns)
+    int n = 0;
+    for (int p = 0; p < n_items; ++p) {
+        const int ti_n = (items[p].N + BI - 1) / BI, tj_n = (items[p].K + BJ - 1) / BJ;
+        for (int bi = 0; bi < ti_n; bi += BA)
+            for (int bj = 0; bj < tj_n; bj += BB)
+                for (int ti = bi; ti < std::min(bi + BA, ti_n); ++ti)
+                    for (int tj = bj; tj < std::min(bj + BB, tj_n); ++tj)
+                        u[n++] = UnitRec{(int16_t)p, (int16_t)ti, (int16_t)tj, 0};
+    }
+    return n == total ? FOCUS_OK : FOCUS_ERR_SHAPE;
+}
+
 // `items` is a HOST array of at most 8 problems (longest reduction first gives the best balance); every db must have been
 // zeroed by the caller (the bias gradients are accumulated with atomics); dW is written densely ([N, K], row stride K).
-extern "C" int focus_linear_wgrad_group(const focus_wgrad_item* items, int n_items, void* stream) {
-    if (!items) return FOCUS_ERR_NULL;
+// dev_units: DEVICE copy of the list focus_linear_wgrad_group_plan made for the same (N, K) sequence.
+extern "C" int focus_linear_wgrad_group(const focus_wgrad_item* items, int n_items, const void* dev_units, void* stream) {
+    if (!items || !dev_units) return FOCUS_ERR_NULL;
     if (n_items <= 0) return FOCUS_OK;
     if (n_items > MAXP) return FOCUS_ERR_SHAPE;
     GroupArgs ga = {};
@@ -271,10 +292,9 @@ extern "C" int focus_linear_wgrad_group(const focus_wgrad_item* items, int n_ite
         q.C = it.dw; q.db = it.db; q.ldp = it.ld_dy; q.ldq = it.ld_x;
         q.I = it.N; q.J = it.K; q.Mred = it.M;
         q.tiles_i = (it.N + BI - 1) / BI; q.tiles_j = (it.K + BJ - 1) / BJ; q.pad_ = 0;
-        ga.unit0[p] = units;
+        if (q.tiles_i > 32767 || q.tiles_j > 32767) return FOCUS_ERR_SHAPE;
         units += q.tiles_i * q.tiles_j;
     }
-    for (int p = n_items; p <= MAXP; ++p) ga.unit0[p] = units;
     ga.nprob = n_items;
     ga.nunits = units;
     hipStream_t s = static_cast<hipStream_t>(stream);
@@ -282,7 +302,8 @@ extern "C" int focus_linear_wgrad_group(const focus_wgrad_item* items, int n_ite
     auto k = gemm_tn_group_kernel;
     static bool once = (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds) == hipSuccess);
     (void)once;
-    hipLaunchKernelGGL(k, dim3(std::min(units, 256)), dim3(64 * (BI * BJ / 4096 + NLOAD)), lds, s, ga);
+    hipLaunchKernelGGL(k, dim3(std::min(units, 256)), dim3(64 * (BI * BJ / 4096 + NLOAD)), lds, s, ga,
+                       static_cast<const UnitRec*>(dev_units));
     FOCUS_CHECK_LAUNCH();
     return FOCUS_OK;
 }

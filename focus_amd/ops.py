@@ -566,6 +566,7 @@ _GROUP_ON = _os.environ.get("FOCUS_WGRAD_GROUP", "1") != "0"
 _GROUP_MIN_ROWS = 4096
 _GROUP_MIN_UNITS = 128
 _group_stack = []
+_group_tables = {}      # (device, (N, K) of the problems of a launch) -> device unit list (focus_linear_wgrad_group_plan)
 
 
 class _WgradGroup:
@@ -667,7 +668,14 @@ def _group_flush(grp, stash):
     for ch in chunks:
         ch.sort()                                            # keeps the longest reductions first inside a launch
         sub = (Item * len(ch))(*[arr[j] for j in ch])
-        _lib.check(L.focus_linear_wgrad_group(sub, len(ch), _stream()), "linear_wgrad_group")
+        sig = (dev,) + tuple((arr[j].N, arr[j].K) for j in ch)
+        table = _group_tables.get(sig)
+        if table is None:                                    # the unit list depends on the (N, K) sequence only
+            nu = L.focus_linear_wgrad_group_units(sub, len(ch))
+            host = torch.empty(nu * 8, dtype=torch.uint8).pin_memory()
+            _lib.check(L.focus_linear_wgrad_group_plan(sub, len(ch), ctypes.c_void_p(host.data_ptr()), nu * 8), "wgrad_group_plan")
+            table = _group_tables[sig] = host.to(dev)        # (blocking copy, once per signature)
+        _lib.check(L.focus_linear_wgrad_group(sub, len(ch), _p(table), _stream()), "linear_wgrad_group")
     if GEMM_TIMING is not None:
         e1.record()
         fl = sum(2.0 * t[2].shape[0] * t[2].shape[1] * t[3].shape[1] for t in probs)
@@ -695,6 +703,10 @@ class wgrad_group:
     def __exit__(self, *exc):
         if self.grp is not None:
             _group_stack.pop()
+            # the aliases are referenced by the autograd graph from here on; keeping them in the group (which the group
+            # node's ctx holds) would close a reference cycle through C++ autograd nodes that the collector cannot break
+            self.grp.alias = {}
+            self.grp = None
         return False
 
 
@@ -2050,3 +2062,165 @@ def gru_cell(x, h, w_ih, w_hh, b_ih, b_hh):
             and b_ih is not None and b_hh is not None and (h.data_ptr() - x.data_ptr()) % 16 == 0 and x.is_cuda):
         return _GruCellFn.apply(x, h, w_ih, w_hh, b_ih, b_hh)
     return _GruGatesFn.apply(linear(x, w_ih, b_ih), linear(h, w_hh, b_hh), h)
+
+
+# --------------------------------------------------------------------------------------------------
+# The per-iteration tail of the slot update as one forward launch (csrc/slot_tail.hip):
+#   [gru] hn = GRUCell(upd, h)   [mlp] s = hn + W2 relu(W1 LN1(hn) + b1) + b2   [q] q = Wq LN2(slots)
+# --------------------------------------------------------------------------------------------------
+class SlotTailParams:
+    """The parameters of SlotAttentionVideo's recurrent tail (steve.py:35-49), in the order _SlotTailFn takes them."""
+
+    def __init__(self, gru, norm_mlp, mlp, norm_slots, project_q):
+        self.tensors = (gru.weight_ih, gru.weight_hh, gru.bias_ih, gru.bias_hh, norm_mlp.weight, norm_mlp.bias,
+                        mlp[0].weight, mlp[0].bias, mlp[2].weight, mlp[2].bias, norm_slots.weight, norm_slots.bias,
+                        project_q.weight)
+        self.eps = (norm_mlp.eps, norm_slots.eps)
+
+
+def slot_tail_ok(x, params):
+    """The fused tail takes bf16 rows of width 192 with a 768-wide MLP (the BASELINE shape); FOCUS_SLOT_TAIL=0 disables it."""
+    if _os.environ.get("FOCUS_SLOT_TAIL", "1") == "0" or x.dtype != torch.bfloat16 or not x.is_cuda:
+        return False
+    D, H = params.tensors[0].shape[1], params.tensors[6].shape[0]
+    return bool(_lib.lib().focus_slot_tail_ok(D, H, BF16)) and all(t is not None for t in params.tensors)
+
+
+def _tail_wgrad(stash, w, has_b, dy, x):
+    """(dw, db) of one Linear application inside the tail: deferred (stacked over the applications) when a stash is open."""
+    if stash is not None:
+        done = _defer_close(stash, (dy, x))
+        return done if done is not None else (None, None)
+    return linear_wgrad(dy, x, bool(has_b))
+
+
+class _SlotTailFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, upd, h, eps1, eps2, do_gru, do_mlp, do_q, w_ih, w_hh, b_ih, b_hh, g1, be1, w1, b1, w2, b2, g2, be2, wq):
+        _need_gpu(h, wq)
+        h = h.contiguous()
+        R, D = h.shape
+        H = w1.shape[0]
+        dev, dt = h.device, h.dtype
+        a = _lib.SlotTailArgs()
+        a.R, a.D, a.H, a.do_gru, a.do_mlp, a.do_q = R, D, H, int(do_gru), int(do_mlp), int(do_q)
+        a.ln1_eps, a.ln2_eps = eps1, eps2
+        keep = [h]
+        new = lambda *s, dtype=dt: torch.empty(*s, device=dev, dtype=dtype)
+        a.h = h.data_ptr()
+        sv = {}
+        if do_gru:
+            upd = upd.contiguous()
+            keep.append(upd)
+            a.upd = upd.data_ptr()
+            ws = [shadow(w_ih, dt), shadow(w_hh, dt)]
+            keep += ws
+            a.w_ih, a.w_hh, a.b_ih, a.b_hh = ws[0].data_ptr(), ws[1].data_ptr(), b_ih.data_ptr(), b_hh.data_ptr()
+            sv["g"], sv["hn"] = new(2, R, 3 * D), new(R, D)
+            a.g, a.hn = sv["g"].data_ptr(), sv["hn"].data_ptr()
+        if do_mlp:
+            ws = [shadow(w1, dt), shadow(w2, dt)]
+            keep += ws
+            a.ln1_g, a.ln1_b, a.w1, a.b1, a.w2, a.b2 = (g1.data_ptr(), be1.data_ptr(), ws[0].data_ptr(), b1.data_ptr(),
+                                                        ws[1].data_ptr(), b2.data_ptr())
+            sv["y"], sv["a"], sv["s"] = new(R, D), new(R, H), new(R, D)
+            sv["mean1"], sv["rstd1"] = new(R, dtype=torch.float32), new(R, dtype=torch.float32)
+            a.y, a.a, a.s, a.mean1, a.rstd1 = (sv["y"].data_ptr(), sv["a"].data_ptr(), sv["s"].data_ptr(), sv["mean1"].data_ptr(),
+                                               sv["rstd1"].data_ptr())
+        if do_q:
+            wqs = shadow(wq, dt)
+            keep.append(wqs)
+            a.ln2_g, a.ln2_b, a.wq = g2.data_ptr(), be2.data_ptr(), wqs.data_ptr()
+            sv["sn"], sv["q"] = new(R, D), new(R, D)
+            sv["mean2"], sv["rstd2"] = new(R, dtype=torch.float32), new(R, dtype=torch.float32)
+            a.sn, a.q, a.mean2, a.rstd2 = sv["sn"].data_ptr(), sv["q"].data_ptr(), sv["mean2"].data_ptr(), sv["rstd2"].data_ptr()
+        _lib.check(_lib.lib().focus_slot_tail_fwd(ctypes.byref(a), _stream()), "slot_tail_fwd")
+        out = sv["s"] if do_mlp else (sv["hn"] if do_gru else h.view_as(h))
+        ctx.flags = (do_gru, do_mlp, do_q)
+        ctx.names = [k for k in ("g", "hn", "y", "a", "s", "mean1", "rstd1", "sn", "mean2", "rstd2") if k in sv]
+        ctx.save_for_backward(upd if do_gru else None, h, w_ih, w_hh, g1, w1, w2, g2, wq, *[sv[k] for k in ctx.names])
+        ctx.has_b = (b_ih is not None, b1 is not None, b2 is not None)
+        ni = ctx.needs_input_grad
+        # parameter gradients: stacked over all applications of the slot loop when ops.deferred_wgrads is open
+        ctx.st = {}
+        if do_gru:
+            ctx.st["ih"] = _defer_open("linear", (w_ih, b_ih), R, ni[7])
+            ctx.st["hh"] = _defer_open("linear", (w_hh, b_hh), R, ni[8])
+        if do_mlp:
+            ctx.st["ln1"] = _defer_open("ln", (g1, be1), R, ni[11])
+            ctx.st["w1"] = _defer_open("linear", (w1, b1), R, ni[13])
+            ctx.st["w2"] = _defer_open("linear", (w2, b2), R, ni[15])
+        if do_q:
+            ctx.st["ln2"] = _defer_open("ln", (g2, be2), R, ni[17])
+            ctx.st["wq"] = _defer_open("linear", (wq, None), R, ni[19])
+        return out, (sv["q"] if do_q else None)
+
+    @staticmethod
+    def backward(ctx, dout, dq):
+        do_gru, do_mlp, do_q = ctx.flags
+        saved = ctx.saved_tensors
+        upd, h, w_ih, w_hh, g1, w1, w2, g2, wq = saved[:9]
+        sv = dict(zip(ctx.names, saved[9:]))
+        R, D = h.shape
+        dt = h.dtype
+        L = _lib.lib()
+        grads = {}
+
+        def ln_bwd(dy, x, gamma, mean, rstd, dres, key):
+            nblk = L.focus_layernorm_bwd_blocks(R)
+            partial = torch.empty(2, nblk, D, device=h.device, dtype=torch.float32)
+            dx = torch.empty_like(x)
+            st = ctx.st.get(key)
+            dg = db = None
+            if st is None:
+                dg, db = torch.empty(D, device=h.device, dtype=torch.float32), torch.empty(D, device=h.device, dtype=torch.float32)
+            _lib.check(L.focus_layernorm_bwd(_p(dy), _p(x), _p(gamma), _p(mean), _p(rstd), _p(dres) if dres is not None else None,
+                                             _p(dx), _p(dg) if dg is not None else None, _p(db) if db is not None else None,
+                                             _p(partial), R, D, _dt(x), _stream()), "layernorm_bwd")
+            if st is not None:
+                done = _defer_close(st, partial)
+                dg, db = done if done is not None else (None, None)
+            return dx, dg, db
+
+        dcur = dout.contiguous() if dout is not None else None
+        if do_q and dq is not None:
+            dq = dq.contiguous()
+            cur = sv["s"] if do_mlp else (sv["hn"] if do_gru else h)
+            dsn = _dx_from(dq, wq, dt)
+            grads["wq"] = _tail_wgrad(ctx.st.get("wq"), wq, None, dq, sv["sn"])[0]
+            dcur, grads["g2"], grads["be2"] = ln_bwd(dsn, cur, g2, sv["mean2"], sv["rstd2"], dcur, "ln2")
+        if dcur is None:
+            dcur = torch.zeros_like(h)
+        if do_mlp:
+            ds = dcur
+            grads["w2"], grads["b2"] = _tail_wgrad(ctx.st.get("w2"), w2, ctx.has_b[2], ds, sv["a"])
+            dz = _dx_from(ds, w2, dt, aux=sv["a"], epilogue=_DEPI[EPI_RELU])
+            grads["w1"], grads["b1"] = _tail_wgrad(ctx.st.get("w1"), w1, ctx.has_b[1], dz, sv["y"])
+            dy1 = _dx_from(dz, w1, dt)
+            dhn, grads["g1"], grads["be1"] = ln_bwd(dy1, sv["hn"], g1, sv["mean1"], sv["rstd1"], ds, "ln1")
+        else:
+            dhn = dcur
+        dupd = None
+        if do_gru:
+            g = sv["g"]
+            G = 3 * D
+            dg = torch.empty_like(g)
+            res = torch.empty(2, R, D, device=h.device, dtype=dt)
+            _lib.check(L.focus_gru_gates_bwd(_p(g[0]), _p(g[1]), _p(h), _p(dhn), _p(dg[0]), _p(dg[1]), _p(res[1]), _p(res[0]), R, D,
+                                             _dt(h), _stream()), "gru_bwd")
+            dxh = torch.empty_like(res)
+            gemm(R, D, G, (dg, 0), (G, 1, 0, R * G), (_stacked_pair(w_ih, w_hh, dt, True), 0), (1, G, 0, D * G),
+                 (dxh, 0), (D, 1, 0, R * D), batch=(1, 2), residual=(res, 0))
+            grads["w_ih"], grads["b_ih"] = _tail_wgrad(ctx.st.get("ih"), w_ih, ctx.has_b[0], dg[0], upd)
+            grads["w_hh"], grads["b_hh"] = _tail_wgrad(ctx.st.get("hh"), w_hh, ctx.has_b[0], dg[1], h)
+            dupd, dh = dxh[0], dxh[1]
+        else:
+            dh = dhn
+        gg = grads.get
+        return (dupd, dh, None, None, None, None, None, gg("w_ih"), gg("w_hh"), gg("b_ih"), gg("b_hh"), gg("g1"), gg("be1"), gg("w1"),
+                gg("b1"), gg("w2"), gg("b2"), gg("g2"), gg("be2"), gg("wq"))
+
+
+def slot_tail(upd, h, params, gru=True, mlp=True, q=True):
+    """-> (slots [R,D], q [R,D] or None).  upd, h [R,D] bf16 (upd is ignored without gru); see the section comment."""
+    return _SlotTailFn.apply(upd, h, float(params.eps[0]), float(params.eps[1]), bool(gru), bool(mlp), bool(q), *params.tensors)

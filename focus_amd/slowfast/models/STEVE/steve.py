@@ -61,6 +61,10 @@ class SlotAttentionVideo(nn.Module):
         ni, ns, nm = self.norm_inputs, self.norm_slots, self.norm_mlp
         attns_collect, slots_collect = [], []
         video_grad = ops.FrameGrad()                              # one d(inputs) buffer written by all frames' LN nodes
+        tail = ops.SlotTailParams(self.gru, nm, self.mlp, ns, self.project_q)
+        fused_tail = ops.slot_tail_ok(slots, tail)                # GRU -> LN -> MLP -> LN -> q as ONE launch per iteration
+        if fused_tail:
+            return self._loop_fused(inputs, slots, B, T, K, Ds, k_scale, tail, video_grad)
         for t in range(T):
             # LayerNorm + k/v projections of frame t (per frame instead of whole-video: same values; the frame is read
             # in place and its gradient rows are written in place: ops.layer_norm_frame)
@@ -82,7 +86,34 @@ class SlotAttentionVideo(nn.Module):
                                     residual=sr, act=ops.EPI_RELU)
             attns_collect.append(attn_vis)
             slots_collect.append(slots)
-            slots = self.predictor(slots)
+            if t < T - 1:
+                # (steve.py:100 also runs the predictor after the LAST frame and discards the result: no output and no
+                # gradient depends on it, and a dead application would keep the stacked parameter gradients of
+                # ops.deferred_wgrads waiting for a backward that never comes)
+                slots = self.predictor(slots)
+        return torch.stack(slots_collect, dim=1), torch.stack(attns_collect, dim=1)
+
+
+    def _loop_fused(self, inputs, slots, B, T, K, Ds, k_scale, tail, video_grad):
+        """The same loop with the recurrent tail of every iteration in one launch (ops.slot_tail): per frame one "q only"
+        call on the incoming slots, then per iteration the slot attention and one tail call (GRU; + residual MLP and the
+        next query unless it is the last iteration)."""
+        ni = self.norm_inputs
+        attns_collect, slots_collect = [], []
+        slots = slots.reshape(B * K, Ds)
+        for t in range(T):
+            x_t = ops.layer_norm_frame(inputs, t, ni.weight, ni.bias, ni.eps, video_grad)
+            k_t, v_t = ops.linear_kv(x_t, self.project_k.weight, self.project_v.weight, alpha_k=k_scale)
+            kv_grad = ops.SlotKVGrad()
+            slots, q = ops.slot_tail(None, slots, tail, gru=False, mlp=False, q=True)
+            for i in range(self.num_iterations):
+                updates, attn_vis = ops.slot_attn_step(k_t, v_t, q.view(B, K, Ds), self.epsilon, kv_grad)  # :76-83
+                last = i == self.num_iterations - 1
+                slots, q = ops.slot_tail(updates.view(-1, Ds), slots, tail, gru=True, mlp=not last, q=not last)
+            attns_collect.append(attn_vis)
+            slots_collect.append(slots.view(B, K, Ds))
+            if t < T - 1:
+                slots = self.predictor(slots.view(B, K, Ds)).reshape(B * K, Ds)
         return torch.stack(slots_collect, dim=1), torch.stack(attns_collect, dim=1)
 
 

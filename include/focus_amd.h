@@ -408,7 +408,29 @@ typedef struct focus_wgrad_item {
     int32_t M, N, K, pad_;
 } focus_wgrad_item;
 int focus_linear_wgrad_group_units(const focus_wgrad_item* items, int n_items);
-int focus_linear_wgrad_group(const focus_wgrad_item* items, int n_items, void* stream);
+/* The launch's unit list (n_units x 8 bytes, HOST memory): a function of the (N, K) sequence only; the caller keeps a DEVICE
+ * copy per shape signature and hands it to focus_linear_wgrad_group. */
+int focus_linear_wgrad_group_plan(const focus_wgrad_item* items, int n_items, void* host_units, size_t bytes);
+int focus_linear_wgrad_group(const focus_wgrad_item* items, int n_items, const void* dev_units, void* stream);
+
+/* The per-iteration tail of the STEVE slot update in one launch (slot_tail.hip; steve.py:72-75,85-93, STEVE/utils.py:107-118):
+ * [do_gru] GRU cell on (upd, h) -> hn;  [do_mlp] s = hn + W2 relu(W1 LN1(hn) + b1) + b2;  [do_q] q = Wq LN2(slots) where slots
+ * is s, hn or (do_gru == 0: "q only") the input h itself.  R rows of D (= 192) channels, hidden width H (= 768); bf16
+ * activations and weights ([out, in] row-major, the bf16 working copies), fp32 biases / LayerNorm parameters / statistics.
+ * Every intermediate a backward needs is an output: g [2,R,3D] (gate pre-activations incl. bias), hn, y = LN1(hn) with
+ * mean1 / rstd1 [R], a = relu(..) [R,H], s, sn = LN2(slots) with mean2 / rstd2, q. */
+typedef struct focus_slot_tail_args {
+    int32_t R, D, H, do_gru, do_mlp, do_q;
+    float ln1_eps, ln2_eps;
+    const void* upd; const void* h;
+    const void* w_ih; const void* w_hh; const float* b_ih; const float* b_hh;
+    const float* ln1_g; const float* ln1_b; const void* w1; const float* b1; const void* w2; const float* b2;
+    const float* ln2_g; const float* ln2_b; const void* wq;
+    void* g; void* hn; void* y; float* mean1; float* rstd1; void* a; void* s;
+    void* sn; float* mean2; float* rstd2; void* q;
+} focus_slot_tail_args;
+int focus_slot_tail_ok(int D, int H, int dtype);
+int focus_slot_tail_fwd(const focus_slot_tail_args* args, void* stream);
 
 /* xdiag[b,s,:] = xt[b,s,s/P,:] (attention.py:533-535) and its adjoint dxt[b,s,s/P,:] += dxdiag[b,s,:]. */
 int focus_diag_gather(const void* xt, void* xdiag, int B, int S, int F, int C, int dtype, void* stream);

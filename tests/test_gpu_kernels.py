@@ -429,7 +429,13 @@ def test_grouped_weight_gradients_match_fp64(rows):
         arr[n].ld_dy, arr[n].ld_x, arr[n].M, arr[n].N, arr[n].K = dy.stride(0), x.stride(0), M, N, K
     assert L.focus_linear_wgrad_group_units(arr, len(shapes)) == 54 + 18 + 18 + 72 + 72 + 2 * 2 + 1 * 3
     stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-    _lib.check(L.focus_linear_wgrad_group(arr, len(shapes), stream), "linear_wgrad_group")
+    nu = L.focus_linear_wgrad_group_units(arr, len(shapes))
+    host = torch.empty(nu * 8, dtype=torch.uint8)
+    _lib.check(L.focus_linear_wgrad_group_plan(arr, len(shapes), ctypes.c_void_p(host.data_ptr()), nu * 8), "plan")
+    rec = host.view(torch.int16).view(nu, 4)
+    assert len({(int(a), int(b), int(c)) for a, b, c, _ in rec.tolist()}) == nu        # every tile exactly once
+    table = host.to(d)
+    _lib.check(L.focus_linear_wgrad_group(arr, len(shapes), ctypes.c_void_p(table.data_ptr()), stream), "linear_wgrad_group")
     torch.cuda.synchronize()
     ck = Check()
     for n, (dy, x, dw, db) in enumerate(keep):

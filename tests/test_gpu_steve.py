@@ -426,7 +426,7 @@ def test_graphed_slot_update_training_steps_equal_eager_bit_for_bit(dropout):
     results = []
     g = torch.Generator().manual_seed(0)
     video = torch.rand(2, 3, 3, 16, 16, generator=g).to(dev())
-    for graphed in (False, True):
+    for graphed in (False, False, True):
         ops.drop_caches()
         cfg, m = _steve_small(True)
         cfg.SOLVER.OPTIMIZING_METHOD = "adam"
@@ -447,7 +447,55 @@ def test_graphed_slot_update_training_steps_equal_eager_bit_for_bit(dropout):
         results.append((losses, {n: p.detach().clone() for n, p in m.named_parameters()}))
         if graphed:
             assert len(m._savi_graphs) == 1
-    (l0, p0), (l1, p1) = results
-    assert l0 == l1, (l0, l1)
-    for n in p0:
+    (l0, p0), (l0b, p0b), (l1, p1) = results
+    assert l0 == l0b == l1, (l0, l0b, l1)
+    # two EAGER runs first: whatever is reproducible run to run (everything on the HIP kernels; MIOpen's convolution weight
+    # gradients use atomics and are not, and Adam turns a flipped sign of a tiny gradient into a 2 lr step) must also be
+    # reproduced bit for bit by the graphed run
+    conv = lambda n: "dvae." in n or ".cnn." in n or ".pos." in n       # parameters whose gradients come from MIOpen convolutions
+    reproducible = [n for n in p0 if torch.equal(p0[n], p0b[n]) and not conv(n)]
+    assert all(n in reproducible for n in p0 if "savi" in n or "steve_decoder.tf" in n or "slot_proj" in n)
+    for n in reproducible:
         assert torch.equal(p0[n], p1[n]), n
+    for n in p0:                                                      # the rest: equal up to the convolutions' own run-to-run noise
+        if conv(n):
+            spread = float((p0[n] - p0b[n]).abs().max())
+            assert float((p0[n] - p1[n]).abs().max()) <= max(10 * spread, 2.5e-3), n
+
+
+def test_fused_slot_tail_matches_the_unfused_loop(monkeypatch):
+    """ops.slot_tail (csrc/slot_tail.hip: GRU -> LN -> MLP -> LN -> q per iteration in one launch) against the same
+    SlotAttentionVideo with FOCUS_SLOT_TAIL=0 (eight launches per iteration): slots, attention maps, input gradient and every
+    parameter gradient.  The two differ only in where bf16 roundings fall (the fused kernel rounds less often)."""
+    from focus_amd import ops
+    from focus_amd.slowfast.models.STEVE.steve import SlotAttentionVideo
+    d = dev()
+    B, T, N, D, K = 4, 3, 512, 192, 11
+    torch.manual_seed(0)
+    m = SlotAttentionVideo(3, K, D, D, 4 * D, num_predictor_blocks=1, num_predictor_heads=4, dropout=0.0).to(d)
+    g = torch.Generator(device=d).manual_seed(1)
+    x0 = torch.randn(B, T, N, D, device=d, generator=g).bfloat16()
+    noise = torch.randn(B, K, D, device=d, generator=g)
+    cs = torch.randn(B, T, K, D, device=d, generator=g)
+
+    def run(fused):
+        monkeypatch.setenv("FOCUS_SLOT_TAIL", "1" if fused else "0")
+        ops.drop_caches()
+        for p in m.parameters():
+            p.grad = None
+        x = x0.clone().requires_grad_()
+        slots, attn = m(x, noise=noise)
+        ((slots.float() * cs).sum() + attn.float().square().sum()).backward()
+        torch.cuda.synchronize()
+        return slots.detach().float(), attn.detach().float(), x.grad.float(), {n: p.grad.clone() for n, p in m.named_parameters()}
+
+    s0, a0, dx0, g0 = run(False)
+    s1, a1, dx1, g1 = run(True)
+    # two bf16 pipelines that round at different places: the bf16 criterion of test_gpu_parity.close (L2-relative error and a
+    # loose max-norm bound); both are held to the fp64 oracle separately (test_slot_attention_slice_vs_oracle runs the fused path)
+    close(s1, s0, 3e-2, "slots")
+    close(a1, a0, 3e-2, "attn")
+    close(dx1, dx0, 5e-2, "d inputs")
+    for n in g0:
+        assert g1[n] is not None, n
+        close(g1[n].float(), g0[n].float(), 6e-2, "grad " + n, floor=1e-2 * float(g0[n].abs().max()) + 1e-12)
