@@ -182,11 +182,32 @@ __global__ __launch_bounds__(1024) void roi_bwd_sep_kernel(const T* __restrict__
             const Geom g = roi_geometry(rois + 4 * k, scale, PH, PW, sr, aligned);
             if (g.grid_h <= 0 || g.grid_w <= 0) continue;                  // block-uniform
             __syncthreads();                                               // previous RoI's gst / Ay / Ax are free
-            for (int bin = x; bin < bins; bin += nw) {
-                const int64_t o = ((int64_t)k * bins + bin) * C + c0 + ch;
-                float gv = ld<T>(dout + o) / g.count;
-                if (relu_out && !(ld<T>(relu_out + o) > 0.f)) gv = 0.f;     // fused ReLU: the saved output is the mask
-                gst[bin * RB_CS + ch] = gv;
+            if (bins <= 16 * nw) {
+                // all loads of this thread issued together (unrolled, clamped addresses instead of a branch): as a rolled
+                // "load, store to LDS" loop every iteration waited for its own load -- 14 serial round trips per RoI, the
+                // whole launch ran at 3 % of the HBM rate (215 us for 48 MB)
+                float gv[16], rv[16];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int bin = min(x + i * nw, bins - 1);
+                    const int64_t o = ((int64_t)k * bins + bin) * C + c0 + ch;
+                    gv[i] = ld<T>(dout + o);
+                    rv[i] = relu_out ? ld<T>(relu_out + o) : 1.f;
+                }
+                const float inv = 1.f / g.count;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int bin = x + i * nw;
+                    if (bin < bins) gst[bin * RB_CS + ch] = rv[i] > 0.f ? gv[i] / g.count : 0.f;
+                }
+                (void)inv;
+            } else {
+                for (int bin = x; bin < bins; bin += nw) {
+                    const int64_t o = ((int64_t)k * bins + bin) * C + c0 + ch;
+                    float gv = ld<T>(dout + o) / g.count;
+                    if (relu_out && !(ld<T>(relu_out + o) > 0.f)) gv = 0.f;     // fused ReLU: the saved output is the mask
+                    gst[bin * RB_CS + ch] = gv;
+                }
             }
             if (threadIdx.x < RB_HMAX * RB_PMAX) { (&Ay[0][0])[threadIdx.x] = 0.f; (&Ax[0][0])[threadIdx.x] = 0.f; }
             __syncthreads();

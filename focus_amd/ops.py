@@ -1389,6 +1389,21 @@ class _TrajTime2BlockFn(torch.autograd.Function):
                                           _p(dxt), _p(g), _p(dl), B, S, F_, heads, d, _dt(xt), _stream()), "traj_time2_bwd")
         R = B * S
         dq2 = dw = db = None
+        if (ctx.needs_input_grad[0] and ctx.needs_input_grad[2] and L.focus_traj_time2_gw_ok(R, heads, d, _dt(xt))
+                and _os.environ.get("FOCUS_TIME2_GW", "1") != "0"):
+            # both consumers of g in one pass over it (csrc/traj_time2_gw.hip): g is 12x the size of dq2
+            wk = shadow(w_kv, xt.dtype)                                  # [2C, C] row-major: rows :C are Wk
+            dq2 = torch.empty(B, S, C, device=dev, dtype=xt.dtype)
+            dw = torch.empty(2 * C, C, device=dev, dtype=torch.float32)
+            nbw = L.focus_traj_time2_gw_workspace_bytes(R, heads, d)
+            wsw = torch.empty(nbw // 4, device=dev, dtype=torch.float32)
+            _lib.check(L.focus_traj_time2_gw(_p(g), _p(q2), _p(wk), wk.stride(0), _p(dq2), _p(dw), _p(wsw), nbw, R, heads, d,
+                                             _dt(xt), _stream()), "traj_time2_gw")
+            dw[C:].zero_()                      # v2 half: no output use, exactly zero gradient
+            if ctx.has_b and ctx.needs_input_grad[3]:
+                db = torch.zeros(2 * C, device=dev, dtype=torch.float32)   # softmax over f is shift invariant: exactly 0
+            dcls = dcat[:, :1].reshape(ctx.cls_shape) if ctx.needs_input_grad[4] else None
+            return dq2, dxt, dw, db, dcls, None
         if ctx.needs_input_grad[0]:
             # dq2[r, h*d+dd] = sum_c g[h,r,c] Wk[h*d+dd, c]   (one launch, batched over the heads)
             wk = shadow(w_kv, xt.dtype)                                  # [2C, C] row-major: rows :C are Wk

@@ -432,6 +432,15 @@ typedef struct focus_slot_tail_args {
 int focus_slot_tail_ok(int D, int H, int dtype);
 int focus_slot_tail_fwd(const focus_slot_tail_args* args, void* stream);
 
+/* Both consumers of g = d(loss)/d(u) of the re-associated temporal step in one pass over g (traj_time2_gw.hip; autograd of
+ * attention.py:536-549): dq2[r, h*d+dd] = sum_c g[h,r,c] Wk[h*d+dd, c] and dWk[h*d+dd, c] = sum_r q2[r, h*d+dd] g[h,r,c].
+ * g [heads][R][C] bf16, q2 / dq2 [R][C] bf16, wk = the bf16 rows of Wk (row stride wk_ld), dwk [C][C] fp32 dense.
+ * bf16, d = 64, C = 768, R % 32 == 0 (focus_traj_time2_gw_ok); ws: focus_traj_time2_gw_workspace_bytes. */
+int focus_traj_time2_gw_ok(int R, int heads, int d, int dtype);
+size_t focus_traj_time2_gw_workspace_bytes(int R, int heads, int d);
+int focus_traj_time2_gw(const void* g, const void* q2, const void* wk, int64_t wk_ld, void* dq2, float* dwk, void* ws,
+                        size_t ws_bytes, int R, int heads, int d, int dtype, void* stream);
+
 /* xdiag[b,s,:] = xt[b,s,s/P,:] (attention.py:533-535) and its adjoint dxt[b,s,s/P,:] += dxdiag[b,s,:]. */
 int focus_diag_gather(const void* xt, void* xdiag, int B, int S, int F, int C, int dtype, void* stream);
 int focus_diag_scatter_add(const void* dxdiag, void* dxt, int B, int S, int F, int C, int dtype, void* stream);

@@ -5,7 +5,7 @@ parameter receives a gradient) and a B=2, T=2 slice of the same shape is compare
 import pytest
 import torch
 
-from test_gpu_parity import close, dev
+from test_gpu_parity import close, dev, rel_l2
 
 pytestmark = pytest.mark.gpu
 
@@ -448,16 +448,25 @@ def test_graphed_slot_update_training_steps_equal_eager_bit_for_bit(dropout):
         if graphed:
             assert len(m._savi_graphs) == 1
     (l0, p0), (l0b, p0b), (l1, p1) = results
-    assert l0 == l0b == l1, (l0, l0b, l1)
-    # two EAGER runs first: whatever is reproducible run to run (everything on the HIP kernels; MIOpen's convolution weight
-    # gradients use atomics and are not, and Adam turns a flipped sign of a tiny gradient into a 2 lr step) must also be
-    # reproduced bit for bit by the graphed run
     conv = lambda n: "dvae." in n or ".cnn." in n or ".pos." in n       # parameters whose gradients come from MIOpen convolutions
-    reproducible = [n for n in p0 if torch.equal(p0[n], p0b[n]) and not conv(n)]
-    assert all(n in reproducible for n in p0 if "savi" in n or "steve_decoder.tf" in n or "slot_proj" in n)
-    for n in reproducible:
-        assert torch.equal(p0[n], p1[n]), n
-    for n in p0:                                                      # the rest: equal up to the convolutions' own run-to-run noise
+    if dropout == 0.0:
+        assert l0 == l0b == l1, (l0, l0b, l1)
+        # two EAGER runs first: whatever is reproducible run to run (everything on the HIP kernels; MIOpen's convolution
+        # weight gradients use atomics and are not, and Adam turns a flipped sign of a tiny gradient into a 2 lr step) must
+        # also be reproduced bit for bit by the graphed run
+        reproducible = [n for n in p0 if torch.equal(p0[n], p0b[n]) and not conv(n)]
+        assert all(n in reproducible for n in p0 if "savi" in n or "steve_decoder.tf" in n or "slot_proj" in n)
+        for n in reproducible:
+            assert torch.equal(p0[n], p1[n]), n
+    else:
+        # with dropout the predictor's attention takes the unfused path whose small-shape bias gradients are summed with
+        # float atomics (focus_colsum over several row blocks): last-bit differences between any two runs; the random
+        # streams themselves agree (a different mask would move the loss in the second digit, not the eighth)
+        assert l0[:2] == l1[:2] and abs(l0[2] - l1[2]) <= 1e-6 * abs(l0[2]), (l0, l1)
+        for n in p0:
+            if not conv(n):
+                assert torch.allclose(p0[n], p1[n], rtol=1e-3, atol=2.5e-3), n
+    for n in p0:                                                      # the convolutions: equal up to their own run-to-run noise
         if conv(n):
             spread = float((p0[n] - p0b[n]).abs().max())
             assert float((p0[n] - p1[n]).abs().max()) <= max(10 * spread, 2.5e-3), n
@@ -478,24 +487,31 @@ def test_fused_slot_tail_matches_the_unfused_loop(monkeypatch):
     noise = torch.randn(B, K, D, device=d, generator=g)
     cs = torch.randn(B, T, K, D, device=d, generator=g)
 
-    def run(fused):
+    def run(fused, fp32=False):
         monkeypatch.setenv("FOCUS_SLOT_TAIL", "1" if fused else "0")
         ops.drop_caches()
         for p in m.parameters():
             p.grad = None
-        x = x0.clone().requires_grad_()
+        x = (x0.float() if fp32 else x0.clone()).requires_grad_()
         slots, attn = m(x, noise=noise)
         ((slots.float() * cs).sum() + attn.float().square().sum()).backward()
         torch.cuda.synchronize()
         return slots.detach().float(), attn.detach().float(), x.grad.float(), {n: p.grad.clone() for n, p in m.named_parameters()}
 
+    sr, ar, dxr, gr = run(False, fp32=True)          # the same module on fp32 inputs: fp32 kernels throughout, no fused tail
     s0, a0, dx0, g0 = run(False)
     s1, a1, dx1, g1 = run(True)
-    # two bf16 pipelines that round at different places: the bf16 criterion of test_gpu_parity.close (L2-relative error and a
-    # loose max-norm bound); both are held to the fp64 oracle separately (test_slot_attention_slice_vs_oracle runs the fused path)
-    close(s1, s0, 3e-2, "slots")
-    close(a1, a0, 3e-2, "attn")
-    close(dx1, dx0, 5e-2, "d inputs")
+    # two bf16 pipelines that round at different places, nine chained slot updates with sharp softmaxes in between: each is
+    # compared with the fp32 run (L2-relative), and the fused one, which rounds less often, may not be further from it than the
+    # unfused one is (25 % slack); both are held to the fp64 oracle separately (test_slot_attention_slice_vs_oracle, fused path)
+
+    def both(f1, f0, ref, cap, what, floor=1e-3):
+        e1, e0 = rel_l2(f1, ref, floor), rel_l2(f0, ref, floor)
+        assert e1 < cap and e1 <= 1.25 * e0 + 5e-3, "%s: fused %.3e, unfused %.3e (cap %.1e)" % (what, e1, e0, cap)
+
+    both(s1, s0, sr, 3e-2, "slots")
+    both(a1, a0, ar, 3e-2, "attn")
+    both(dx1, dx0, dxr, 8e-2, "d inputs")
     for n in g0:
         assert g1[n] is not None, n
-        close(g1[n].float(), g0[n].float(), 6e-2, "grad " + n, floor=1e-2 * float(g0[n].abs().max()) + 1e-12)
+        both(g1[n].float(), g0[n].float(), gr[n].float(), 8e-2, "grad " + n, floor=1e-2 * float(gr[n].abs().max()) + 1e-12)
