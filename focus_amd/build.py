@@ -33,40 +33,9 @@ def _device_asm(src):
 
 
 def lint_hand_loads(asm_path):
-    """Problems in kernels that issue loads by hand: the compiler does not know such a load is still in flight, so a
-    register COPY of its destination (a spill to scratch, or a park in an AGPR: v_accvgpr_write_b32 aN, vM) made before
-    the hand-counted wait copies garbage.  Returns [(kernel, what)] for every kernel with hand-issued loads that has
-    scratch or any VGPR -> AGPR copy (strict: the copy may be of another value, but then the kernel is one register
-    allocation away from the bad case)."""
-    problems = []
-    name, hand, copies, pending = None, False, 0, None
-    in_asm = False
-    with open(asm_path) as f:
-        for line in f:
-            t = line.strip()
-            if name is None:
-                if pending and t.startswith("; ScratchSize:"):
-                    if int(t.split(":")[1]) != 0:
-                        problems.append((pending, "scratch " + t.split(":")[1].strip() + " B/lane"))
-                    pending = None
-                m = re.match(r"^(_Z\w+):", line)
-                if m:
-                    name, hand, copies, pending = m.group(1), False, 0, None
-                continue
-            if t.startswith(";;#ASMSTART"):
-                in_asm = True
-            elif t.startswith(";;#ASMEND"):
-                in_asm = False
-            elif in_asm and t.startswith("global_load_"):
-                hand = True
-            elif re.match(r"v_accvgpr_write_b32 a\d+, v\d+", t):
-                copies += 1
-            elif t.startswith(".Lfunc_end"):
-                if hand and copies:
-                    problems.append((name, "%d VGPR->AGPR copies" % copies))
-                pending = name if hand else None
-                name = None
-    return problems
+    """[(kernel, problem)] for the kernels of a device .s that issue loads by hand (focus_amd/asm_lint.py)."""
+    from focus_amd import asm_lint
+    return asm_lint.lint_hand_loads(asm_path)
 
 
 def _compile(src, headers):
@@ -74,12 +43,16 @@ def _compile(src, headers):
     if _stale(obj, [src] + headers):
         extra = ["-save-temps=obj"] if _hand_loads(src) else []       # keeps the device .s next to the object: linted below
         subprocess.check_call([HIPCC] + FLAGS + extra + ["-c", src, "-o", obj])
-    if _hand_loads(src) and os.path.exists(_device_asm(src)):
+    if _hand_loads(src):
+        if not os.path.exists(_device_asm(src)):                        # an object without its assembly was not linted
+            os.remove(obj)
+            raise RuntimeError("%s issues loads by hand but its device assembly %s is missing: rebuild" % (
+                os.path.basename(src), _device_asm(src)))
         bad = lint_hand_loads(_device_asm(src))
         if bad:
             os.remove(obj)
-            raise RuntimeError("%s: kernels with hand-issued loads whose registers the compiler copies:\n  %s" % (
-                os.path.basename(src), "\n  ".join("%s: %s" % b for b in bad)))
+            raise RuntimeError("%s: registers of hand-issued loads touched before their wait (%d reports):\n  %s" % (
+                os.path.basename(src), len(bad), "\n  ".join("%s: %s" % b for b in bad[:40])))
     return obj
 
 

@@ -904,6 +904,13 @@ __global__ __launch_bounds__(256) void slot_kv_grad_kernel(const KvGradArgs a, i
   }
 }
 
+// FOCUS_SLOT_HAND=0: the compiler-issued variants (FULL = false) also where every row exists -- the same arithmetic with
+// hipcc's own s_waitcnt in place of the hand-counted ones; read per call so that one test can compare the two bit for bit.
+static bool slot_hand_loads() {
+    const char* e = getenv("FOCUS_SLOT_HAND");
+    return !(e && atoi(e) == 0);
+}
+
 inline bool slot_mfma_ok(const void* a, const void* b, const void* c, int64_t kv_bs, int K, int D, int dtype) {
     static const bool enabled = !(getenv("FOCUS_SLOT_MFMA") && atoi(getenv("FOCUS_SLOT_MFMA")) == 0);
     return enabled && dtype == FOCUS_BF16 && K <= 16 && (D == 64 || D == 128 || D == 192 || D == 256) && (kv_bs & 7) == 0 &&
@@ -941,7 +948,7 @@ extern "C" int focus_slot_attn_fwd(const void* k_t, const void* v_t, int64_t kv_
     if (slot_mfma_ok(k_t, v_t, q, kv_bs, K, D, dtype)) {
         dim3 gm(nchunks_mfma(N), B);
 #define SFM_(KS, FULL) hipLaunchKernelGGL((slot_fwd_mfma_kernel<KS, FULL>), gm, dim3(256), 0, s, (const bf16_t*)k_t, (const bf16_t*)v_t, kv_bs, (const bf16_t*)q, (bf16_t*)attn_vis, attn_bs, (float*)partial, N, K, eps)
-#define SFM(KS) do { if (N % MROWS == 0) SFM_(KS, true); else SFM_(KS, false); } while (0)
+#define SFM(KS) do { if (N % MROWS == 0 && slot_hand_loads()) SFM_(KS, true); else SFM_(KS, false); } while (0)
         if (D == 64) SFM(2); else if (D == 128) SFM(4); else if (D == 192) SFM(6); else SFM(8);
 #undef SFM
 #undef SFM_
@@ -995,7 +1002,7 @@ extern "C" int focus_slot_attn_bwd(const void* k_t, const void* v_t, int64_t kv_
 #define SBD(KS, FULL, DA) hipLaunchKernelGGL((slot_bwd_defer_kernel<KS, FULL, DA>), gm, dim3(256), 0, s, (const bf16_t*)k_t, (const bf16_t*)v_t, kv_bs, (const bf16_t*)attn_vis, attn_bs, colsum, (const bf16_t*)upd, (const bf16_t*)dupd, (const bf16_t*)dattn_vis, (bf16_t*)wl, (float*)partial, N, K, eps)
 #define SBM(KS) do { \
         if (wl) { \
-            if (N % MROWS == 0) { if (dattn_vis) SBD(KS, true, true); else SBD(KS, true, false); } \
+            if (N % MROWS == 0 && slot_hand_loads()) { if (dattn_vis) SBD(KS, true, true); else SBD(KS, true, false); } \
             else { if (dattn_vis) SBD(KS, false, true); else SBD(KS, false, false); } } \
         else hipLaunchKernelGGL((slot_bwd_mfma_kernel<KS>), gm, dim3(256), 0, s, (const bf16_t*)k_t, (const bf16_t*)v_t, kv_bs, (const bf16_t*)q, (const bf16_t*)attn_vis, attn_bs, colsum, (const bf16_t*)upd, (const bf16_t*)dupd, (const bf16_t*)dattn_vis, (bf16_t*)dk_t, (bf16_t*)dv_t, accumulate, (float*)partial, N, K, eps); } while (0)
         if (D == 64) SBM(2); else if (D == 128) SBM(4); else if (D == 192) SBM(6); else SBM(8);

@@ -103,6 +103,15 @@ __device__ __forceinline__ Owner owner_of_block(int nchunk, int spread) {
     return o;
 }
 
+// A block's tile range in whole turns of its prefetch ring (DEPTH tiles): the unrolled ring loops below then have one exit,
+// at the loop head, and no register of the ring is live across a second one (a mid-turn exit made hipcc rotate ring
+// registers with v_mov on the back edge -- copies of loads still in flight; focus_amd/build.py lint_hand_loads).  The last
+// range may run up to DEPTH - 1 tiles past ntiles: their loads clamp to the last row, their stores are masked by row < rows.
+__device__ __forceinline__ int turn_begin(int ntiles, int range, int nranges, int depth) {
+    const int turns = (ntiles + depth - 1) / depth;
+    return (int)((int64_t)turns * range / nranges) * depth;
+}
+
 // Global loads the compiler does not track (hand-counted s_waitcnt vmcnt, cdna_hip_programming.md 5.7 form (iii)): used
 // for the prefetch rings -- hipcc's own counting of ring loads in these loops ends in vmcnt(0) ladders.
 __device__ __forceinline__ void gload16_asm(bf16x8& dst, const void* p) {
@@ -113,6 +122,11 @@ __device__ __forceinline__ void gload4_asm(float& dst, const void* p) {
 }
 __device__ __forceinline__ void pin(bf16x8& v) { asm volatile("" : "+v"(v)); }
 __device__ __forceinline__ void pin(float& v) { asm volatile("" : "+v"(v)); }
+// Leaving a slot: whatever is computed FROM a ring slot must itself be pinned before the slot is refilled.  Volatile asm
+// statements keep their order, plain VALU work does not: hipcc once sank the residual add of time2_dx_lds_kernel below the
+// refill, which made the old and the new contents of the slot live together, gave the refill other registers and rotated
+// them back with v_mov on the loop's back edge -- copies of loads still in flight (the build's lint_hand_loads reports it).
+__device__ __forceinline__ void pin(uint4& v) { asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w)); }
 
 // ---- U images in LDS (conflict degrees from tools/lds_bank_model.py, lane groups of MI355X_MICROARCH.md "LDS") ----
 // forward : U[16 s][heads][64 c], head pitch 128 + 16 B, query pitch + 16 B: read as the MFMA B operand with the HEAD on
@@ -214,7 +228,7 @@ __global__ __launch_bounds__(512) void time2_logits_kernel(const bf16_t* __restr
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int urow = fwd_urow(heads);
     const int ntiles = (rows + TQ - 1) / TQ;
-    const int t_begin = (int)((int64_t)ntiles * own.range / own.nranges), t_end = (int)((int64_t)ntiles * (own.range + 1) / own.nranges);
+    const int t_begin = turn_begin(ntiles, own.range, own.nranges, 3), t_end = turn_begin(ntiles, own.range + 1, own.nranges, 3);   // 3 = XD below
     const int niter = t_end - t_begin;
     WFrag<UPW> wf;
     load_w_frags<UPW>(wf, wkT, ldw, cc, heads, w, lane);
@@ -271,7 +285,6 @@ __global__ __launch_bounds__(512) void time2_logits_kernel(const bf16_t* __restr
       for (int k = 0; k < XD; ++k) {
         const int k1 = (k + 1) % XD;                              // (static after unrolling)
         const int it = itb + k;
-        if (it >= niter) break;
         const int t = t_begin + it, row0 = t * TQ;
         const char* sU = smem + (it & 1) * (TQ * urow);
         char* sUn = smem + ((it + 1) & 1) * (TQ * urow);
@@ -370,7 +383,7 @@ __global__ __launch_bounds__(512) void time2_logits_lds_kernel(const bf16_t* __r
     char* sQb = smem + 2 * TQ * urow;
     char* sXb = sQb + 2 * TQ * QP;
     const int ntiles = (rows + TQ - 1) / TQ;
-    const int t_begin = (int)((int64_t)ntiles * own.range / own.nranges), t_end = (int)((int64_t)ntiles * (own.range + 1) / own.nranges);
+    const int t_begin = turn_begin(ntiles, own.range, own.nranges, 2), t_end = turn_begin(ntiles, own.range + 1, own.nranges, 2);
     const int niter = t_end - t_begin;
     if (niter <= 0) return;
     WFrag<UPW> wf;
@@ -451,7 +464,6 @@ __global__ __launch_bounds__(512) void time2_logits_lds_kernel(const bf16_t* __r
 #pragma unroll
       for (int k = 0; k < 2; ++k) {
         const int it = itb + k;
-        if (it >= niter) break;
         const int t = t_begin + it, row0 = t * TQ;
         // A: this tile's x~ fragments and U rows, the next tile's q2 fragments -> registers
         const char* sx = sXb + k * (XROWS * XP);
@@ -666,7 +678,7 @@ __global__ __launch_bounds__(512) void time2_dx_kernel(const bf16_t* __restrict_
     const int C = heads * CH, cc = own.cc;
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int ntiles = (rows + TQ - 1) / TQ;
-    const int t_begin = (int)((int64_t)ntiles * own.range / own.nranges), t_end = (int)((int64_t)ntiles * (own.range + 1) / own.nranges);
+    const int t_begin = turn_begin(ntiles, own.range, own.nranges, FT > 8 ? 2 : 3), t_end = turn_begin(ntiles, own.range + 1, own.nranges, FT > 8 ? 2 : 3);   // = XD below
     const int niter = t_end - t_begin;
     WFrag<UPW> wf;
     load_w_frags<UPW>(wf, wkT, ldw, cc, heads, w, lane);
@@ -725,7 +737,6 @@ __global__ __launch_bounds__(512) void time2_dx_kernel(const bf16_t* __restrict_
       for (int k = 0; k < XD; ++k) {
         const int k1 = (k + 1) % XD;                              // (static after unrolling)
         const int it = itb + k;
-        if (it >= niter) break;
         const int t = t_begin + it, row0 = t * TQ;
         const char* sU = smem + (it & 1) * (TQ * BWD_UROW);
         char* sUn = smem + ((it + 1) & 1) * (TQ * BWD_UROW);
@@ -778,7 +789,8 @@ __global__ __launch_bounds__(512) void time2_dx_kernel(const bf16_t* __restrict_
                 for (int r = 0; r < 4; ++r) v[4 * mt + r] = fmaf(av, dv[4 * mt + r], acc[mt][r]);
             o[i][0] = pack8(v);
             o[i][1] = pack8(v + 8);
-        }
+            pin(o[i][0]); pin(o[i][1]);                          // the last use of this slot's operands is BEFORE its refill:
+        }                                                        // see "leaving a slot" at pin()
         asm volatile("" ::: "memory");
         pin_q(qr[k1]);
         pin_d(dr[k]);
@@ -819,7 +831,7 @@ __global__ __launch_bounds__(512) void time2_dx_lds_kernel(const bf16_t* __restr
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
     char* sQb = smem + 2 * TQ * BWD_UROW;
     const int ntiles = (rows + TQ - 1) / TQ;
-    const int t_begin = (int)((int64_t)ntiles * own.range / own.nranges), t_end = (int)((int64_t)ntiles * (own.range + 1) / own.nranges);
+    const int t_begin = turn_begin(ntiles, own.range, own.nranges, 2), t_end = turn_begin(ntiles, own.range + 1, own.nranges, 2);
     const int niter = t_end - t_begin;
     if (niter <= 0) return;
     WFrag<UPW> wf;
@@ -907,7 +919,6 @@ __global__ __launch_bounds__(512) void time2_dx_lds_kernel(const bf16_t* __restr
 #pragma unroll
       for (int k = 0; k < 2; ++k) {
         const int it = itb + k;
-        if (it >= niter) break;
         const int t = t_begin + it, row0 = t * TQ;
         const char* sU = smem + k * (TQ * BWD_UROW);
         // A: U^T of this tile (gathered h-major) and the next tile's q2 fragments -> registers
@@ -970,7 +981,8 @@ __global__ __launch_bounds__(512) void time2_dx_lds_kernel(const bf16_t* __restr
                 for (int r = 0; r < 4; ++r) v[4 * mt + r] = fmaf(av, dv[4 * mt + r], acc[mt][r]);
             o[i][0] = pack8(v);
             o[i][1] = pack8(v + 8);
-        }
+            pin(o[i][0]); pin(o[i][1]);                          // the last use of this slot's operands is BEFORE its refill:
+        }                                                        // see "leaving a slot" at pin()
         asm volatile("" ::: "memory");
         pin_d(dr[k]);
         load_d(dr[k], t + 2);

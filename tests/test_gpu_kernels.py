@@ -279,6 +279,41 @@ def test_slot_attention_kernels_tight():
     ck.done()
 
 
+@pytest.mark.parametrize("N,K,D", [(4096, 11, 192), (1024, 7, 64), (512, 16, 256)])
+def test_slot_kernels_hand_issued_loads_equal_compiler_issued_bit_for_bit(N, K, D, monkeypatch):
+    """slot_fwd_mfma_kernel / slot_bwd_defer_kernel prefetch through inline-asm loads with hand-counted waits where every row
+    of a workgroup exists (FULL); FOCUS_SLOT_HAND=0 runs the same arithmetic with compiler-issued loads and hipcc's own
+    s_waitcnt.  Same inputs, three iterations sharing one SlotKVGrad: every output and gradient must agree bitwise (a wait
+    counted one short shows up here as soon as a load is late; focus_amd/asm_lint.py is the static side of this check)."""
+    from focus_amd import ops
+    B, iters = 4, 3
+    d = dev()
+    g = torch.Generator().manual_seed(N + K)
+    k = bf(torch.randn(B, N, D, generator=g) * D ** -0.5).to(d)
+    v = bf(torch.randn(B, N, D, generator=g)).to(d)
+    qs = [bf(torch.randn(B, K, D, generator=g)).to(d) for _ in range(iters)]
+    cus = [torch.randn(B, K, D, generator=g).to(d) for _ in range(iters)]
+    cas = [(torch.randn(B, N, K, generator=g) * 1e-2).to(d) for _ in range(iters)]
+
+    def run(hand):
+        monkeypatch.setenv("FOCUS_SLOT_HAND", "1" if hand else "0")
+        kg, vg = k.clone().requires_grad_(), v.clone().requires_grad_()
+        qg = [q.clone().requires_grad_() for q in qs]
+        acc = ops.SlotKVGrad()
+        outs, loss = [], 0.0
+        for i in range(iters):
+            u, a = ops.slot_attn_step(kg, vg, qg[i], 1e-8, acc)
+            outs += [u.detach().clone(), a.detach().clone()]
+            loss = loss + (u.float() * cus[i]).sum() + (a.float() * cas[i]).sum()
+        loss.backward()
+        torch.cuda.synchronize()
+        return outs + [kg.grad, vg.grad] + [q.grad for q in qg]
+
+    hand, auto = run(True), run(False)
+    for i, (a, b) in enumerate(zip(hand, auto)):
+        assert torch.equal(a, b), "tensor %d differs between hand-issued and compiler-issued loads" % i
+
+
 @pytest.mark.parametrize("iters,N,K,D", [(3, 4096, 11, 192), (1, 300, 16, 64), (4, 1000, 7, 128), (2, 77, 3, 256)])
 def test_slot_kv_grad_shared_by_the_iterations_of_a_frame(iters, N, K, D):
     """d(k_t), d(v_t) when `iters` corrector iterations read the same k_t, v_t (steve.py:68-83) through one SlotKVGrad:
