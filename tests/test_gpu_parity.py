@@ -362,6 +362,57 @@ def test_training_steps_keep_bf16_shadows_fresh(oracle):
     close(got, ref, 5e-2, "logits after 2 optimizer steps")
 
 
+def test_bf16_training_trajectory_follows_the_fp32_oracle(oracle):
+    """Twenty optimizer steps of train_step (focus_amd/train.py; tools/train_net.py:86-120 of the reference) on the small
+    ORViT-Motionformer fixture in bf16 -- HIP kernels, fused clip + AdamW, bf16 weight shadows refreshed by the step --
+    against the oracle's fp32 forward differentiated by autograd on the CPU with torch.optim.AdamW over the same two
+    parameter groups, the same clip and the same batch.  The two loss curves must stay within 2 % of each other at every
+    step (a stale shadow, a dropped gradient or a wrong bias correction shows within a few steps at this learning rate)."""
+    from focus_amd.slowfast.models import build_model
+    from focus_amd.slowfast.models.losses import get_loss_func
+    from focus_amd.slowfast.models.optimizer import construct_optimizer
+    from focus_amd.train import train_step
+    a, p = load_golden("motionformer_small")
+    steps, lr, wd, clip = 20, 1e-3, 0.05, 1.0
+    cfg = _small_cfg(True)
+    cfg.merge_from_list(["SOLVER.OPTIMIZING_METHOD", "adamw", "SOLVER.BASE_LR", lr, "SOLVER.WEIGHT_DECAY", wd,
+                         "SOLVER.CLIP_GRAD_L2NORM", clip])
+    m = build_model(cfg)
+    m.load_state_dict({k: v.float() for k, v in p.items()})
+    m.train()
+    opt = construct_optimizer(m, cfg)
+    loss_fun = get_loss_func(cfg)(reduction="mean")
+    x, boxes = T(a["x"]).to(dev()), T(a["boxes"]).to(dev())
+    labels = torch.from_numpy(a["labels"]).to(dev())
+    got = []
+    for _ in range(steps):
+        _, loss = train_step(m, opt, loss_fun, [x], labels, {"orvit_bboxes": boxes}, cfg)
+        got.append(float(loss.detach()))
+
+    # the oracle's curve: fp32 masters as leaves, the groups of construct_optimizer (optimizer.py:36-60 of the reference:
+    # 1-D parameters and the model's no_weight_decay() names carry no decay)
+    ocfg = dict(depth=3, heads=4, orvit_layers=[1], temporal_resolution=2, patch=(2, 16, 16), crop=64)
+    skip = m.no_weight_decay() if hasattr(m, "no_weight_decay") else set()
+    leaves = {k: v.float().clone().requires_grad_() for k, v in p.items() if k in dict(m.named_parameters())}
+    fixed = {k: v.float() for k, v in p.items() if k not in leaves}
+    no_decay = [k for k in leaves if k in skip or (cfg.SOLVER.ZERO_WD_1D_PARAM and leaves[k].dim() == 1)]
+    ref_opt = torch.optim.AdamW([{"params": [leaves[k] for k in leaves if k not in no_decay], "weight_decay": wd},
+                                 {"params": [leaves[k] for k in no_decay], "weight_decay": 0.0}], lr=lr, eps=1e-8)
+    xr, br, lab = T(a["x"]), T(a["boxes"]), torch.from_numpy(a["labels"])
+    want = []
+    for _ in range(steps):
+        logits = oracle.motionformer_forward({**fixed, **leaves}, xr, br, ocfg, training=True)
+        loss = oracle.label_smoothing_ce(logits, lab)
+        want.append(float(loss.detach()))
+        ref_opt.zero_grad(set_to_none=True)
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(list(leaves.values()), clip)
+        ref_opt.step()
+    assert want[-1] < 0.8 * want[0], want                          # the fixture really trains at this learning rate
+    worst = max(abs(g - w) / abs(w) for g, w in zip(got, want))
+    assert worst < 2e-2, "bf16 loss curve leaves the fp32 oracle's by %.2f %%:\n%s\n%s" % (100 * worst, got, want)
+
+
 def test_trajectory_attention_beyond_one_key_tile(oracle):
     """Frames longer than one 224-key register tile of the fused kernels (the HR 16x336 config has P=441): bf16 runs
     the key-tiled fused kernels, fp32 the generic path; head dim 64 so everything else runs the MFMA kernels."""

@@ -514,4 +514,9 @@ def test_fused_slot_tail_matches_the_unfused_loop(monkeypatch):
     both(dx1, dx0, dxr, 1.5e-1, "d inputs")       # measured: 8.4e-2 fused, 8.6e-2 unfused
     for n in g0:
         assert g1[n] is not None, n
+        if float(gr[n].abs().max()) < 1e-3 * float(g0[n].abs().max()):
+            # exactly zero in exact arithmetic (norm_slots.bias shifts every slot's q alike and the softmax over the slots
+            # does not see it): both bf16 runs hold rounding noise only, of the same size
+            assert float(g1[n].abs().max()) <= 2.0 * float(g0[n].abs().max()) + 1e-12, n
+            continue
         both(g1[n].float(), g0[n].float(), gr[n].float(), 1.5e-1, "grad " + n, floor=1e-2 * float(gr[n].abs().max()) + 1e-12)
