@@ -344,6 +344,10 @@ def bench_job(cfg):
 
     if world == 1 and a.workload in ("steve", "all") and not a.fp32:
         rec = _guard(lambda: bench_steve(a, dev))
+        if a.steve_model_batch > 0 and not a.steve_eager:
+            import torch as _t
+            _t.cuda.empty_cache()
+            rec["model_step"] = _guard(lambda: bench_steve_model(a, dev))
         if out is None:
             out = rec
         else:
@@ -366,6 +370,78 @@ def _guard(fn):
         import traceback
         traceback.print_exc(file=sys.stderr)
         return {"failed": repr(e)}
+
+
+def bench_steve_model(a, dev):
+    """The whole STEVE training step (tools/steve_train_net.py:57-126 through focus_amd.train.slot_train_step) at the
+    BASELINE frame shape, 24 x 128 x 128: dVAE, CNN encoder, the slot update above, and the 8-block transformer decoder over
+    the 1024 image tokens of every frame (causal flash attention, csrc/flash_attn.hip) with the vocabulary-4096 cross
+    entropy; decoder dropout 0.1 as in configs/movi_e/base.yaml.  Also the forward alone (STEVE.forward, eval-mode)."""
+    import torch
+    from focus_amd import ops
+    from focus_amd.slowfast.config.defaults import get_cfg
+    from focus_amd.slowfast.models import MODEL_REGISTRY
+    from focus_amd.slowfast.models.optimizer import construct_optimizer_slot
+    from focus_amd.train import slot_train_step
+    cfg = get_cfg()
+    cfg.MODEL.MODEL_NAME = "STEVE"
+    cfg.NUM_GPUS = 1
+    cfg.TRAIN.MIXED_PRECISION = True
+    cfg.SOLVER.OPTIMIZING_METHOD = "adam"
+    cfg.SOLVER.CLIP_GRAD_L2NORM = 0.05
+    sl = cfg.SLOTS
+    sl.NUM_ITERS, sl.NUM_SLOTS, sl.CNN_HID_SIZE, sl.SIZE, sl.DIM, sl.MLP_HID_SIZE, sl.IMG_SIZE, sl.VOCAB_SIZE = 3, 11, 64, 192, 192, 768, 128, 4096
+    sl.NUM_PREDICTOR_BLOCKS, sl.NUM_PREDICTOR_HEADS, sl.PREDICTOR_DROPOUT = 1, 4, 0.0
+    sl.DECODER.DIM, sl.DECODER.NUM_BLOCKS, sl.DECODER.NUM_HEADS, sl.DECODER.DROPOUT = 192, 8, 4, 0.1
+    B, T = a.steve_model_batch, 24
+    torch.manual_seed(0)
+    m = MODEL_REGISTRY.get("STEVE")(cfg).to(dev)
+    opt = construct_optimizer_slot(m, cfg)
+    video = torch.rand(B, T, 3, 128, 128, device=dev)
+    flash = []
+    real = ops.flash_attention
+    ops.flash_attention = lambda *x, **k: (flash.append(1), real(*x, **k))[1]
+    try:
+        m.train()
+        step = 0
+        for _ in range(2):
+            loss = slot_train_step(m, opt, video, step, cfg)[0]
+            step += 1
+        torch.cuda.synchronize()
+        calls = len(flash) // 2
+        n = max(2, min(a.steps, 3))
+        t0 = time.perf_counter()
+        for _ in range(n):
+            loss = slot_train_step(m, opt, video, step, cfg)[0]
+            step += 1
+        torch.cuda.synchronize()
+        ms = 1e3 * (time.perf_counter() - t0) / n
+        peak = torch.cuda.max_memory_allocated() / 2 ** 30
+        m.eval()
+        with torch.no_grad():
+            m(video, 1.0, True)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(n):
+                m(video, 1.0, True)
+            torch.cuda.synchronize()
+        fwd_ms = 1e3 * (time.perf_counter() - t0) / n
+    finally:
+        ops.flash_attention = real
+    # the causal self-attention products that reach the matrix pipe: 3 of 4 16-channel steps of q.k, 2 d-blocks of P.v,
+    # half of the 1024 x 1024 square; backward 2.5x the forward (dq, dkv recompute the logits)
+    attn_flops = 8 * B * T * 4 * (1024 * 1024 / 2) * 2 * (48 + 48) * 3.5
+    del m, opt
+    ops.drop_caches()
+    torch.cuda.empty_cache()
+    return {"workload": "STEVE training step, movi_e 24x128x128, 11 slots, 3 iterations, decoder 8 blocks x 4 heads x 48, "
+                        "vocabulary 4096, dropout 0.1, batch=%d, bf16 token path (configs/movi_e/base.yaml at IMG_SIZE 128)" % B,
+            "ms_per_step": round(ms, 2), "clips_per_s": round(B / (ms * 1e-3), 2), "forward_ms": round(fwd_ms, 2),
+            "steps": n, "final_loss": round(float(loss.detach()), 4), "peak_memory_GiB": round(peak, 1),
+            "flash_attention_calls_per_step": calls,
+            "decoder_attention": "csrc/flash_attn.hip: no [1024, 1024] probabilities or dropout masks in memory "
+                                 "(the materialised form is 6.4 GB per block and direction at batch 32)",
+            "decoder_attention_algorithmic_tflop_per_step": round(attn_flops / 1e12, 2)}
 
 
 def bench_steve(a, dev):
@@ -571,6 +647,8 @@ def main(argv=None, job=None):
     ap.add_argument("--gemm-shapes", action="store_true", help="print per-shape GEMM timings to stderr")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--steve-eager", action="store_true", help="time the STEVE sub-record eagerly (no HIP graph)")
+    ap.add_argument("--steve-model-batch", type=int, default=16,
+                    help="clips of the whole-model STEVE training-step record at 24x128x128 (0: skip)")
     ap.add_argument("--backend", default="nccl", help="process-group backend (nccl = RCCL; gloo for a rehearsal)")
     ap.add_argument("--bf16-grads", action="store_true", help="cfg.DDP_BF16_GRADS: bf16 gradient buckets on the wire")
     ap.add_argument("--same-device", action="store_true",

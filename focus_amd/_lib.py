@@ -44,6 +44,14 @@ class SlotTailArgs(ctypes.Structure):
                                                 "rstd2", "q")])
 
 
+class FlashArgs(ctypes.Structure):
+    _fields_ = ([(n, ctypes.c_void_p) for n in ("q", "k", "v", "out", "lse", "dout", "delta", "dq", "dk", "dv", "seed")] +
+                [(n, ctypes.c_int64) for n in ("ldq", "ldk", "ldv", "ldo", "lddo", "lddq", "lddk", "lddv",
+                                               "bsq", "bsk", "bsv", "bso", "bsdo", "bsdq", "bsdk", "bsdv")] +
+                [(n, ctypes.c_int32) for n in ("B", "heads", "Nq", "Nk", "d", "dtype", "causal")] +
+                [("drop_thr", ctypes.c_uint32), ("scale", ctypes.c_float), ("pad_", ctypes.c_int32)])
+
+
 _CTYPE = {"int": ctypes.c_int, "int32_t": ctypes.c_int32, "int64_t": ctypes.c_int64,
           "size_t": ctypes.c_size_t, "float": ctypes.c_float, "double": ctypes.c_double}
 

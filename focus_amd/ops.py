@@ -1528,6 +1528,92 @@ class _SmallAttnFn(torch.autograd.Function):
         return dq, dk, dv, None, None, None, None
 
 
+# --------------------------------------------------------------------------------------------------
+# Flash attention (STEVE decoder: causal self-attention over the image tokens, transformer.py:23-49, :131-151)
+# --------------------------------------------------------------------------------------------------
+def flash_ok(q, k, v, heads, causal):
+    """bf16 [B, n, C] row views (dense or column blocks of one projection output) with head dim 32 / 48 / 64."""
+    if not (q.is_cuda and q.dtype == torch.bfloat16 and k.dtype == q.dtype and v.dtype == q.dtype and q.dim() == 3):
+        return False
+    C = q.shape[2]
+    if C % heads:
+        return False
+    for t in (q, k, v):
+        if t.stride(2) != 1 or t.stride(1) % 8 or t.stride(0) % 8 or t.data_ptr() % 16:
+            return False
+    return bool(_lib.lib().focus_flash_attn_ok(q.shape[1], k.shape[1], C // heads, _lib.BF16, int(bool(causal))))
+
+
+def drop_threshold(p):
+    """The 16-bit threshold the kernels compare against: p is quantised to thr / 65536 (0.1 -> 6554)."""
+    thr = int(round(float(p) * 65536.0))
+    assert 0 <= thr < 65536, "dropout probability out of range"
+    return thr
+
+
+def _flash_args(q, k, v, out, lse, heads, scale, causal, thr, seed):
+    B, Nq, C = q.shape
+    a = _lib.FlashArgs()
+    a.q, a.k, a.v, a.out, a.lse = _p(q), _p(k), _p(v), _p(out), _p(lse)
+    a.seed = _p(seed) if seed is not None else None
+    a.ldq, a.ldk, a.ldv, a.ldo = q.stride(1), k.stride(1), v.stride(1), out.stride(1)
+    a.bsq, a.bsk, a.bsv, a.bso = q.stride(0), k.stride(0), v.stride(0), out.stride(0)
+    a.B, a.heads, a.Nq, a.Nk, a.d, a.dtype, a.causal = B, heads, Nq, k.shape[1], C // heads, _lib.BF16, int(bool(causal))
+    a.drop_thr, a.scale = thr, scale
+    return a
+
+
+class _FlashAttnFn(torch.autograd.Function):
+    """out = dropout(softmax(scale q k^T [+ causal mask])) v per head, nothing of size Nq x Nk in memory
+    (csrc/flash_attn.hip).  `seed`: int32 [1] device tensor naming the dropout draw (None: no dropout)."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, heads, scale, causal, thr, seed):
+        _need_gpu(q, k, v)
+        B, Nq, C = q.shape
+        out = torch.empty(B, Nq, C, device=q.device, dtype=q.dtype)
+        lse = torch.empty(B, heads, Nq, device=q.device, dtype=torch.float32)
+        a = _flash_args(q, k, v, out, lse, heads, scale, causal, thr, seed)
+        _lib.check(_lib.lib().focus_flash_attn_fwd(ctypes.byref(a), _stream()), "flash_attn_fwd")
+        ctx.save_for_backward(q, k, v, out, lse, seed)
+        ctx.cfg = (heads, scale, causal, thr)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        q, k, v, out, lse, seed = ctx.saved_tensors
+        heads, scale, causal, thr = ctx.cfg
+        B, Nq, C = q.shape
+        Nk = k.shape[1]
+        dout = dout.contiguous()
+        es = q.element_size()
+        if (Nq == Nk and q.stride(1) == 3 * C == k.stride(1) == v.stride(1) and k.data_ptr() == q.data_ptr() + C * es
+                and v.data_ptr() == k.data_ptr() + C * es):
+            # q | k | v are the column blocks of one projection output (ops.linear_qkv): so are their gradients
+            dqkv = torch.empty(B, Nq, 3 * C, device=q.device, dtype=q.dtype)
+            dq, dk, dv = dqkv[..., :C], dqkv[..., C:2 * C], dqkv[..., 2 * C:]
+        else:
+            dq = torch.empty(B, Nq, C, device=q.device, dtype=q.dtype)
+            dk = torch.empty(B, Nk, C, device=q.device, dtype=q.dtype)
+            dv = torch.empty(B, Nk, C, device=q.device, dtype=q.dtype)
+        delta = torch.empty(B, heads, Nq, device=q.device, dtype=torch.float32)
+        a = _flash_args(q, k, v, out, lse, heads, scale, causal, thr, seed)
+        a.dout, a.delta, a.dq, a.dk, a.dv = _p(dout), _p(delta), _p(dq), _p(dk), _p(dv)
+        a.lddo, a.lddq, a.lddk, a.lddv = dout.stride(1), dq.stride(1), dk.stride(1), dv.stride(1)
+        a.bsdo, a.bsdq, a.bsdk, a.bsdv = dout.stride(0), dq.stride(0), dk.stride(0), dv.stride(0)
+        _lib.check(_lib.lib().focus_flash_attn_bwd(ctypes.byref(a), _stream()), "flash_attn_bwd")
+        return dq, dk, dv, None, None, None, None, None
+
+
+def flash_attention(q, k, v, heads, scale, causal=False, p=0.0, seed=None):
+    """Attention over [B, n, C] rows without materialised probabilities.  p > 0: dropout on the probabilities
+    (transformer.py:44-45) drawn from `seed` (int32 [1] on the device; a fresh one from torch's generator when None)."""
+    thr = drop_threshold(p) if p > 0.0 else 0
+    if thr and seed is None:
+        seed = torch.randint(0, 2 ** 31 - 1, (1,), device=q.device, dtype=torch.int32)
+    return _FlashAttnFn.apply(q, k, v, heads, scale, causal, thr, seed if thr else None)
+
+
 def small_attention(q, k, v, heads, scale, causal=False, drop=None):
     return _SmallAttnFn.apply(q, k, v, heads, scale, causal, drop)
 

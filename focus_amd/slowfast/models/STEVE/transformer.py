@@ -33,20 +33,27 @@ class MultiHeadAttention(nn.Module):
         causal = attn_mask is not None
         if causal:
             assert attn_mask.shape == (T, S) and T == S, "only the decoder's causal mask is supported"
-        if q is k and k is v and not causal and T <= 16 and q.dtype == torch.bfloat16 and self.d_model % 64 == 0:
-            # self-attention over the slots (the predictor): the three projections are the column blocks of one product,
-            # which ops.small_attention's one-launch kernels read in place
+        d = self.d_model // self.num_heads
+        p = self.attn_dropout.p if self.training else 0.0
+        bf16 = q.dtype == torch.bfloat16
+        if q is k and k is v and bf16 and ((not causal and T <= 16 and self.d_model % 64 == 0) or d in (32, 48, 64)):
+            # self-attention: the three projections are the column blocks of one product, which ops.small_attention's
+            # one-launch kernels (the predictor over the slots) and ops.flash_attention (the decoder over the image tokens)
+            # read in place
             Q, Kt, V = ops.linear_qkv(q, self.proj_q.weight, self.proj_k.weight, self.proj_v.weight)
         else:
             Q = ops.linear(q, self.proj_q.weight)
             Kt = ops.linear(k, self.proj_k.weight)
             V = ops.linear(v, self.proj_v.weight)
-        d = self.d_model // self.num_heads
-        p = self.attn_dropout.p
-        drop = None
-        if self.training and p > 0.0:
-            drop = F.dropout(torch.ones(B, self.num_heads, T, S, device=q.device, dtype=q.dtype), p, True)
-        a = ops.small_attention(Q, Kt, V, self.num_heads, d ** -0.5, causal=causal, drop=drop)
+        if (causal or T > 16) and ops.flash_ok(Q, Kt, V, self.num_heads, causal):
+            # the decoder (causal over 1024 tokens; cross-attention from them to the slots): no [T, S] probabilities and no
+            # dropout mask in memory, the mask is a function of a seed drawn from torch's generator (csrc/flash_attn.hip)
+            a = ops.flash_attention(Q, Kt, V, self.num_heads, d ** -0.5, causal=causal, p=p)
+        else:
+            drop = None
+            if p > 0.0:
+                drop = F.dropout(torch.ones(B, self.num_heads, T, S, device=q.device, dtype=q.dtype), p, True)
+            a = ops.small_attention(Q, Kt, V, self.num_heads, d ** -0.5, causal=causal, drop=drop)
         if self.training and self.output_dropout.p > 0.0:
             out = self.output_dropout(ops.linear(a, self.proj_o.weight))
             return out if residual is None else residual + out

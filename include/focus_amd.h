@@ -432,6 +432,31 @@ typedef struct focus_slot_tail_args {
 int focus_slot_tail_ok(int D, int H, int dtype);
 int focus_slot_tail_fwd(const focus_slot_tail_args* args, void* stream);
 
+/* Multi-head attention without the [Nq, Nk] probabilities in memory (flash_attn.hip) -- the STEVE decoder's causal
+ * self-attention over the image tokens of a frame: STEVE/transformer.py:23-49 (MultiHeadAttention.forward: scale, mask,
+ * softmax, dropout on the probabilities, product with v) with the upper-triangular mask of :131-132 / :149-151, and its autograd.
+ *   out[b, n, h*d:(h+1)*d] = dropout(softmax_k(scale * q.k + causal mask)) v        lse[b, h, n] = log sum_k exp(scale * q.k)
+ * q / k / v / out / dout / dq / dk / dv: bf16 rows of `heads * d` channels, row strides ld*, batch strides bs* (elements; the
+ * three inputs may be column blocks of one projection output).  d in {32, 48, 64}; causal needs Nq == Nk.
+ * drop_thr = round(p * 65536) (0: no dropout): element (b*heads + h, query, key) is kept iff the 16-bit half (key & 1) of
+ * lowbias32(seed[0] ^ (bh * 0x9E3779B1) ^ (query * 0x85EBCA77) ^ ((key >> 1) * 0xC2B2AE3D)) is >= drop_thr, kept values are
+ * scaled by 65536 / (65536 - drop_thr); `seed` is read on the device, so a draw can be captured in a graph.
+ * bwd: delta [B, heads, Nq] fp32 is scratch (written by the dQ kernel, read by the dK/dV kernel); dq, dk, dv fully written. */
+typedef struct focus_flash_args {
+    const void* q; const void* k; const void* v; void* out; float* lse;
+    const void* dout; float* delta; void* dq; void* dk; void* dv;
+    const uint32_t* seed;
+    int64_t ldq, ldk, ldv, ldo, lddo, lddq, lddk, lddv;
+    int64_t bsq, bsk, bsv, bso, bsdo, bsdq, bsdk, bsdv;
+    int32_t B, heads, Nq, Nk, d, dtype, causal;
+    uint32_t drop_thr;
+    float scale;
+    int32_t pad_;
+} focus_flash_args;
+int focus_flash_attn_ok(int Nq, int Nk, int d, int dtype, int causal);
+int focus_flash_attn_fwd(const focus_flash_args* args, void* stream);
+int focus_flash_attn_bwd(const focus_flash_args* args, void* stream);
+
 /* Both consumers of g = d(loss)/d(u) of the re-associated temporal step in one pass over g (traj_time2_gw.hip; autograd of
  * attention.py:536-549): dq2[r, h*d+dd] = sum_c g[h,r,c] Wk[h*d+dd, c] and dWk[h*d+dd, c] = sum_r q2[r, h*d+dd] g[h,r,c].
  * g [heads][R][C] bf16, q2 / dq2 [R][C] bf16, wk = the bf16 rows of Wk (row stride wk_ld), dwk [C][C] fp32 dense.

@@ -520,3 +520,44 @@ def test_fused_slot_tail_matches_the_unfused_loop(monkeypatch):
             assert float(g1[n].abs().max()) <= 2.0 * float(g0[n].abs().max()) + 1e-12, n
             continue
         both(g1[n].float(), g0[n].float(), gr[n].float(), 1.5e-1, "grad " + n, floor=1e-2 * float(gr[n].abs().max()) + 1e-12)
+
+
+def test_decoder_at_full_width_runs_flash_attention_and_matches_the_oracle(oracle, monkeypatch):
+    """TransformerDecoder at the width of the BASELINE shape (d_model 192, 4 heads of 48, STEVE/transformer.py:117-193) in
+    bf16: the causal self-attention and the cross-attention to the slots both take ops.flash_attention (no [T, S]
+    probabilities in memory); output, input gradients and parameter gradients against oracle.transformer_decoder in fp32 on
+    the CPU (the oracle's decoder is pinned by the reference's steve_forward_small fixture at d_model 32)."""
+    from focus_amd import ops
+    from focus_amd.slowfast.models.STEVE.transformer import TransformerDecoder
+    d = dev()
+    B, T, K, D, H, NB = 3, 320, 11, 192, 4, 2
+    torch.manual_seed(3)
+    m = TransformerDecoder(NB, T, D, H, dropout=0.0).to(d)
+    g = torch.Generator().manual_seed(4)
+    x0 = torch.randn(B, T, D, generator=g)
+    e0 = torch.randn(B, K, D, generator=g)
+    cu = torch.randn(B, T, D, generator=g)
+    calls = []
+    real = ops.flash_attention
+    monkeypatch.setattr(ops, "flash_attention", lambda *a, **k: (calls.append(a[0].shape), real(*a, **k))[1])
+    x = x0.bfloat16().to(d).requires_grad_()
+    e = e0.bfloat16().to(d).requires_grad_()
+    y = m(x, e)
+    (y.float() * cu.to(d)).sum().backward()
+    assert len(calls) == 2 * NB, calls                                 # self- and cross-attention of every block
+    p = {"tf." + k: v.detach().float().cpu() for k, v in m.state_dict().items() if v.dtype.is_floating_point}
+    leaves = {k: v.clone().requires_grad_() for k, v in p.items()}
+    xr = x0.bfloat16().float().requires_grad_()
+    er = e0.bfloat16().float().requires_grad_()
+    yr = oracle.transformer_decoder(leaves, "tf", xr, er, H, NB)
+    (yr * cu).sum().backward()
+    close(y, yr, 3e-2, "decoder output")
+    close(x.grad, xr.grad, 5e-2, "d input")
+    close(e.grad, er.grad, 5e-2, "d slots")
+    named = dict(m.named_parameters())
+    for k, v in leaves.items():
+        n = k[3:]
+        if n in named and v.grad is not None:
+            # (LayerNorm gains and shifts: sums of 960 signed bf16-rounded products that largely cancel)
+            close(named[n].grad, v.grad, 1e-1 if "layer_norm" in n else 6e-2, "grad " + n,
+                  floor=1e-2 * float(v.grad.abs().max()) + 1e-12)
