@@ -420,7 +420,7 @@ __global__ __launch_bounds__(256, 2) void flash_dq_kernel(const focus_flash_args
 constexpr int QC = 32;
 
 template <int D>
-__global__ __launch_bounds__(256) void flash_dkv_kernel(const focus_flash_args a) {
+__global__ __launch_bounds__(256, 2) void flash_dkv_kernel(const focus_flash_args a) {
     constexpr int KS = D / 16, CH = D / 8, NW = 4;
     __shared__ __attribute__((aligned(1024))) char ring[4 * 8192 + 4 * 256];   // 4 x (Q | dO), then 4 x (lse | delta)
 
