@@ -140,6 +140,13 @@ def _defaults():
                             WEIGHT_DECAY=1e-4, WARMUP_FACTOR=0.1, WARMUP_EPOCHS=0.0, WARMUP_START_LR=0.01,
                             OPTIMIZING_METHOD="sgd", BASE_LR_SCALE_NUM_SHARDS=False, COSINE_AFTER_WARMUP=False,
                             ZERO_WD_1D_PARAM=False, CLIP_GRAD_VAL=None, CLIP_GRAD_L2NORM=0.05))
+    # MViT backbone (defaults.py:415-499 of the reference) for the MViT+ORViT variant
+    C.MVIT = CfgNode(dict(MODE="conv", POOL_FIRST=False, CLS_EMBED_ON=True, PATCH_KERNEL=[3, 7, 7], PATCH_STRIDE=[2, 4, 4],
+                          PATCH_PADDING=[2, 4, 4], PATCH_2D=False, EMBED_DIM=96, NUM_HEADS=1, MLP_RATIO=4.0, QKV_BIAS=True,
+                          DROPPATH_RATE=0.1, DEPTH=16, NORM="layernorm", DIM_MUL=[], HEAD_MUL=[], POOL_KV_STRIDE=None,
+                          POOL_KV_STRIDE_ADAPTIVE=None, POOL_Q_STRIDE=[], POOL_KVQ_KERNEL=None, ZERO_DECAY_POS_CLS=True,
+                          NORM_STEM=False, SEP_POS_EMBED=False, DROPOUT_RATE=0.0, POOL_KV_IGNORE_111_KERNEL=False))
+    C.DETECTION = CfgNode(dict(ENABLE=False))
     C.DATA_LOADER = CfgNode(dict(NUM_WORKERS=8, PIN_MEMORY=True, ENABLE_MULTI_THREAD_DECODE=False))
     C.TENSORBOARD = CfgNode(dict(ENABLE=True))
     C.NUM_GPUS = 1

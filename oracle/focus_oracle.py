@@ -368,6 +368,124 @@ def motionformer_forward(p, x, boxes, cfg, training=True):
     return logits if training else torch.softmax(logits, dim=-1)
 
 
+# ----------------------------------------------------------------------------------------------
+# MViT with ORViT blocks (video_model_builder.py:765-1101, attention.py:16-352, utils.py:31-44, head_helper.py:363-419)
+# ----------------------------------------------------------------------------------------------
+def round_width(width, multiplier, min_width=1, divisor=1):
+    """slowfast/models/utils.py:31-44."""
+    if not multiplier:
+        return width
+    width *= multiplier
+    min_width = min_width or divisor
+    out = max(min_width, int(width + divisor / 2) // divisor * divisor)
+    if out < 0.9 * width:
+        out += divisor
+    return int(out)
+
+
+def mvit_plan(cfg):
+    """The per-layer (dim, dim_out, heads, kernel_q, stride_q, kernel_kv, stride_kv) of MViT.__init__ (:857-913).  cfg: dict
+    with embed_dim, heads, depth, dim_mul, head_mul ([[layer, factor], ...]), pool_q_stride ([[layer, t, h, w], ...]),
+    pool_kvq_kernel, pool_kv_stride_adaptive."""
+    depth = cfg["depth"]
+    dim_mul, head_mul = [1.0] * (depth + 1), [1.0] * (depth + 1)
+    for i, m in cfg["dim_mul"]:
+        dim_mul[i] = m
+    for i, m in cfg["head_mul"]:
+        head_mul[i] = m
+    stride_q = [[] for _ in range(depth)]
+    for e in cfg["pool_q_stride"]:
+        stride_q[e[0]] = list(e[1:])
+    kern = list(cfg["pool_kvq_kernel"])
+    stride_kv, skv = [], list(cfg["pool_kv_stride_adaptive"])
+    for i in range(depth):                                                # :877-888
+        if stride_q[i]:
+            skv = [max(skv[d] // stride_q[i][d], 1) for d in range(3)]
+        stride_kv.append(list(skv))
+    plan, dim, heads = [], cfg["embed_dim"], cfg["heads"]
+    for i in range(depth):
+        heads = round_width(heads, head_mul[i])
+        dim = round_width(dim, dim_mul[i], divisor=heads)
+        dim_out = round_width(dim, dim_mul[i + 1], divisor=round_width(heads, head_mul[i + 1]))
+        plan.append(dict(dim=dim, dim_out=dim_out, heads=heads, kernel_q=kern if stride_q[i] else [], stride_q=stride_q[i],
+                         kernel_kv=kern, stride_kv=stride_kv[i]))
+    return plan
+
+
+def _pool_tokens(t, thw, pool, has_cls=True):
+    """attention_pool (attention.py:16-50) around `pool`: a function of the [B*heads, C, T, H, W] grid."""
+    cls, t = (t[:, :, :1], t[:, :, 1:]) if has_cls else (None, t)
+    B, N, L, C = t.shape
+    T, H, W = thw
+    g = pool(t.reshape(B * N, T, H, W, C).permute(0, 4, 1, 2, 3))
+    thw2 = [g.shape[2], g.shape[3], g.shape[4]]
+    t = g.reshape(B, N, C, -1).transpose(2, 3)
+    if has_cls:
+        t = torch.cat([cls, t], dim=2)
+    return t, thw2
+
+
+def multiscale_block(p, name, x, thw, lay, eps=1e-6):
+    """MultiScaleBlock.forward (attention.py:343-352) with MultiScaleAttention.forward (:158-258), mode 'conv', pooling after
+    the projections."""
+    B, N, C = x.shape
+    h = lay["heads"]
+    y = layer_norm(p, name + ".norm1", x, eps)
+    qkv = {}
+    for n in "qkv":
+        qkv[n] = split_heads(linear(p, name + ".attn." + n, y), h)        # [B,h,N,d]
+    shapes = {}
+    for n, kernel, stride in (("q", lay["kernel_q"], lay["stride_q"]), ("k", lay["kernel_kv"], lay["stride_kv"]),
+                              ("v", lay["kernel_kv"], lay["stride_kv"])):
+        shapes[n] = thw
+        if len(kernel) > 0 and not (all(a == 1 for a in kernel) and all(a == 1 for a in stride)):
+            w = p[name + ".attn.pool_%s.weight" % n]
+            pad = [a // 2 for a in kernel]
+            t, shapes[n] = _pool_tokens(qkv[n], thw, lambda g_: F.conv3d(g_, w, None, stride, pad, 1, w.shape[0]))
+            qkv[n] = layer_norm(p, name + ".attn.norm_" + n, t, 1e-5)     # nn.LayerNorm default eps (attention.py:293)
+    d = C // h
+    att = torch.softmax((qkv["q"] @ qkv["k"].transpose(-1, -2)) * d ** -0.5, dim=-1)
+    a = linear(p, name + ".attn.proj", merge_heads(att @ qkv["v"]))
+    sq = lay["stride_q"]
+    if len(sq) > 0:                                                       # pool_skip: MaxPool3d (:333-340)
+        ks = [s_ + 1 if s_ > 1 else s_ for s_ in sq]
+        res, _ = _pool_tokens(x.unsqueeze(1), thw, lambda g_: F.max_pool3d(g_, ks, sq, [k_ // 2 for k_ in ks]))
+        res = res.squeeze(1)
+    else:
+        res = x
+    x = res + a
+    xn = layer_norm(p, name + ".norm2", x, eps)
+    m = mlp(p, name + ".mlp", xn)
+    if lay["dim"] != lay["dim_out"]:
+        x = linear(p, name + ".proj", xn)
+    return x + m, shapes["q"]
+
+
+def mvit_forward(p, x, boxes, cfg, training=True):
+    """MViT.forward (video_model_builder.py:1043-1101): conv stem, cls token, separate position embeddings, the blocks with
+    ORViT in place of (orvit_layers) or beside (orvit_add_layers) a MultiScaleBlock, norm, cls row, TransformerBasicHead.
+    cfg: mvit_plan's keys + patch_kernel / patch_stride / patch_padding, crop, frames, orvit_layers, orvit_add_layers."""
+    y = F.conv3d(x, p["patch_embed.proj.weight"], p["patch_embed.proj.bias"], cfg["patch_stride"], cfg["patch_padding"])
+    tok = y.flatten(2).transpose(1, 2)
+    B = tok.shape[0]
+    dims = [cfg["frames"] // cfg["patch_stride"][0], cfg["crop"] // cfg["patch_stride"][1], cfg["crop"] // cfg["patch_stride"][2]]
+    pos = p["pos_embed_spatial"].repeat(1, dims[0], 1) + torch.repeat_interleave(p["pos_embed_temporal"], dims[1] * dims[2], dim=1)
+    pos = torch.cat([p["pos_embed_class"], pos], 1)
+    xx = torch.cat([p["cls_token"].expand(B, -1, -1), tok], dim=1) + pos
+    thw = dims
+    for i, lay in enumerate(mvit_plan(cfg)):
+        prev, thw_prev = xx, thw
+        if i in cfg["orvit_layers"]:
+            xx = orvit_block(p, "blocks.%d" % i, prev, boxes, thw_prev, lay["heads"], cfg["crop"])
+        else:
+            xx, thw = multiscale_block(p, "blocks.%d" % i, prev, thw_prev, lay)
+        if i in cfg["orvit_add_layers"]:
+            xx = xx + orvit_block(p, "orvit_blocks.%d" % i, prev, boxes, thw_prev, lay["heads"], cfg["crop"])
+    feat = layer_norm(p, "norm", xx, 1e-6)[:, 0]
+    logits = linear(p, "head.projection", feat)
+    return logits if training else torch.softmax(logits, dim=1)
+
+
 def label_smoothing_ce(logits, target, smoothing=0.1):
     """losses.py:53-59."""
     lp = torch.log_softmax(logits, dim=-1)

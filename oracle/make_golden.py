@@ -486,6 +486,60 @@ def main_ckpt():
     print("wrote ckpt_small.pyth, ckpt_small_pretrained.pyth, ckpt_small_expected.npz")
 
 
+def main_mvit():
+    """MViT with ORViT blocks (video_model_builder.py:765-1101) at a reduced size: the reference's own MViT, MultiScaleBlock /
+    MultiScaleAttention (attention.py:16-352), round_width (utils.py:31-44, the real function: its module's two config-file
+    imports get empty stand-ins) and ORViT, one ORViT in place of a block and one beside a block."""
+    torch.set_grad_enabled(True)
+    mods = load_reference(_roi_align_tv)
+    load_motionformer(mods)
+    import sys as _sys
+    from oracle._ref_loader import _load, _ns
+    ed = _ns("easydict")
+    ed.EasyDict = dict
+    real_utils = _load("slowfast.models.utils", "slowfast/models/utils.py")
+    vmb = mods["video_model_builder"]
+    vmb.round_width = real_utils.round_width
+    misc = _ns("slowfast.utils.misc")
+    misc.get_num_classes = lambda cfg: cfg.MODEL.NUM_CLASSES          # misc.py:417-421, non-EPIC branch
+    _sys.modules["slowfast.utils"].misc = misc
+    # As shipped the reference's MViT cannot be constructed: MultiScaleBlock passes drop_rate= to common.Mlp, whose keyword
+    # is drop= (attention.py:321-327 vs common.py:8-15: TypeError).  The keyword is mapped here; the arithmetic is the file's.
+    att = mods["attention"]
+    real_mlp = att.Mlp
+    att.Mlp = lambda *a, **k: real_mlp(*a, **{('drop' if n == 'drop_rate' else n): v for n, v in k.items()})
+    g = torch.Generator().manual_seed(20263)
+    cfg = small_cfg(crop=64, O=3, T=2)
+    cfg.DATA.TEST_CROP_SIZE = 64
+    cfg.DATA.INPUT_CHANNEL_NUM = [3]
+    cfg.ORVIT.LAYERS, cfg.ORVIT.ADD_LAYERS = [3], [2]
+    cfg.DETECTION = ns(ENABLE=False)
+    cfg.MODEL.DROPOUT_RATE, cfg.MODEL.HEAD_ACT = 0.0, "softmax"
+    cfg.MVIT = ns(MODE="conv", POOL_FIRST=False, CLS_EMBED_ON=True, PATCH_KERNEL=[3, 7, 7], PATCH_STRIDE=[2, 4, 4],
+                  PATCH_PADDING=[1, 3, 3], PATCH_2D=False, EMBED_DIM=32, NUM_HEADS=2, MLP_RATIO=4.0, QKV_BIAS=True,
+                  DROPPATH_RATE=0.0, DEPTH=4, NORM="layernorm", DIM_MUL=[[1, 2.0]], HEAD_MUL=[[1, 2.0]], POOL_KV_STRIDE=None,
+                  POOL_KV_STRIDE_ADAPTIVE=[1, 4, 4], POOL_Q_STRIDE=[[1, 1, 2, 2]], POOL_KVQ_KERNEL=[3, 3, 3],
+                  ZERO_DECAY_POS_CLS=False, NORM_STEM=False, SEP_POS_EMBED=True, DROPOUT_RATE=0.0,
+                  POOL_KV_IGNORE_111_KERNEL=False)
+    torch.manual_seed(0)
+    m = vmb.MViT(cfg)
+    randomize(m, g, std=0.1)
+    m.train()
+    x = torch.randn(2, 3, 4, 64, 64, generator=g).half().float()
+    boxes = make_boxes(g, 2, 4, 3)
+    ct = torch.randn(2, 10, generator=g)
+    y = m([x], {"orvit_bboxes": boxes.clone()})
+    (y * ct).sum().backward()
+    keys = ["patch_embed.proj.weight", "pos_embed_spatial", "pos_embed_temporal", "cls_token", "blocks.0.attn.q.weight",
+            "blocks.0.attn.pool_k.weight", "blocks.0.attn.norm_k.weight", "blocks.0.proj.weight", "blocks.1.attn.pool_q.weight",
+            "blocks.1.attn.norm_q.bias", "blocks.1.mlp.fc1.weight", "blocks.2.attn.v.bias", "orvit_blocks.2.attn.qkv.weight",
+            "orvit_blocks.2.box_categories", "blocks.3.attn.proj_kv.weight", "blocks.3.patch_to_d.0.weight",
+            "head.projection.weight"]
+    np.savez(os.path.join(OUT, "mvit_orvit_small.npz"), x=x.numpy().astype(np.float16), boxes=boxes.numpy(), ct=ct.numpy(),
+             y=y.detach().numpy(), **pack("p.", m.state_dict()), **grads_of(m, keys))
+    print("wrote mvit_orvit_small.npz", tuple(y.shape))
+
+
 def _load_losses():
     """The reference's own slowfast/models/losses.py (plain torch + the stubbed logger)."""
     from oracle._ref_loader import _load
@@ -501,6 +555,9 @@ def mods_loss(logits, labels):
 
 
 if __name__ == "__main__":
+    if "--mvit-only" in sys.argv:
+        main_mvit()
+        sys.exit(0)
     if "--ckpt-only" in sys.argv:
         main_ckpt()
     elif "--metrics-only" in sys.argv:

@@ -188,3 +188,22 @@ def test_steve_state_dict_keys_match_the_reference():
     assert sorted(sd.keys()) == [str(k) for k in a["state_keys"]]
     for k, v in p.items():
         assert tuple(sd[k].shape) == tuple(v.shape), k
+
+
+MVIT_SMALL = dict(embed_dim=32, heads=2, depth=4, dim_mul=[[1, 2.0]], head_mul=[[1, 2.0]], pool_q_stride=[[1, 1, 2, 2]],
+                  pool_kvq_kernel=[3, 3, 3], pool_kv_stride_adaptive=[1, 4, 4], patch_kernel=[3, 7, 7], patch_stride=[2, 4, 4],
+                  patch_padding=[1, 3, 3], crop=64, frames=4, orvit_layers=[3], orvit_add_layers=[2])
+
+
+def test_mvit_with_orvit_blocks(oracle):
+    """oracle.mvit_forward against the reference's own MViT (video_model_builder.py:765-1101) at a reduced size, one ORViT
+    in place of a block and one beside a block (oracle/make_golden.py main_mvit)."""
+    a, p = load_golden("mvit_orvit_small", dtype=torch.float64)
+    p = leafify(p)
+    y = oracle.mvit_forward(p, T(a["x"], torch.float64), T(a["boxes"], torch.float64), MVIT_SMALL, training=True)
+    close(y, a["y"], 2e-5)                                      # the fixture is the reference in fp32
+    (y * T(a["ct"], torch.float64)).sum().backward()
+    check_grads(a, p, 2e-4)
+    plan = oracle.mvit_plan(MVIT_SMALL)
+    assert [(l["dim"], l["dim_out"], l["heads"]) for l in plan] == [(32, 64, 2), (64, 64, 4), (64, 64, 4), (64, 64, 4)]
+    assert oracle.round_width(96, 2.0, divisor=2) == 192 and oracle.round_width(1, 2.0) == 2
