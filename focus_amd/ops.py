@@ -1120,6 +1120,32 @@ def unbind_frames(x):
     return _UnbindFramesFn.apply(x)
 
 
+def _guard_shared(shared, what):
+    """The shared-gradient nodes (FrameGrad, SlotKVGrad) hand autograd ONE gradient from the node whose backward runs last.
+    That needs every node that was counted in forward to run in this backward; a loss on a subset of the frames /
+    iterations (or torch.autograd.grad on an early output) leaves some unreached, and the shared gradient would silently
+    never leave.  The first node of a backward pass therefore queues a check for the end of that pass: nodes still pending
+    then raise instead of dropping d(inputs)."""
+    if getattr(shared, "_guarded", False):
+        return
+    shared._guarded = True
+
+    def check():
+        shared._guarded = False
+        if shared.pending != 0:
+            left = shared.pending
+            shared.pending = 0
+            for n in ("buf", "dk", "dv"):
+                if hasattr(shared, n):
+                    setattr(shared, n, None)
+            if hasattr(shared, "items"):
+                shared.items = []
+            raise RuntimeError("%s: %d of the nodes sharing this gradient were not reached by backward (a loss on a subset "
+                               "of the frames / iterations?); their shared gradient would have been dropped -- give such "
+                               "uses their own %s, or none" % (what, left, type(shared).__name__))
+    torch.autograd.Variable._execution_engine.queue_callback(check)
+
+
 class FrameGrad:
     """Whole-video gradient buffer shared by the per-frame LayerNorm nodes of one video tensor (see layer_norm_frame)."""
 
@@ -1161,6 +1187,7 @@ class _FrameLayerNormFn(torch.autograd.Function):
         video, gamma, mean, rstd = ctx.saved_tensors
         B, T, N, D = video.shape
         rows, t, sh = B * N, ctx.t, ctx.shared
+        _guard_shared(sh, "layer_norm_frame")
         dy = dy.contiguous()
         if sh.buf is None:
             sh.buf = torch.empty_like(video)
@@ -1961,6 +1988,8 @@ class _SlotAttnFn(torch.autograd.Function):
         nb = L.focus_slot_attn_workspace_bytes(B, N, K, D)
         ws = torch.empty(nb, device=k_t.device, dtype=torch.uint8)
         dq = torch.empty_like(q)
+        if acc is not None:
+            _guard_shared(acc, "slot_attn_step")
         if acc is not None and L.focus_slot_kv_grad_ok(K, D, _dt(k_t), acc.total):
             # deferred: this launch writes its (w, dlogits) rows; the frame's last node forms dk, dv for all iterations
             wl = torch.empty(B, N, 32, device=k_t.device, dtype=k_t.dtype)

@@ -561,3 +561,37 @@ def test_decoder_at_full_width_runs_flash_attention_and_matches_the_oracle(oracl
             # (LayerNorm gains and shifts: sums of 960 signed bf16-rounded products that largely cancel)
             close(named[n].grad, v.grad, 1e-1 if "layer_norm" in n else 6e-2, "grad " + n,
                   floor=1e-2 * float(v.grad.abs().max()) + 1e-12)
+
+
+def test_shared_gradient_nodes_refuse_a_loss_on_a_subset_of_their_uses():
+    """FrameGrad / SlotKVGrad hand autograd one gradient from the node that runs last.  A loss that leaves some of the counted
+    nodes out of the backward pass (here: a loss on one of three frames, on one of two iterations) must raise at the end of
+    that pass instead of dropping d(inputs) for the whole video; the complete loss right after still works."""
+    from focus_amd import ops
+    d = dev()
+    B, T, N, D, K = 2, 3, 256, 64, 5
+    g = torch.Generator(device=d).manual_seed(0)
+    video = torch.randn(B, T, N, D, device=d, generator=g).bfloat16().requires_grad_()
+    gamma = torch.ones(D, device=d, requires_grad=True)
+    beta = torch.zeros(D, device=d, requires_grad=True)
+    sh = ops.FrameGrad()
+    ys = [ops.layer_norm_frame(video, t, gamma, beta, 1e-5, sh) for t in range(T)]
+    with pytest.raises(RuntimeError, match="not reached by backward"):
+        ys[1].float().sum().backward()
+    video.grad = None
+    sh = ops.FrameGrad()
+    ys = [ops.layer_norm_frame(video, t, gamma, beta, 1e-5, sh) for t in range(T)]
+    sum(y.float().square().sum() for y in ys).backward()
+    assert video.grad is not None and float(video.grad.float().abs().sum()) > 0
+
+    k = torch.randn(B, N, D, device=d, generator=g).bfloat16().requires_grad_()
+    v = torch.randn(B, N, D, device=d, generator=g).bfloat16().requires_grad_()
+    qs = [torch.randn(B, K, D, device=d, generator=g).bfloat16().requires_grad_() for _ in range(2)]
+    acc = ops.SlotKVGrad()
+    outs = [ops.slot_attn_step(k, v, q, 1e-8, acc) for q in qs]
+    with pytest.raises(RuntimeError, match="not reached by backward"):
+        outs[0][0].float().sum().backward()
+    acc = ops.SlotKVGrad()
+    outs = [ops.slot_attn_step(k, v, q, 1e-8, acc) for q in qs]
+    sum(u.float().sum() + a.float().square().sum() for u, a in outs).backward()
+    assert k.grad is not None and v.grad is not None
