@@ -417,15 +417,17 @@ def bench_steve_model(a, dev):
         torch.cuda.synchronize()
         ms = 1e3 * (time.perf_counter() - t0) / n
         peak = torch.cuda.max_memory_allocated() / 2 ** 30
-        m.eval()
-        with torch.no_grad():
-            m(video, 1.0, True)
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(n):
+        fwd_ms = float("nan")
+        if getattr(a, "steve_model_eval", True):
+            m.eval()
+            with torch.no_grad():
                 m(video, 1.0, True)
-            torch.cuda.synchronize()
-        fwd_ms = 1e3 * (time.perf_counter() - t0) / n
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(n):
+                    m(video, 1.0, True)
+                torch.cuda.synchronize()
+            fwd_ms = 1e3 * (time.perf_counter() - t0) / n
     finally:
         ops.flash_attention = real
     # the causal self-attention products that reach the matrix pipe: 3 of 4 16-channel steps of q.k, 2 d-blocks of P.v,
