@@ -44,6 +44,13 @@ class SlotTailArgs(ctypes.Structure):
                                                 "rstd2", "q")])
 
 
+class SlotTailBwdArgs(ctypes.Structure):
+    _fields_ = ([(n, ctypes.c_int32) for n in ("R", "D", "H", "do_gru", "do_mlp", "do_q")] +
+                [(n, ctypes.c_void_p) for n in ("dout", "dq", "h", "g", "hn", "a", "cur", "mean1", "rstd1", "mean2", "rstd2",
+                                                "ln1_g", "ln2_g", "w_ih_t", "w_hh_t", "w1_t", "w2_t", "wq_t", "dupd", "dh", "ds",
+                                                "dz", "dg", "part1", "part2")])
+
+
 class FlashArgs(ctypes.Structure):
     _fields_ = ([(n, ctypes.c_void_p) for n in ("q", "k", "v", "out", "lse", "dout", "delta", "dq", "dk", "dv", "seed")] +
                 [(n, ctypes.c_int64) for n in ("ldq", "ldk", "ldv", "ldo", "lddo", "lddq", "lddk", "lddv",

@@ -51,9 +51,12 @@ __device__ __forceinline__ Seg seg_at(const focus_slot_tail_args& a, int i) {
     return r;
 }
 
+__device__ __forceinline__ Seg seg_at(const focus_slot_tail_bwd_args& a, int i);     // the backward's stream (below)
+
 // DMA of the next unit of the stream into slot (issued % NSLOT); lane -> 16-byte chunk c = 64 p + lane of the [16][24] chunk
 // grid; the chunk a row keeps at position j of an 8-chunk group is chunk j ^ ((row >> 1) & 7) (conflict-free fragment reads)
-__device__ __forceinline__ void ws_issue(const focus_slot_tail_args& a, WStream& ws, int w, int lane) {
+template <typename Args>
+__device__ __forceinline__ void ws_issue(const Args& a, WStream& ws, int w, int lane) {
     if (ws.issued >= ws.total) return;
     const Seg sg = seg_at(a, ws.is);
     const int nb = w + 4 * ws.it;
@@ -86,8 +89,8 @@ __device__ __forceinline__ void ws_wait(const WStream& ws, int u) {
 }
 
 // one product: consumes this wave's next nt * nkc units; epi(column, first row, acc) per finished block
-template <typename Epi>
-__device__ __forceinline__ void gemm16(const focus_slot_tail_args& a, WStream& ws, int& ucons, const char* ring_ptr, const bf16_t* sAct,
+template <typename Args, typename Epi>
+__device__ __forceinline__ void gemm16(const Args& a, WStream& ws, int& ucons, const char* ring_ptr, const bf16_t* sAct,
                                        int pitch, int nt, int nkc, int w, int lane, Epi epi) {
     const int row = lane & 15, kq = lane >> 4;
     for (int t = 0; t < nt; ++t) {
@@ -267,6 +270,263 @@ __global__ __launch_bounds__(256) void slot_tail_fwd_kernel(const focus_slot_tai
     }
 }
 
+// ---- backward -------------------------------------------------------------------------------------------------
+// The same chain run backwards on the same 16 rows per workgroup, against the TRANSPOSED bf16 weight copies ([in][out]: the
+// dX products are then the same act[16][KIN] . W'[NOUT][KIN]^T form and stream through the same ring):
+//   dsn = dq Wq ; ds = LN_slots'(dsn) + dout ; dz = (ds W2) * (a > 0) ; dy1 = dz W1 ; dhn = LN_mlp'(dy1) + ds ;
+//   GRU gates' -> dgi, dgh [3D] ; dupd = dgi W_ih ; dh = dgh W_hh + z * dhn
+// Every dY a weight gradient needs (ds, dz, dgi, dgh; dq is an input) is written out once: the weight gradients themselves are
+// formed later, stacked over all applications of the loop (ops.deferred_wgrads).  LayerNorm parameter gradients leave as one
+// [2][workgroups][D] partial per LayerNorm.  Stored values round to bf16 exactly where the unfused kernels rounded.
+__device__ __forceinline__ Seg seg_at(const focus_slot_tail_bwd_args& a, int i) {
+    const int D = a.D, H = a.H;
+    // (the index is laundered between the tests: as one chain on one value hipcc turns the five pointers into a table in
+    // scratch memory indexed at run time)
+    int j = __builtin_amdgcn_readfirstlane(i);
+    Seg r = Seg{static_cast<const bf16_t*>(a.wq_t), D, a.do_q ? D / 64 : 0, 1};
+    asm volatile("" : "+s"(j));
+    if (j == 1) r = Seg{static_cast<const bf16_t*>(a.w2_t), D, a.do_mlp ? H / 64 : 0, 1};
+    asm volatile("" : "+s"(j));
+    if (j == 2) r = Seg{static_cast<const bf16_t*>(a.w1_t), H, a.do_mlp ? D / 64 : 0, H / 192};
+    asm volatile("" : "+s"(j));
+    if (j == 3) r = Seg{static_cast<const bf16_t*>(a.w_ih_t), 3 * D, a.do_gru ? D / 64 : 0, 3};
+    asm volatile("" : "+s"(j));
+    if (j == 4) r = Seg{static_cast<const bf16_t*>(a.w_hh_t), 3 * D, a.do_gru ? D / 64 : 0, 3};
+    return r;
+}
+
+// LayerNorm backward of the 16 rows of LDS tiles (16 threads per row): dx = rstd * (dy g - mean(dy g) - xhat mean(dy g xhat))
+// (+ res), written bf16 to sOut and gOut; then the column sums of dy xhat and dy over the rows into partial[0/1][block][D].
+template <int D>
+__device__ __forceinline__ void ln16_bwd(const bf16_t* sDy, const bf16_t* sX, const bf16_t* sRes, bf16_t* sOut, int pitch,
+                                         const float* __restrict__ gamma, const float* sMean, const float* sRstd, bf16_t* gOut,
+                                         float* partial, int nblk, int r0, int R, int tid) {
+    constexpr int PER = D / 16;
+    const int row = tid >> 4, l = tid & 15;
+    const float mean = sMean[row], rstd = sRstd[row];
+    float xh[PER], dg[PER];
+    float c1 = 0.f, c2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        const int c = l + 16 * j;
+        xh[j] = (bf16_to_f32(sX[row * pitch + c]) - mean) * rstd;
+        dg[j] = bf16_to_f32(sDy[row * pitch + c]) * gamma[c];
+        c1 += dg[j];
+        c2 += dg[j] * xh[j];
+    }
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) { c1 += __shfl_xor(c1, o, 64); c2 += __shfl_xor(c2, o, 64); }
+    c1 *= 1.f / D; c2 *= 1.f / D;
+    const bool live = r0 + row < R;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        const int c = l + 16 * j;
+        float v = (dg[j] - c1 - xh[j] * c2) * rstd;
+        if (sRes) v += bf16_to_f32(sRes[row * pitch + c]);
+        const bf16_t o = f32_to_bf16(v);
+        sOut[row * pitch + c] = o;
+        if (live && gOut) gOut[(int64_t)(r0 + row) * D + c] = o;
+    }
+    // parameter-gradient partials: thread c < D sums its column over the 16 rows (rows past R hold dy = 0)
+    if (tid < D) {
+        float sg = 0.f, sb = 0.f;
+#pragma unroll
+        for (int rr = 0; rr < ROWS; ++rr) {
+            const float dy = bf16_to_f32(sDy[rr * pitch + tid]);
+            sg += dy * (bf16_to_f32(sX[rr * pitch + tid]) - sMean[rr]) * sRstd[rr];
+            sb += dy;
+        }
+        partial[(int64_t)blockIdx.x * D + tid] = sg;
+        partial[(int64_t)(nblk + blockIdx.x) * D + tid] = sb;
+    }
+}
+
+__device__ __forceinline__ void load_rows16(bf16_t* sDst, int pitch, const void* gsrc, int D, int r0, int R, int tid) {
+    const bf16_t* G = static_cast<const bf16_t*>(gsrc);
+    for (int i = tid; i < ROWS * (D / 8); i += 256) {
+        const int row = i / (D / 8), c8 = (i % (D / 8)) * 8;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (G && r0 + row < R) v = *reinterpret_cast<const uint4*>(G + (int64_t)(r0 + row) * D + c8);
+        *reinterpret_cast<uint4*>(sDst + row * pitch + c8) = v;
+    }
+}
+
+template <int D, int H>
+__global__ __launch_bounds__(256) void slot_tail_bwd_kernel(const focus_slot_tail_bwd_args a) {
+    constexpr int PD = D + 8, PH = H + 8, G3 = 3 * D, PG = G3 + 8;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    bf16_t* sA0 = reinterpret_cast<bf16_t*>(smem);              // [16][PD]  dq, then dy1, then z * dhn
+    bf16_t* sDs = sA0 + ROWS * PD;                              // [16][PD]  dout -> ds -> dhn
+    bf16_t* sX = sDs + ROWS * PD;                               // [16][PD]  the LayerNorm inputs (slots, then h'), then h
+    bf16_t* sT = sX + ROWS * PD;                                // [16][PD]  dsn
+    bf16_t* sG = sT + ROWS * PD;                                // [2][16][PG] gates / gate gradients | [16][PH] dz
+    float* sStat = reinterpret_cast<float*>(sG + 2 * ROWS * PG);   // [2][16] mean, rstd
+    unsigned char* sMask = reinterpret_cast<unsigned char*>(sStat + 2 * ROWS);   // [16][H/8] bits: a > 0 (the ReLU's derivative)
+    char* sRing = reinterpret_cast<char*>(sMask + ROWS * (H / 8));
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r0 = blockIdx.x * ROWS, R = a.R, nblk = gridDim.x;
+    static_assert(D == 192 && H % 192 == 0 && (H / 16) % 4 == 0, "block counts per wave");
+
+    WStream ws;
+    ws.total = 0;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) ws.total += seg_at(a, i).nt * seg_at(a, i).nkc;
+    ws.is = ws.it = ws.ikc = ws.issued = 0;
+    while (ws.is < 5 && seg_at(a, ws.is).nt == 0) ++ws.is;
+    const char* ring_ptr = sRing + w * (NSLOT * UNIT_BYTES);
+    ws.ring = lds_addr_of(ring_ptr);
+    int ucons = 0;
+#pragma unroll
+    for (int p = 0; p < NSLOT - 1; ++p) ws_issue(a, ws, w, lane);
+
+    auto load_stats = [&](const float* m, const float* r) __attribute__((always_inline)) {
+        if (tid < ROWS) {
+            const bool live = r0 + tid < R;
+            sStat[tid] = live ? m[r0 + tid] : 0.f;
+            sStat[ROWS + tid] = live ? r[r0 + tid] : 0.f;
+        }
+    };
+    load_rows16(sDs, PD, a.dout, D, r0, R, tid);                 // (NULL: zeros)
+    if (a.do_mlp) {
+        // the ReLU mask as bits, read now: a global load inside the products' epilogues would drain the weight ring
+        const bf16_t* A = static_cast<const bf16_t*>(a.a);
+        for (int i = tid; i < ROWS * (H / 8); i += 256) {
+            const int row = i / (H / 8), c8 = (i % (H / 8)) * 8;
+            unsigned m = 0;
+            if (r0 + row < R) {
+                const uint4 v = *reinterpret_cast<const uint4*>(A + (int64_t)(r0 + row) * H + c8);
+                const uint32_t wv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const uint32_t bits = (wv[e >> 1] >> ((e & 1) * 16)) & 0xffffu;
+                    m |= (bits != 0 && !(bits & 0x8000u)) ? (1u << e) : 0u;   // a = relu(..) >= 0: positive <=> non-zero, sign clear
+                }
+            }
+            sMask[i] = (unsigned char)m;
+        }
+    }
+    if (a.do_q) {
+        load_rows16(sA0, PD, a.dq, D, r0, R, tid);
+        load_rows16(sX, PD, a.cur, D, r0, R, tid);
+        load_stats(a.mean2, a.rstd2);
+        __syncthreads();
+        // dsn = dq . Wq
+        gemm16(a, ws, ucons, ring_ptr, sA0, PD, D / 64, 1, w, lane, [&](int col, int rbase, const f32x4& acc) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sT[(rbase + r) * PD + col] = f32_to_bf16(acc[r]);
+        });
+        __syncthreads();
+        ln16_bwd<D>(sT, sX, sDs, sDs, PD, a.ln2_g, sStat, sStat + ROWS, static_cast<bf16_t*>(a.ds), a.part2, nblk, r0, R, tid);
+    } else if (a.ds) {
+        // no query this time: ds = dout (still written: it is the dY of fc2's weight gradient)
+        __syncthreads();
+        bf16_t* DS = static_cast<bf16_t*>(a.ds);
+        for (int i = tid; i < ROWS * D; i += 256) {
+            const int row = i / D, c = i % D;
+            if (r0 + row < R) DS[(int64_t)(r0 + row) * D + c] = sDs[row * PD + c];
+        }
+    }
+    __syncthreads();
+    if (a.do_mlp) {
+        // dz = (ds . W2) * (a > 0)
+        bf16_t* sDz = sG;
+        bf16_t* DZ = static_cast<bf16_t*>(a.dz);
+        gemm16(a, ws, ucons, ring_ptr, sDs, PD, H / 64, 1, w, lane, [&](int col, int rbase, const f32x4& acc) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const bool live = r0 + rbase + r < R;
+                const bool on = (sMask[(rbase + r) * (H / 8) + (col >> 3)] >> (col & 7)) & 1;
+                const bf16_t v = f32_to_bf16(on ? acc[r] : 0.f);
+                sDz[(rbase + r) * PH + col] = v;
+                if (live) DZ[(int64_t)(r0 + rbase + r) * H + col] = v;
+            }
+        });
+        load_rows16(sX, PD, a.hn, D, r0, R, tid);               // (sX is free: LN_slots' is done)
+        load_stats(a.mean1, a.rstd1);
+        __syncthreads();
+        // dy1 = dz . W1
+        gemm16(a, ws, ucons, ring_ptr, sDz, PH, D / 64, H / 192, w, lane, [&](int col, int rbase, const f32x4& acc) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sA0[(rbase + r) * PD + col] = f32_to_bf16(acc[r]);
+        });
+        __syncthreads();
+        ln16_bwd<D>(sA0, sX, sDs, sDs, PD, a.ln1_g, sStat, sStat + ROWS, nullptr, a.part1, nblk, r0, R, tid);
+        __syncthreads();
+    }
+    if (a.do_gru) {
+        // gate gradients from the stored pre-activations (bias included), h and dhn; in place in the padded gate tile
+        const bf16_t* G = static_cast<const bf16_t*>(a.g);
+        for (int i = tid; i < 2 * ROWS * (G3 / 8); i += 256) {
+            const int which = i / (ROWS * (G3 / 8)), rem = i % (ROWS * (G3 / 8));
+            const int row = rem / (G3 / 8), c8 = (rem % (G3 / 8)) * 8;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (r0 + row < R) v = *reinterpret_cast<const uint4*>(G + ((int64_t)which * R + r0 + row) * G3 + c8);
+            *reinterpret_cast<uint4*>(sG + (which * ROWS + row) * PG + c8) = v;
+        }
+        load_rows16(sX, PD, a.h, D, r0, R, tid);
+        __syncthreads();
+        bf16_t* DG = static_cast<bf16_t*>(a.dg);
+        for (int i = tid; i < ROWS * D; i += 256) {
+            const int row = i / D, c = i % D;
+            bf16_t* ga = sG + row * PG;
+            bf16_t* gb = sG + (ROWS + row) * PG;
+            const float hn_ = bf16_to_f32(gb[2 * D + c]);
+            const float rg = sigm_(bf16_to_f32(ga[c]) + bf16_to_f32(gb[c]));
+            const float zg = sigm_(bf16_to_f32(ga[D + c]) + bf16_to_f32(gb[D + c]));
+            const float ng = tanhf(bf16_to_f32(ga[2 * D + c]) + rg * hn_);
+            const float hv = bf16_to_f32(sX[row * PD + c]), gd = bf16_to_f32(sDs[row * PD + c]);
+            const float dn = gd * (1.f - zg), dzg = gd * (hv - ng);
+            const float dpre_n = dn * (1.f - ng * ng);
+            const float dr = dpre_n * hn_;
+            const bf16_t pr = f32_to_bf16(dr * rg * (1.f - rg)), pz = f32_to_bf16(dzg * zg * (1.f - zg));
+            const bf16_t pn = f32_to_bf16(dpre_n), pnr = f32_to_bf16(dpre_n * rg);
+            ga[c] = pr; ga[D + c] = pz; ga[2 * D + c] = pn;
+            gb[c] = pr; gb[D + c] = pz; gb[2 * D + c] = pnr;
+            sA0[row * PD + c] = f32_to_bf16(gd * zg);            // the direct path of dh
+            if (r0 + row < R) {
+                bf16_t* o0 = DG + (int64_t)(r0 + row) * G3;
+                bf16_t* o1 = DG + ((int64_t)R + r0 + row) * G3;
+                o0[c] = pr; o0[D + c] = pz; o0[2 * D + c] = pn;
+                o1[c] = pr; o1[D + c] = pz; o1[2 * D + c] = pnr;
+            }
+        }
+        __syncthreads();
+        bf16_t* DU = static_cast<bf16_t*>(a.dupd);
+        bf16_t* DH = static_cast<bf16_t*>(a.dh);
+        gemm16(a, ws, ucons, ring_ptr, sG, PG, D / 64, 3, w, lane, [&](int col, int rbase, const f32x4& acc) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (r0 + rbase + r < R) DU[(int64_t)(r0 + rbase + r) * D + col] = f32_to_bf16(acc[r]);
+        });
+        gemm16(a, ws, ucons, ring_ptr, sG + ROWS * PG, PG, D / 64, 3, w, lane, [&](int col, int rbase, const f32x4& acc) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (r0 + rbase + r < R)
+                    DH[(int64_t)(r0 + rbase + r) * D + col] = f32_to_bf16(acc[r] + bf16_to_f32(sA0[(rbase + r) * PD + col]));
+        });
+    } else {
+        bf16_t* DH = static_cast<bf16_t*>(a.dh);
+        for (int i = tid; i < ROWS * D; i += 256) {
+            const int row = i / D, c = i % D;
+            if (r0 + row < R) DH[(int64_t)(r0 + row) * D + c] = sDs[row * PD + c];
+        }
+    }
+}
+
+template <int D, int H>
+int launch_tail_bwd(const focus_slot_tail_bwd_args& a, hipStream_t s) {
+    constexpr size_t lds = (size_t)(4 * ROWS * (D + 8) + 2 * ROWS * (3 * D + 8)) * 2 + 2 * ROWS * 4 + ROWS * (H / 8) +
+                           (size_t)4 * NSLOT * UNIT_BYTES;
+    static_assert(2 * ROWS * (3 * D + 8) >= ROWS * (H + 8), "the dz tile reuses the gate tile");
+    static_assert(lds <= 160 * 1024, "LDS");
+    auto k = slot_tail_bwd_kernel<D, H>;
+    static bool once = (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds) == hipSuccess);
+    (void)once;
+    hipLaunchKernelGGL(k, dim3((a.R + ROWS - 1) / ROWS), dim3(256), lds, s, a);
+    FOCUS_CHECK_LAUNCH();
+    return FOCUS_OK;
+}
+
 template <int D, int H>
 int launch_tail_fwd(const focus_slot_tail_args& a, hipStream_t s) {
     constexpr size_t lds = (size_t)(4 * ROWS * (D + 8) + 2 * ROWS * 3 * D) * 2 + (size_t)4 * NSLOT * UNIT_BYTES;
@@ -293,4 +553,19 @@ extern "C" int focus_slot_tail_fwd(const focus_slot_tail_args* args, void* strea
         return FOCUS_ERR_NULL;
     if (a.do_q && (!a.ln2_g || !a.ln2_b || !a.wq || !a.sn || !a.mean2 || !a.rstd2 || !a.q)) return FOCUS_ERR_NULL;
     return launch_tail_fwd<192, 768>(a, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int focus_slot_tail_bwd_blocks(int R) { return (R + ROWS - 1) / ROWS; }
+
+extern "C" int focus_slot_tail_bwd(const focus_slot_tail_bwd_args* args, void* stream) {
+    if (!args) return FOCUS_ERR_NULL;
+    const focus_slot_tail_bwd_args& a = *args;
+    if (a.R <= 0) return FOCUS_OK;
+    if (!focus_slot_tail_ok(a.D, a.H, FOCUS_BF16)) return FOCUS_ERR_SHAPE;
+    if (!a.dh) return FOCUS_ERR_NULL;
+    if (a.do_q && (!a.dq || !a.cur || !a.mean2 || !a.rstd2 || !a.ln2_g || !a.wq_t || !a.ds || !a.part2)) return FOCUS_ERR_NULL;
+    if (a.do_mlp && (!a.do_gru || !a.a || !a.hn || !a.mean1 || !a.rstd1 || !a.ln1_g || !a.w1_t || !a.w2_t || !a.ds || !a.dz || !a.part1))
+        return FOCUS_ERR_NULL;
+    if (a.do_gru && (!a.g || !a.h || !a.w_ih_t || !a.w_hh_t || !a.dg || !a.dupd)) return FOCUS_ERR_NULL;
+    return launch_tail_bwd<192, 768>(a, static_cast<hipStream_t>(stream));
 }

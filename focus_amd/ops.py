@@ -2312,6 +2312,9 @@ class _SlotTailFn(torch.autograd.Function):
                 dg, db = done if done is not None else (None, None)
             return dx, dg, db
 
+        if _SLOT_TAIL_BWD and dt == torch.bfloat16 and bool(L.focus_slot_tail_ok(D, w1.shape[0], _dt(h))) \
+                and (do_gru or (do_q and dq is not None)):
+            return _SlotTailFn._backward_fused(ctx, dout, dq, upd, h, w_ih, w_hh, g1, w1, w2, g2, wq, sv)
         dcur = dout.contiguous() if dout is not None else None
         if do_q and dq is not None:
             dq = dq.contiguous()
@@ -2349,6 +2352,83 @@ class _SlotTailFn(torch.autograd.Function):
         gg = grads.get
         return (dupd, dh, None, None, None, None, None, gg("w_ih"), gg("w_hh"), gg("b_ih"), gg("b_hh"), gg("g1"), gg("be1"), gg("w1"),
                 gg("b1"), gg("w2"), gg("b2"), gg("g2"), gg("be2"), gg("wq"))
+
+
+def _slot_tail_backward_fused(ctx, dout, dq, upd, h, w_ih, w_hh, g1, w1, w2, g2, wq, sv):
+    """The backward of the tail as ONE launch (focus_slot_tail_bwd): dX chain in the kernel, the dY rows of every weight gradient
+    written out and handed to the (deferred) weight-gradient machinery exactly as the composed backward does."""
+    do_gru, do_mlp, do_q = ctx.flags
+    do_q = do_q and dq is not None
+    R, D = h.shape
+    H = w1.shape[0]
+    dev, dt = h.device, h.dtype
+    L = _lib.lib()
+    new = lambda *s_, dtype=dt: torch.empty(*s_, device=dev, dtype=dtype)
+    a = _lib.SlotTailBwdArgs()
+    a.R, a.D, a.H, a.do_gru, a.do_mlp, a.do_q = R, D, H, int(do_gru), int(do_mlp), int(do_q)
+    keep = []
+    if dout is not None:
+        dout = dout.contiguous()
+        a.dout = dout.data_ptr()
+    nblk = L.focus_slot_tail_bwd_blocks(R)
+    ds = dz = dg = dupd = part1 = part2 = None
+    dh = new(R, D)
+    a.dh, a.h = dh.data_ptr(), h.data_ptr()
+    if do_q:
+        dq = dq.contiguous()
+        cur = sv["s"] if do_mlp else (sv["hn"] if do_gru else h)
+        wqt = shadow(wq, dt, transposed=True)
+        part2 = new(2, nblk, D, dtype=torch.float32)
+        keep += [wqt, cur]
+        a.dq, a.cur, a.mean2, a.rstd2, a.ln2_g, a.wq_t, a.part2 = (dq.data_ptr(), cur.data_ptr(), sv["mean2"].data_ptr(),
+                                                                   sv["rstd2"].data_ptr(), g2.data_ptr(), wqt.data_ptr(),
+                                                                   part2.data_ptr())
+    if do_q or do_mlp:
+        ds = new(R, D)
+        a.ds = ds.data_ptr()
+    if do_mlp:
+        w1t, w2t = shadow(w1, dt, transposed=True), shadow(w2, dt, transposed=True)
+        dz, part1 = new(R, H), new(2, nblk, D, dtype=torch.float32)
+        keep += [w1t, w2t]
+        a.a, a.hn, a.mean1, a.rstd1, a.ln1_g, a.w1_t, a.w2_t, a.dz, a.part1 = (
+            sv["a"].data_ptr(), sv["hn"].data_ptr(), sv["mean1"].data_ptr(), sv["rstd1"].data_ptr(), g1.data_ptr(), w1t.data_ptr(),
+            w2t.data_ptr(), dz.data_ptr(), part1.data_ptr())
+    if do_gru:
+        wit, wht = shadow(w_ih, dt, transposed=True), shadow(w_hh, dt, transposed=True)
+        dg, dupd = new(2, R, 3 * D), new(R, D)
+        keep += [wit, wht]
+        a.g, a.w_ih_t, a.w_hh_t, a.dg, a.dupd = sv["g"].data_ptr(), wit.data_ptr(), wht.data_ptr(), dg.data_ptr(), dupd.data_ptr()
+    _lib.check(L.focus_slot_tail_bwd(ctypes.byref(a), _stream()), "slot_tail_bwd")
+    grads = {}
+
+    def ln_done(key, part):
+        st = ctx.st.get(key)
+        if st is not None:
+            done = _defer_close(st, part)
+            return done if done is not None else (None, None)
+        both = part.sum(1)
+        return both[0], both[1]
+
+    if do_q:
+        grads["wq"] = _tail_wgrad(ctx.st.get("wq"), wq, None, dq, sv["sn"])[0]
+        grads["g2"], grads["be2"] = ln_done("ln2", part2)
+    if do_mlp:
+        grads["w2"], grads["b2"] = _tail_wgrad(ctx.st.get("w2"), w2, ctx.has_b[2], ds, sv["a"])
+        grads["w1"], grads["b1"] = _tail_wgrad(ctx.st.get("w1"), w1, ctx.has_b[1], dz, sv["y"])
+        grads["g1"], grads["be1"] = ln_done("ln1", part1)
+    if do_gru:
+        grads["w_ih"], grads["b_ih"] = _tail_wgrad(ctx.st.get("ih"), w_ih, ctx.has_b[0], dg[0], upd)
+        grads["w_hh"], grads["b_hh"] = _tail_wgrad(ctx.st.get("hh"), w_hh, ctx.has_b[0], dg[1], h)
+    gg = grads.get
+    return (dupd, dh, None, None, None, None, None, gg("w_ih"), gg("w_hh"), gg("b_ih"), gg("b_hh"), gg("g1"), gg("be1"), gg("w1"),
+            gg("b1"), gg("w2"), gg("b2"), gg("g2"), gg("be2"), gg("wq"))
+
+
+_SlotTailFn._backward_fused = staticmethod(_slot_tail_backward_fused)
+# Measured (profiles/r03 notes in DESIGN.md 0): one workgroup per 16 rows streams 1.1 MB of weights by itself -- 35 us per
+# call against ~26 us for the five small launches it replaces, which spread their weight reads over many CUs.  It wins only
+# where launches are the cost (eager: 36 -> 34 ms per step) and loses under graph replay (17.4 -> 18.7 ms): off by default.
+_SLOT_TAIL_BWD = _os.environ.get("FOCUS_SLOT_TAIL_BWD", "0") != "0"
 
 
 def slot_tail(upd, h, params, gru=True, mlp=True, q=True):

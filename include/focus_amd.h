@@ -431,6 +431,23 @@ typedef struct focus_slot_tail_args {
 } focus_slot_tail_args;
 int focus_slot_tail_ok(int D, int H, int dtype);
 int focus_slot_tail_fwd(const focus_slot_tail_args* args, void* stream);
+/* The same chain backwards in one launch (autograd of steve.py:84-93 / utils.py:107-118 per iteration), against the TRANSPOSED
+ * bf16 weight copies ([in][out]).  Inputs: dout (gradient of the slots; may be NULL = 0), dq (with do_q), the forward's saved
+ * tensors (cur = the slots LayerNorm_slots normalised: s, or hn without the MLP, or h without the GRU).  Outputs: dupd, dh
+ * [R,D]; the dY rows the weight gradients are later formed from: ds [R,D] (fc2; also with do_q alone), dz [R,H] (fc1), dg
+ * [2,R,3D] (W_ih, W_hh) (dq itself is Wq's); LayerNorm parameter partials part1 / part2 [2][focus_slot_tail_bwd_blocks(R)][D]
+ * fp32 ([0] = d gamma, [1] = d beta; sum over the blocks). */
+typedef struct focus_slot_tail_bwd_args {
+    int32_t R, D, H, do_gru, do_mlp, do_q;
+    const void* dout; const void* dq;
+    const void* h; const void* g; const void* hn; const void* a; const void* cur;
+    const float* mean1; const float* rstd1; const float* mean2; const float* rstd2;
+    const float* ln1_g; const float* ln2_g;
+    const void* w_ih_t; const void* w_hh_t; const void* w1_t; const void* w2_t; const void* wq_t;
+    void* dupd; void* dh; void* ds; void* dz; void* dg; float* part1; float* part2;
+} focus_slot_tail_bwd_args;
+int focus_slot_tail_bwd_blocks(int R);
+int focus_slot_tail_bwd(const focus_slot_tail_bwd_args* args, void* stream);
 
 /* Multi-head attention without the [Nq, Nk] probabilities in memory (flash_attn.hip) -- the STEVE decoder's causal
  * self-attention over the image tokens of a frame: STEVE/transformer.py:23-49 (MultiHeadAttention.forward: scale, mask,

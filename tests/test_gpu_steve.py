@@ -595,3 +595,40 @@ def test_shared_gradient_nodes_refuse_a_loss_on_a_subset_of_their_uses():
     outs = [ops.slot_attn_step(k, v, q, 1e-8, acc) for q in qs]
     sum(u.float().sum() + a.float().square().sum() for u, a in outs).backward()
     assert k.grad is not None and v.grad is not None
+
+
+def test_fused_backward_tail_matches_the_composed_one(monkeypatch):
+    """focus_slot_tail_bwd (one launch: dX chain of q-projection, LayerNorms, MLP and GRU on 16-row workgroups) against the
+    backward composed of the single kernels, behind the SAME fused forward: input gradients and every parameter gradient of a
+    three-frame slot loop.  Both round to bf16 at the same places; the products differ in accumulation order only."""
+    from focus_amd import ops
+    from focus_amd.slowfast.models.STEVE.steve import SlotAttentionVideo
+    d = dev()
+    B, T, N, D, K = 4, 3, 512, 192, 11
+    torch.manual_seed(0)
+    m = SlotAttentionVideo(3, K, D, D, 4 * D, num_predictor_blocks=1, num_predictor_heads=4, dropout=0.0).to(d)
+    g = torch.Generator(device=d).manual_seed(1)
+    x0 = torch.randn(B, T, N, D, device=d, generator=g).bfloat16()
+    noise = torch.randn(B, K, D, device=d, generator=g)
+    cs = torch.randn(B, T, K, D, device=d, generator=g)
+
+    def run(fused_bwd):
+        monkeypatch.setattr(ops, "_SLOT_TAIL_BWD", fused_bwd)
+        ops.drop_caches()
+        for p in m.parameters():
+            p.grad = None
+        x = x0.clone().requires_grad_()
+        slots, attn = m(x, noise=noise)
+        ((slots.float() * cs).sum() + attn.float().square().sum()).backward()
+        torch.cuda.synchronize()
+        return slots.detach().float(), x.grad.float(), {n: p.grad.clone().float() for n, p in m.named_parameters()}
+
+    s0, dx0, g0 = run(False)
+    s1, dx1, g1 = run(True)
+    assert torch.equal(s0, s1)                                         # the same forward
+    assert rel_l2(dx1, dx0) < 2e-2, rel_l2(dx1, dx0)
+    for n in g0:
+        scale = float(g0[n].abs().max())
+        if scale < 1e-3 * max(float(v.abs().max()) for v in g0.values()) and "norm_slots.bias" in n:
+            continue                                                    # exactly zero in exact arithmetic: rounding noise
+        assert rel_l2(g1[n], g0[n], floor=1e-2 * scale + 1e-12) < 3e-2, (n, rel_l2(g1[n], g0[n], floor=1e-2 * scale + 1e-12))
