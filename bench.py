@@ -38,7 +38,9 @@ def make_cfg(n_gpus, per_gpu_batch, mixed=True, hr=False):
     cfg = get_cfg()
     # configs/ORViT/SSv2_ORViT-MF_224_16x4.yaml (hot-path keys) with the synthetic-run overrides of SURVEY 8(d)
     cfg.merge_from_list([
-        "ORVIT.ENABLE", True, "ORVIT.O", 4, "ORVIT.LAYERS", [1, 6, 10], "ORVIT.USE_MOTION_STREAM", True,
+        "ORVIT.ENABLE", True, "ORVIT.O", 4, "ORVIT.LAYERS", [1, 6, 10],
+        # (FOCUS_BENCH_NO_MOTION=1: a tuning probe that drops the motion stream to show how much of it the step still waits for)
+        "ORVIT.USE_MOTION_STREAM", os.environ.get("FOCUS_BENCH_NO_MOTION", "0") != "1",
         "ORVIT.MOTION_STREAM_ATTN_TYPE", "joint", "TRAIN.DATASET", "Ssv2", "TRAIN.METHOD", "sup",
         "TRAIN.BATCH_SIZE", per_gpu_batch * max(n_gpus, 1), "TRAIN.MIXED_PRECISION", mixed,
         "DATA.NUM_FRAMES", 16, "DATA.TRAIN_CROP_SIZE", 224, "MF.PATCH_SIZE", 16, "MF.PATCH_SIZE_TEMP", 2,

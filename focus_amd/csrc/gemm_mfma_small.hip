@@ -12,6 +12,7 @@
 // M x N / 1024 workgroups (66 .. 264 for the STEVE shapes): every CU gets work, nothing is serial.
 #include "focus_common.h"
 #include "gemm_internal.h"
+#include <algorithm>
 #include <cstdlib>
 
 namespace {
@@ -20,10 +21,10 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
 constexpr int TS = 32;          // output tile (rows and columns)
-constexpr int MAXSTEPS = 12;    // K steps of 32 per wave held in registers: K <= 4 * 12 * 32 = 1536
+constexpr int MAXSTEPS = 12;    // K steps of 32 per wave held in registers per pass: 4 * 12 * 32 = 1536 of K per pass
 
 template <int EPI, typename TC, int NS>
-__global__ __launch_bounds__(256) void gemm_nt_small_kernel(const focus_gemm_desc d, int tiles_n) {
+__global__ __launch_bounds__(256) void gemm_nt_small_kernel(const focus_gemm_desc d, int tiles_n, int npass) {
     __shared__ __attribute__((aligned(16))) float part[4][4][64][4];       // [wave][sub-tile][lane][4]
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int tm = blockIdx.x / tiles_n, tn = blockIdx.x - tm * tiles_n;
@@ -38,23 +39,14 @@ __global__ __launch_bounds__(256) void gemm_nt_small_kernel(const focus_gemm_des
     TC* X = d.aux ? static_cast<TC*>(d.aux) + coff : nullptr;
     const int frow = lane & 15, fq = lane >> 4;
     const int nsteps = d.K / 32;                                  // steps w, w + 4, ... belong to wave w
-    // all operand fragments of this wave: one round trip
-    bf16x8 fa[NS][2], fb[NS][2];
+    // all operand fragments of this wave: one round trip per pass of NS steps (one pass for K <= 128 NS; the motion stream's
+    // K = 3072 products take two: 192 workgroups x two round trips instead of 12 workgroups walking 48 barrier-locked steps)
     const bf16_t* arow[2];
     const bf16_t* brow[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         arow[i] = A + (int64_t)min(m0 + 16 * i + frow, d.M - 1) * d.rsA + 8 * fq;
         brow[i] = B + (int64_t)min(n0 + 16 * i + frow, d.N - 1) * d.csB + 8 * fq;
-    }
-#pragma unroll
-    for (int s = 0; s < NS; ++s) {
-        const int ks = min(w + 4 * s, nsteps - 1) * 32;           // steps past the end re-read the last one (not used)
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            fa[s][i] = *reinterpret_cast<const bf16x8*>(arow[i] + ks);
-            fb[s][i] = *reinterpret_cast<const bf16x8*>(brow[i] + ks);
-        }
     }
     // the epilogue's own operands (bias, residual, saved activation of the sub-tile this wave finishes) are requested now,
     // together with the fragments: after the LDS combine they would be a second, fully exposed round trip
@@ -67,7 +59,10 @@ __global__ __launch_bounds__(256) void gemm_nt_small_kernel(const focus_gemm_des
         for (int r = 0; r < 4; ++r) {
             if (gn + r >= d.N) break;
             if (d.bias) bs[r] = d.bias[gn + r];
-            if constexpr (EPI >= FOCUS_EPI_DGELU) xs[r] = ld<TC>(X + off + r);
+        }
+        if constexpr (EPI >= FOCUS_EPI_DGELU) {
+            if (full) { const f4 xa = ld4<TC>(X + off); xs[0] = xa.x; xs[1] = xa.y; xs[2] = xa.z; xs[3] = xa.w; }
+            else for (int r = 0; r < 4 && gn + r < d.N; ++r) xs[r] = ld<TC>(X + off + r);
         }
         if (R) {
             if (full) { const f4 rr = ld4<TC>(R + off); rs[0] = rr.x; rs[1] = rr.y; rs[2] = rr.z; rs[3] = rr.w; }
@@ -79,14 +74,26 @@ __global__ __launch_bounds__(256) void gemm_nt_small_kernel(const focus_gemm_des
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int pass = 0; pass < npass; ++pass) {
+        bf16x8 fa[NS][2], fb[NS][2];
 #pragma unroll
-    for (int s = 0; s < NS; ++s) {
-        if (w + 4 * s < nsteps) {
+        for (int s = 0; s < NS; ++s) {
+            const int ks = min(w + 4 * (pass * NS + s), nsteps - 1) * 32;   // steps past the end re-read the last one (not used)
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < 2; ++i) {
+                fa[s][i] = *reinterpret_cast<const bf16x8*>(arow[i] + ks);
+                fb[s][i] = *reinterpret_cast<const bf16x8*>(brow[i] + ks);
+            }
+        }
 #pragma unroll
-                for (int j = 0; j < 2; ++j)                       // "swapped": the lane ends with 4 consecutive columns of one row
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[s][j], fa[s][i], acc[i][j], 0, 0, 0);
+        for (int s = 0; s < NS; ++s) {
+            if (w + 4 * (pass * NS + s) < nsteps) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)                   // "swapped": the lane ends with 4 consecutive columns of one row
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[s][j], fa[s][i], acc[i][j], 0, 0, 0);
+            }
         }
     }
 #pragma unroll
@@ -133,9 +140,10 @@ void launch_small(const focus_gemm_desc& d, hipStream_t s) {
     const int tiles_m = (d.M + TS - 1) / TS, tiles_n = (d.N + TS - 1) / TS;
     const dim3 grid(tiles_m * tiles_n, d.batch0 * d.batch1);
     const int per_wave = (d.K / 32 + 3) / 4;
-    if (per_wave <= 2) hipLaunchKernelGGL((gemm_nt_small_kernel<EPI, TC, 2>), grid, dim3(256), 0, s, d, tiles_n);
-    else if (per_wave <= 6) hipLaunchKernelGGL((gemm_nt_small_kernel<EPI, TC, 6>), grid, dim3(256), 0, s, d, tiles_n);
-    else hipLaunchKernelGGL((gemm_nt_small_kernel<EPI, TC, MAXSTEPS>), grid, dim3(256), 0, s, d, tiles_n);
+    if (per_wave <= 2) hipLaunchKernelGGL((gemm_nt_small_kernel<EPI, TC, 2>), grid, dim3(256), 0, s, d, tiles_n, 1);
+    else if (per_wave <= 6) hipLaunchKernelGGL((gemm_nt_small_kernel<EPI, TC, 6>), grid, dim3(256), 0, s, d, tiles_n, 1);
+    else hipLaunchKernelGGL((gemm_nt_small_kernel<EPI, TC, MAXSTEPS>), grid, dim3(256), 0, s, d, tiles_n,
+                            (per_wave + MAXSTEPS - 1) / MAXSTEPS);
 }
 
 template <typename TC>
@@ -160,7 +168,8 @@ int launch_small_epi(const focus_gemm_desc& d, hipStream_t s) {
 bool focus_gemm_mfma_small_ok(const focus_gemm_desc& d) {
     static const bool enabled = !(getenv("FOCUS_GEMM_SMALL") && atoi(getenv("FOCUS_GEMM_SMALL")) == 0);
     if (!enabled || !focus_gemm_mfma_nt_ok(d)) return false;      // bf16, both operands K-contiguous, aligned
-    if (d.M > 1024 || d.K > 4 * MAXSTEPS * 32 || (d.K & 31) || d.accumulate || d.csC != 1) return false;
+    static const int passes = getenv("FOCUS_GEMM_SMALL_PASSES") ? std::max(1, atoi(getenv("FOCUS_GEMM_SMALL_PASSES"))) : 3;
+    if (d.M > 1024 || d.K > passes * 4 * MAXSTEPS * 32 || (d.K & 31) || d.accumulate || d.csC != 1) return false;
     if (d.dtype_c != FOCUS_BF16 && d.dtype_c != FOCUS_F32) return false;
     const int64_t tiles = (int64_t)((d.M + TS - 1) / TS) * ((d.N + TS - 1) / TS);
     if (tiles > 4096 || d.batch0 * d.batch1 > 65535) return false;

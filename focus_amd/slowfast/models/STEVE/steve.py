@@ -3,6 +3,8 @@ slowfast/models/STEVE/steve.py).  The iterative slot update (SlotAttentionVideo,
 the HIP kernels; the model around it (STEVE.forward, :253-330 -- SURVEY.md section 8(f) rank 1) keeps the reference's
 module tree and state_dict keys: convolutions (dVAE, CNN encoder) and the Gumbel-softmax stay on ATen/MIOpen, every
 Linear / LayerNorm / FFN / attention of the encoder MLP, the slot projection and the decoder goes through the C ABI."""
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -13,6 +15,16 @@ from ..build import MODEL_REGISTRY
 from .dvae import dVAE
 from .transformer import TransformerDecoder, TransformerEncoder
 from .utils import Conv2dBlock, conv2d, gru_cell, gumbel_softmax, linear
+
+_PIPELINE_KV = os.environ.get("FOCUS_STEVE_PIPELINE", "1") != "0"
+_SIDE_STREAMS = {}
+
+
+def _side_stream(device):
+    s = _SIDE_STREAMS.get(device)
+    if s is None:
+        s = _SIDE_STREAMS[device] = torch.cuda.Stream(device=device)
+    return s
 
 
 class SlotAttentionVideo(nn.Module):
@@ -101,9 +113,40 @@ class SlotAttentionVideo(nn.Module):
         ni = self.norm_inputs
         attns_collect, slots_collect = [], []
         slots = slots.reshape(B * K, Ds)
-        for t in range(T):
+
+        def keys_values(t):
+            # LayerNorm of frame t and its k / v projection: the only work of a frame that does not depend on the slots
             x_t = ops.layer_norm_frame(inputs, t, ni.weight, ni.bias, ni.eps, video_grad)
-            k_t, v_t = ops.linear_kv(x_t, self.project_k.weight, self.project_v.weight, alpha_k=k_scale)
+            return ops.linear_kv(x_t, self.project_k.weight, self.project_v.weight, alpha_k=k_scale)
+
+        # Frame t + 1's keys and values are produced on a side stream while frame t's iterations run: the recurrence is a
+        # chain of narrow launches (the 16-row tails and the predictor keep ~22 of 256 CUs busy) next to which these two
+        # full-width kernels -- and, in the backward, the k / v gradient products and the frame LayerNorm's backward, which
+        # autograd runs on the stream of their forward -- find idle CUs.  Same values: nothing here depends on the order.
+        pipe = _PIPELINE_KV and inputs.is_cuda
+        if pipe:
+            main, side = torch.cuda.current_stream(), _side_stream(inputs.device)
+            if torch.distributed.is_available() and torch.distributed.is_initialized():
+                from focus_amd import parallel
+                parallel.note_grad_stream(main)
+                parallel.note_grad_stream(side)
+            side.wait_stream(main)
+            inputs.record_stream(side)
+            with torch.cuda.stream(side):
+                ahead = keys_values(0)
+                ready = side.record_event()
+        for t in range(T):
+            if pipe:
+                main.wait_event(ready)
+                k_t, v_t = ahead
+                k_t.record_stream(main)
+                v_t.record_stream(main)
+                if t + 1 < T:
+                    with torch.cuda.stream(side):
+                        ahead = keys_values(t + 1)
+                        ready = side.record_event()
+            else:
+                k_t, v_t = keys_values(t)
             kv_grad = ops.SlotKVGrad()
             slots, q = ops.slot_tail(None, slots, tail, gru=False, mlp=False, q=True)
             for i in range(self.num_iterations):

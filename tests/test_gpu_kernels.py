@@ -71,7 +71,9 @@ BENCH_SHAPES = [(12552, 768, 768), (12552, 2304, 768), (12552, 3072, 768), (1255
 RAGGED_SHAPES = [(1601, 768, 768), (333, 200, 192), (12808, 1536, 768), (129, 97, 64), (6272, 384, 768)]
 # few rows: gemm_mfma_small.hip (the recurrent STEVE Linears at B*K = 352 rows, the motion stream at 256, ragged edges)
 SMALL_SHAPES = [(352, 192, 192), (352, 576, 192), (352, 192, 768), (352, 768, 192), (256, 768, 1536), (45, 72, 64),
-                (1000, 40, 128), (17, 8, 1536)]
+                (1000, 40, 128), (17, 8, 1536),
+                # more than one pass over the register-resident operands (K > 1536): the motion stream's fc2 and its dX
+                (256, 768, 3072), (256, 768, 2304), (77, 40, 4608), (256, 3072, 768)]
 
 
 @pytest.mark.parametrize("shape", BENCH_SHAPES + RAGGED_SHAPES + SMALL_SHAPES)
