@@ -91,6 +91,7 @@ class Motionformer(nn.Module):
         else:
             self.head = nn.Linear(self.embed_dim, self.num_classes) if self.num_classes > 0 else nn.Identity()
 
+        self._bicubic = {}            # (grid, patches, device) -> the bicubic resampling matrix of _spatial_pos
         self.init_weights()
         self.apply(self._init_weights)
 
@@ -126,10 +127,19 @@ class Motionformer(nn.Module):
         if self.cfg.DATA.TRAIN_CROP_SIZE == 224:
             return pos[0]
         g = int(math.sqrt(n0))
-        sp = pos[:, 1:].reshape(1, g, g, -1).permute(0, 3, 1, 2)
-        sp = torch.nn.functional.interpolate(sp, scale_factor=math.sqrt(npatch / n0), mode="bicubic")
-        sp = sp.permute(0, 2, 3, 1).reshape(-1, pos.shape[-1])
-        return torch.cat([pos[0, :1], sp], dim=0)
+        # Bicubic resampling is a fixed linear map of the g x g grid: its [npatch, n0] matrix is read off ATen's own
+        # interpolate applied to the identity (once per size and device: the same taps, hence the same values up to the order
+        # of a 16-term fp32 sum) and applied as one small product.  ATen's upsample_bicubic2d / its backward on the
+        # [1, 768, 14, 14] tensor took 2.5 + 6.6 ms of EVERY 48 ms HR step (profiles/r03_kernel_summary_hr.txt).
+        key = (g, npatch, pos.device)
+        m = self._bicubic.get(key)
+        if m is None:
+            eye = torch.eye(n0, device=pos.device, dtype=torch.float32).reshape(1, n0, g, g)
+            with torch.no_grad():
+                up = torch.nn.functional.interpolate(eye, scale_factor=math.sqrt(npatch / n0), mode="bicubic")
+            m = self._bicubic[key] = up.reshape(n0, -1).t().contiguous()          # [npatch, n0]
+        sp = m @ pos[0, 1:].float()
+        return torch.cat([pos[0, :1], sp.to(pos.dtype)], dim=0)
 
     def forward_features(self, x, metadata):
         x = x[0]
