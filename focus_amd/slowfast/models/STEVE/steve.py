@@ -304,12 +304,24 @@ class STEVE(nn.Module):
         self.dvae = dVAE(args.SLOTS.VOCAB_SIZE, args.SLOTS.IMG_CHANNELS)
         self.steve_encoder = STEVEEncoder(args)
         self.steve_decoder = STEVEDecoder(args)
+        # The convolutions (dVAE, CNN encoder: ATen / MIOpen) run channels-last: MIOpen's kernels for these shapes are NHWC
+        # ones and an NCHW caller pays a layout transpose before and after every convolution (batched_transpose_32x32: 6 ms of
+        # a 162 ms step); the token path wants [B*T, H*W, C] rows anyway.  Shapes, values and state_dict keys are unchanged.
+        self.channels_last = os.environ.get("FOCUS_STEVE_CHANNELS_LAST", "1") != "0"
+        if self.channels_last:
+            self.dvae.to(memory_format=torch.channels_last)
+            self.steve_encoder.cnn.to(memory_format=torch.channels_last)
+
+    def _frames(self, video):
+        """[B,T,C,H,W] -> [B*T,C,H,W] in the memory format the convolutions run in."""
+        flat = video.flatten(end_dim=1)
+        return flat.contiguous(memory_format=torch.channels_last) if self.channels_last else flat
 
     # ---- shared by forward / encode (steve.py:294-313, :333-353) ----
     def _slots(self, video, noise=None):
         B, T, C, H, W = video.shape
         enc = self.steve_encoder
-        emb = enc.pos(enc.cnn(video.flatten(end_dim=1)))                                  # B*T, d_model, H_enc, W_enc
+        emb = enc.pos(enc.cnn(self._frames(video)))                                       # B*T, d_model, H_enc, W_enc
         H_enc, W_enc = emb.shape[-2:]
         emb_set = emb.permute(0, 2, 3, 1).flatten(start_dim=1, end_dim=2).to(self.compute_dtype)    # B*T, H_enc*W_enc, d_model
         ln = enc.layer_norm
@@ -346,14 +358,23 @@ class STEVE(nn.Module):
         B, T, C, H, W = video.size()
         noise = noise or {}
         dec = self.steve_decoder
-        video_flat = video.flatten(end_dim=1)                                             # B*T, C, H, W
+        video_flat = self._frames(video)                                                  # B*T, C, H, W
 
         # dvae encode (:262-271)
-        z_logits = F.log_softmax(self.dvae.encoder(video_flat), dim=1)                    # B*T, vocab, H_enc, W_enc
-        z_soft = gumbel_softmax(z_logits, tau, hard, dim=1, noise=noise.get("gumbel_soft"))
-        z_hard = gumbel_softmax(z_logits, tau, True, dim=1, noise=noise.get("gumbel_hard")).detach()
-        z_hard = z_hard.permute(0, 2, 3, 1).flatten(start_dim=1, end_dim=2)               # B*T, H_enc*W_enc, vocab
-        target = torch.argmax(z_hard, dim=-1)                                             # the one-hot's index
+        # The vocabulary axis is moved LAST for the three softmax-family passes over the [B*T, 4096, H/4, W/4] logits: as dim=1
+        # of an NCHW tensor ATen runs them with its strided "spatial" kernels -- 29 of the 162 ms of kernel time of a training
+        # step at 24 x 128 x 128 -- and the same vectors normalised along a contiguous axis take a tenth of that.  Same
+        # values; the decoder's 1x1 convolution receives the channels-last view (MIOpen's own layout).
+        z_logits = F.log_softmax(self.dvae.encoder(video_flat).permute(0, 2, 3, 1), dim=-1)   # B*T, H_enc, W_enc, vocab
+        last = lambda e: None if e is None else e.permute(0, 2, 3, 1)
+        z_soft = gumbel_softmax(z_logits, tau, hard, dim=-1, noise=last(noise.get("gumbel_soft"))).permute(0, 3, 1, 2)
+        # the hard sample is only ever read through its arg-max (:268-269), which is the arg-max of the perturbed logits:
+        # softmax is monotonic, so no second softmax, one-hot scatter and straight-through sum over 4096 x 1024 x B*T values
+        e_hard = last(noise.get("gumbel_hard"))
+        if e_hard is None:
+            e_hard = torch.empty_like(z_logits).exponential_()
+        with torch.no_grad():
+            target = (z_logits - (e_hard + torch.finfo(z_logits.dtype).tiny).log()).argmax(dim=-1).flatten(start_dim=1)
         z_emb = dec.dict.dictionary(target)                                               # B*T, H_enc*W_enc, d_model
         z_emb = torch.cat([dec.bos.expand(B * T, -1, -1), z_emb], dim=1)
         z_emb = dec.pos(z_emb)
