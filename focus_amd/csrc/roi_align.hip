@@ -135,7 +135,9 @@ __global__ __launch_bounds__(256) void roi_bwd_kernel(const T* __restrict__ dout
 // No atomics, no zero fill, dout read once, dfeat written once in the feature dtype.  (The scatter form needs 4
 // float atomics per sampling point and channel: 154 M global atomics per call at the bench shape, 474 us; LDS float
 // atomics were slower still -- ds_add_f32 retires about one lane per clock.)
-constexpr int RB_HMAX = 16, RB_PMAX = 16, RB_CS = 64;
+// Two instances: <64 channels, 16, 16> for maps and crops up to 16 x 16 (the 14 x 14 of the 224 crops; block = 64 x W <= 1024
+// threads), <32 channels, 24, 24> for up to 24 x 24 (the 21 x 21 of the HR 336 crops, which the first cannot hold: the
+// atomic fallback took 560 us per call there).  CS = channels per workgroup, HM / PM = register-array bounds for H, PH / PW.
 
 // 1-D half of locate(): v -> (low, high, weight of low, weight of high); low < 0 when the coordinate is out of range
 __device__ __forceinline__ void locate1(float v, int L, int* low, int* high, float* w_low, float* w_high) {
@@ -147,33 +149,34 @@ __device__ __forceinline__ void locate1(float v, int L, int* low, int* high, flo
     *low = lo; *high = hi; *w_low = __fsub_rn(1.0f, l); *w_high = l;
 }
 
-template <typename T>
-__global__ __launch_bounds__(1024) void roi_bwd_sep_kernel(const T* __restrict__ dout, const T* __restrict__ relu_out,
+template <typename T, int CS, int HM, int PM>
+__global__ __launch_bounds__(CS * HM) void roi_bwd_sep_kernel(const T* __restrict__ dout, const T* __restrict__ relu_out,
                                                            const float* __restrict__ rois,
                                                            const int32_t* __restrict__ roi_img, T* __restrict__ dfeat,
                                                            int64_t img_stride, int ipb, int64_t batch_stride,
                                                            int C, int H, int W, int K, int PH, int PW, float scale,
                                                            int sr, int aligned) {
-    extern __shared__ __attribute__((aligned(16))) float gst[];   // [bins][RB_CS]: dout / count of the current RoI
-    __shared__ __attribute__((aligned(16))) float Ay[RB_HMAX][RB_PMAX], Ax[RB_HMAX][RB_PMAX];
+    extern __shared__ __attribute__((aligned(16))) float gst[];   // [bins][CS]: dout / count of the current RoI
+    __shared__ __attribute__((aligned(16))) float Ay[HM][PM], Ax[HM][PM];
     __shared__ int match[1024], wcnt[16], nmatch_s;
-    const int img = blockIdx.y, c0 = blockIdx.x * RB_CS;
-    const int ch = threadIdx.x & 63, x = threadIdx.x >> 6;                 // x < W (blockDim = 64 * W)
-    const int nw = blockDim.x >> 6, bins = PH * PW;
-    float acc[RB_HMAX];
+    const int img = blockIdx.y, c0 = blockIdx.x * CS;
+    const int ch = threadIdx.x % CS, x = threadIdx.x / CS;                 // x < W (blockDim = CS * W)
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int nwv = (blockDim.x + 63) >> 6, nx = blockDim.x / CS, bins = PH * PW;
+    float acc[HM];
 #pragma unroll
-    for (int y = 0; y < RB_HMAX; ++y) acc[y] = 0.f;
+    for (int y = 0; y < HM; ++y) acc[y] = 0.f;
     for (int kb = 0; kb < K; kb += blockDim.x) {
         // the RoIs of this image, in index order
         const int kk = kb + threadIdx.x;
         const bool m = kk < K && roi_img[kk] == img;
         const unsigned long long bal = __ballot(m);
         __syncthreads();
-        if (ch == 0) wcnt[x] = __popcll(bal);
+        if (lane == 0) wcnt[wv] = __popcll(bal);
         __syncthreads();
         int off = 0, tot = 0;
-        for (int j = 0; j < nw; ++j) { if (j < x) off += wcnt[j]; tot += wcnt[j]; }
-        if (m) match[off + __popcll(bal & ((1ull << ch) - 1ull))] = kk;
+        for (int j = 0; j < nwv; ++j) { if (j < wv) off += wcnt[j]; tot += wcnt[j]; }
+        if (m) match[off + __popcll(bal & ((1ull << lane) - 1ull))] = kk;
         if (threadIdx.x == 0) nmatch_s = tot;
         __syncthreads();
         const int nmatch = nmatch_s;
@@ -182,34 +185,33 @@ __global__ __launch_bounds__(1024) void roi_bwd_sep_kernel(const T* __restrict__
             const Geom g = roi_geometry(rois + 4 * k, scale, PH, PW, sr, aligned);
             if (g.grid_h <= 0 || g.grid_w <= 0) continue;                  // block-uniform
             __syncthreads();                                               // previous RoI's gst / Ay / Ax are free
-            if (bins <= 16 * nw) {
+            constexpr int NB = PM;                      // bins per thread held in registers (bins <= NB * columns)
+            if (bins <= NB * nx) {
                 // all loads of this thread issued together (unrolled, clamped addresses instead of a branch): as a rolled
                 // "load, store to LDS" loop every iteration waited for its own load -- 14 serial round trips per RoI, the
                 // whole launch ran at 3 % of the HBM rate (215 us for 48 MB)
-                float gv[16], rv[16];
+                float gv[NB], rv[NB];
 #pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const int bin = min(x + i * nw, bins - 1);
+                for (int i = 0; i < NB; ++i) {
+                    const int bin = min(x + i * nx, bins - 1);
                     const int64_t o = ((int64_t)k * bins + bin) * C + c0 + ch;
                     gv[i] = ld<T>(dout + o);
                     rv[i] = relu_out ? ld<T>(relu_out + o) : 1.f;
                 }
-                const float inv = 1.f / g.count;
 #pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const int bin = x + i * nw;
-                    if (bin < bins) gst[bin * RB_CS + ch] = rv[i] > 0.f ? gv[i] / g.count : 0.f;
+                for (int i = 0; i < NB; ++i) {
+                    const int bin = x + i * nx;
+                    if (bin < bins) gst[bin * CS + ch] = rv[i] > 0.f ? gv[i] / g.count : 0.f;
                 }
-                (void)inv;
             } else {
-                for (int bin = x; bin < bins; bin += nw) {
+                for (int bin = x; bin < bins; bin += nx) {
                     const int64_t o = ((int64_t)k * bins + bin) * C + c0 + ch;
                     float gv = ld<T>(dout + o) / g.count;
                     if (relu_out && !(ld<T>(relu_out + o) > 0.f)) gv = 0.f;     // fused ReLU: the saved output is the mask
-                    gst[bin * RB_CS + ch] = gv;
+                    gst[bin * CS + ch] = gv;
                 }
             }
-            if (threadIdx.x < RB_HMAX * RB_PMAX) { (&Ay[0][0])[threadIdx.x] = 0.f; (&Ax[0][0])[threadIdx.x] = 0.f; }
+            for (int i = threadIdx.x; i < HM * PM; i += blockDim.x) { (&Ay[0][0])[i] = 0.f; (&Ax[0][0])[i] = 0.f; }
             __syncthreads();
             // one thread per bin row / bin column: no two threads write the same Ay / Ax entry
             if (threadIdx.x < PH) {
@@ -228,30 +230,30 @@ __global__ __launch_bounds__(1024) void roi_bwd_sep_kernel(const T* __restrict__
                 }
             }
             __syncthreads();
-            // this thread's row of Ax in registers (4 x ds_read_b128 instead of PH*PW broadcast reads)
-            float ax[RB_PMAX];
+            // this thread's row of Ax in registers (ds_read_b128s instead of PH*PW broadcast reads)
+            float ax[PM];
 #pragma unroll
-            for (int q4 = 0; q4 < RB_PMAX / 4; ++q4) {
+            for (int q4 = 0; q4 < PM / 4; ++q4) {
                 const float4 v = *reinterpret_cast<const float4*>(&Ax[x][q4 * 4]);
                 ax[q4 * 4 + 0] = v.x; ax[q4 * 4 + 1] = v.y; ax[q4 * 4 + 2] = v.z; ax[q4 * 4 + 3] = v.w;
             }
-            float t1[RB_PMAX];
+            float t1[PM];
 #pragma unroll
-            for (int ph = 0; ph < RB_PMAX; ++ph) {
+            for (int ph = 0; ph < PM; ++ph) {
                 float t = 0.f;
                 if (ph < PH) {
 #pragma unroll
-                    for (int pw = 0; pw < RB_PMAX; ++pw)
-                        if (pw < PW) t = fmaf(gst[(ph * PW + pw) * RB_CS + ch], ax[pw], t);
+                    for (int pw = 0; pw < PM; ++pw)
+                        if (pw < PW) t = fmaf(gst[(ph * PW + pw) * CS + ch], ax[pw], t);
                 }
                 t1[ph] = t;
             }
 #pragma unroll
-            for (int y = 0; y < RB_HMAX; ++y) {
+            for (int y = 0; y < HM; ++y) {
                 if (y < H) {
                     float t = 0.f;
 #pragma unroll
-                    for (int q4 = 0; q4 < RB_PMAX / 4; ++q4) {
+                    for (int q4 = 0; q4 < PM / 4; ++q4) {
                         const float4 a = *reinterpret_cast<const float4*>(&Ay[y][q4 * 4]);   // zero beyond PH
                         t = fmaf(a.x, t1[q4 * 4 + 0], t); t = fmaf(a.y, t1[q4 * 4 + 1], t);
                         t = fmaf(a.z, t1[q4 * 4 + 2], t); t = fmaf(a.w, t1[q4 * 4 + 3], t);
@@ -262,16 +264,19 @@ __global__ __launch_bounds__(1024) void roi_bwd_sep_kernel(const T* __restrict__
         }
     }
 #pragma unroll
-    for (int y = 0; y < RB_HMAX; ++y)
+    for (int y = 0; y < HM; ++y)
         if (y < H)
             st<T>(dfeat + (int64_t)(img / ipb) * batch_stride + (int64_t)(img % ipb) * img_stride + (int64_t)(y * W + x) * C + c0 + ch,
                   acc[y]);
 }
 
-// 1 when the separable kernel takes the shape (else: atomic kernel + cast)
+// which separable instance takes the shape: 1 = <64, 16, 16>, 2 = <32, 24, 24>, 0 = none (atomic kernel + cast)
 static int roi_sep_ok(int C, int H, int W, int PH, int PW) {
     static const int mode = getenv("FOCUS_ROI_BWD") ? atoi(getenv("FOCUS_ROI_BWD")) : 1;
-    return mode != 0 && H <= RB_HMAX && W <= 16 && W >= 2 && PH <= RB_PMAX && PW <= RB_PMAX && PH * PW * RB_CS * 4 <= 56 * 1024 && C % RB_CS == 0;
+    if (mode == 0 || W < 2) return 0;
+    if (H <= 16 && W <= 16 && PH <= 16 && PW <= 16 && PH * PW * 64 * 4 <= 56 * 1024 && C % 64 == 0) return 1;
+    if (H <= 24 && W <= 24 && PH <= 24 && PW <= 24 && PH * PW * 32 * 4 <= 60 * 1024 && C % 32 == 0) return 2;
+    return 0;
 }
 
 __global__ void roi_indices_kernel(const float* __restrict__ rois, int32_t* __restrict__ grid,
@@ -327,15 +332,19 @@ extern "C" int focus_roi_align_bwd(const void* dout, const void* relu_out, const
     if (!dense && !roi_sep_ok(C, H, W, PH, PW)) return FOCUS_ERR_SHAPE;   // the atomic path accumulates into a dense map
     if (relu_out && !roi_sep_ok(C, H, W, PH, PW)) return FOCUS_ERR_SHAPE; // the fused-ReLU mask is a separable-path feature
     hipStream_t s = (hipStream_t)stream;
-    if (roi_sep_ok(C, H, W, PH, PW)) {
-        dim3 grid(C / RB_CS, NI), blk(64 * W);
-        const size_t lds = (size_t)PH * PW * RB_CS * sizeof(float);
-        if (dtype == FOCUS_BF16)
-            hipLaunchKernelGGL((roi_bwd_sep_kernel<bf16_t>), grid, blk, lds, s, (const bf16_t*)dout, (const bf16_t*)relu_out, rois, roi_img,
-                               (bf16_t*)dfeat, img_stride, imgs_per_batch, batch_stride, C, H, W, K, PH, PW, scale, sr, aligned);
-        else
-            hipLaunchKernelGGL((roi_bwd_sep_kernel<float>), grid, blk, lds, s, (const float*)dout, (const float*)relu_out, rois, roi_img,
-                               (float*)dfeat, img_stride, imgs_per_batch, batch_stride, C, H, W, K, PH, PW, scale, sr, aligned);
+    const int sep = roi_sep_ok(C, H, W, PH, PW);
+    if (sep) {
+        const int cs = sep == 1 ? 64 : 32;
+        dim3 grid(C / cs, NI), blk(cs * W);
+        const size_t lds = (size_t)PH * PW * cs * sizeof(float);
+#define ROI_SEP(T, CS, HM) do { \
+            auto k = roi_bwd_sep_kernel<T, CS, HM, HM>; \
+            if (lds > 48 * 1024 && hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return FOCUS_ERR_LAUNCH; \
+            hipLaunchKernelGGL(k, grid, blk, lds, s, (const T*)dout, (const T*)relu_out, rois, roi_img, (T*)dfeat, img_stride, \
+                               imgs_per_batch, batch_stride, C, H, W, K, PH, PW, scale, sr, aligned); } while (0)
+        if (dtype == FOCUS_BF16) { if (sep == 1) ROI_SEP(bf16_t, 64, 16); else ROI_SEP(bf16_t, 32, 24); }
+        else { if (sep == 1) ROI_SEP(float, 64, 16); else ROI_SEP(float, 32, 24); }
+#undef ROI_SEP
         FOCUS_CHECK_LAUNCH();
         return FOCUS_OK;
     }

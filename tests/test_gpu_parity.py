@@ -694,9 +694,11 @@ def test_trajectory_attention_frame_counts(oracle, F_, P):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("H,W,PH,PW", [(14, 14, 14, 14), (14, 14, 7, 7), (16, 16, 8, 5), (7, 9, 7, 9)])
+@pytest.mark.parametrize("H,W,PH,PW", [(14, 14, 14, 14), (14, 14, 7, 7), (16, 16, 8, 5), (7, 9, 7, 9),
+                                       # the 32-channel instance for maps up to 24 x 24 (HR 336 crops: 21 x 21 patches)
+                                       (21, 21, 21, 21), (24, 18, 20, 24), (21, 21, 7, 7)])
 def test_roi_align_separable_backward(oracle, dtype, H, W, PH, PW):
-    """The separable backward (Ay . dout . Ax^T, channel count a multiple of 64) against the oracle's scatter form,
+    """The separable backward (Ay . dout . Ax^T, both instances: 64 channels x 16 x 16, 32 channels x 24 x 24) against the oracle's scatter form,
     with degenerate, off-map and whole-map boxes and several RoIs (or none) per image."""
     from focus_amd import ops
     g = torch.Generator().manual_seed(H * 100 + PH)
