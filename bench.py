@@ -395,6 +395,7 @@ def bench_steve_model(a, dev):
     sl.NUM_ITERS, sl.NUM_SLOTS, sl.CNN_HID_SIZE, sl.SIZE, sl.DIM, sl.MLP_HID_SIZE, sl.IMG_SIZE, sl.VOCAB_SIZE = 3, 11, 64, 192, 192, 768, 128, 4096
     sl.NUM_PREDICTOR_BLOCKS, sl.NUM_PREDICTOR_HEADS, sl.PREDICTOR_DROPOUT = 1, 4, 0.0
     sl.DECODER.DIM, sl.DECODER.NUM_BLOCKS, sl.DECODER.NUM_HEADS, sl.DECODER.DROPOUT = 192, 8, 4, 0.1
+    sl.GRAPH_SLOT_UPDATE = os.environ.get("FOCUS_BENCH_STEVE_GRAPH", "0") != "0"   # (=1: slot update from HIP graphs; no gain at batch 16)
     B, T = a.steve_model_batch, 24
     torch.manual_seed(0)
     m = MODEL_REGISTRY.get("STEVE")(cfg).to(dev)
@@ -439,7 +440,8 @@ def bench_steve_model(a, dev):
     ops.drop_caches()
     torch.cuda.empty_cache()
     return {"workload": "STEVE training step, movi_e 24x128x128, 11 slots, 3 iterations, decoder 8 blocks x 4 heads x 48, "
-                        "vocabulary 4096, dropout 0.1, batch=%d, bf16 token path (configs/movi_e/base.yaml at IMG_SIZE 128)" % B,
+                        "vocabulary 4096, dropout 0.1, batch=%d, bf16 token path (configs/movi_e/base.yaml at IMG_SIZE 128)%s" % (
+                            B, ", slot update replayed from HIP graphs (SLOTS.GRAPH_SLOT_UPDATE)" if sl.GRAPH_SLOT_UPDATE else ""),
             "ms_per_step": round(ms, 2), "clips_per_s": round(B / (ms * 1e-3), 2), "forward_ms": round(fwd_ms, 2),
             "steps": n, "final_loss": round(float(loss.detach()), 4), "peak_memory_GiB": round(peak, 1),
             "flash_attention_calls_per_step": calls,
