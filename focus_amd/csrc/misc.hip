@@ -344,16 +344,20 @@ extern "C" int focus_colsum(const void* x, float* out, int M, int N, int64_t row
     hipStream_t s = (hipStream_t)stream;
     // a single row strip stores its sums directly: no zero fill, no atomics (short matrices: slot / object-token layers)
     const bool vec = dtype == FOCUS_BF16 && (N & 7) == 0 && (row_stride & 7) == 0 && focus_aligned(x, 16);
-    const bool one_strip = M <= (vec ? 512 : 256);
+    // small problems (the narrow layers of reduced test models, stacked over the applications of a loop): ONE strip however
+    // long, i.e. a fixed summation order -- with several strips the fp32 atomics below make the sums differ in the last bit
+    // from run to run, which a bit-exact replay test cannot tell from a real divergence.  Large ones keep the parallel strips.
+    const bool small = (int64_t)M * N <= (4 << 20);
+    const bool one_strip = small || M <= (vec ? 512 : 256);
     if (!accumulate && !one_strip && hipMemsetAsync(out, 0, sizeof(float) * N, s) != hipSuccess) return FOCUS_ERR_LAUNCH;
     if (vec) {
-        const int rpb = 512;
+        const int rpb = one_strip ? M : 512;
         hipLaunchKernelGGL(colsum_bf16_vec_kernel, dim3((N + 255) / 256, (M + rpb - 1) / rpb), dim3(256), 0, s,
                            (const bf16_t*)x, out, M, N, row_stride, rpb, accumulate);
         FOCUS_CHECK_LAUNCH();
         return FOCUS_OK;
     }
-    const int rpb = 256;
+    const int rpb = one_strip ? M : 256;
     dim3 grid((N + 63) / 64, (M + rpb - 1) / rpb);
     DISPATCH_T(dtype, hipLaunchKernelGGL((colsum_kernel<T>), grid, dim3(256), 0, s, (const T*)x, out, M, N,
                                          row_stride, rpb, accumulate));
