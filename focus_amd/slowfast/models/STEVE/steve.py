@@ -16,7 +16,11 @@ from .dvae import dVAE
 from .transformer import TransformerDecoder, TransformerEncoder
 from .utils import Conv2dBlock, conv2d, gru_cell, gumbel_softmax, linear
 
-_PIPELINE_KV = os.environ.get("FOCUS_STEVE_PIPELINE", "1") != "0"
+# Next-frame k / v on a side stream (see _loop_fused): opt-in.  Eager runs are bit-reproducible with it, but whole-step graph
+# replays were not always (tools/steve_pipeline_check.py: d(k), d(v) reaching the projection's backward before they were
+# complete -- fenced since -- and, once in nine replays after the fence, a first replay whose forward differed); a replay that
+# is not bit-identical to the eager step is not shipped as the default for 0.4 ms.
+_PIPELINE_KV = os.environ.get("FOCUS_STEVE_PIPELINE", "0") != "0"
 _SIDE_STREAMS = {}
 
 
@@ -25,6 +29,28 @@ def _side_stream(device):
     if s is None:
         s = _SIDE_STREAMS[device] = torch.cuda.Stream(device=device)
     return s
+
+
+class _KVFence(torch.autograd.Function):
+    """Identity on (k_t, v_t) at the point where the main stream takes over the keys and values a side stream produced.
+    Forward: the main stream waits for the producer's event.  Backward (it runs on the main stream, after the frame's
+    d(k), d(v) have been enqueued there): the side stream is made to wait for the main stream EXPLICITLY before the gradients
+    travel on to the projection's backward on the side stream -- the engine's own producer / consumer hand-over alone left
+    whole-step graph replays with occasionally stale d(k), d(v) in that product (tools/steve_pipeline_check.py)."""
+
+    @staticmethod
+    def forward(ctx, k, v, main, side, ready):
+        main.wait_event(ready)
+        k.record_stream(main)
+        v.record_stream(main)
+        ctx.streams = (main, side)
+        return k.view_as(k), v.view_as(v)
+
+    @staticmethod
+    def backward(ctx, dk, dv):
+        main, side = ctx.streams
+        side.wait_stream(torch.cuda.current_stream())
+        return dk, dv, None, None, None
 
 
 class SlotAttentionVideo(nn.Module):
@@ -137,10 +163,7 @@ class SlotAttentionVideo(nn.Module):
                 ready = side.record_event()
         for t in range(T):
             if pipe:
-                main.wait_event(ready)
-                k_t, v_t = ahead
-                k_t.record_stream(main)
-                v_t.record_stream(main)
+                k_t, v_t = _KVFence.apply(ahead[0], ahead[1], main, side, ready)
                 if t + 1 < T:
                     with torch.cuda.stream(side):
                         ahead = keys_values(t + 1)
