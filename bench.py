@@ -470,7 +470,7 @@ def bench_steve(a, dev):
             p.grad = None
 
     def fwd_bwd():
-        slots, attn = m(x, noise=noise)
+        slots, attn = m(x, noise)
         (slots.float().square().mean() + attn.float().mean()).backward()
         return slots, attn
 
