@@ -270,6 +270,235 @@ __global__ __launch_bounds__(256) void slot_tail_fwd_kernel(const focus_slot_tai
     }
 }
 
+// ---- the same forward as a few right-sized launches ("staged") ---------------------------------------------------
+// One workgroup per 16 rows streams 1 MB of weights through one CU (~29 us).  Cut at the points where a whole row is needed
+// (the two LayerNorms and the K = 768 product), every piece splits over output-column tiles as well: 264 one-wave workgroups
+// per launch, each loading a few KB of weights straight into MFMA fragments -- the kernel boundary is the cross-CU exchange.
+//   gru  : (row block, 16 hidden units): the six gate tiles of those units, gate math, h'
+//   mlp1 : (row block, 64 hidden columns): LayerNorm_mlp of its rows (redundantly per workgroup: 6 KB), fc1 + ReLU
+//   mlp2 : (row block, 16 columns): fc2 over K = 768, + bias + h'
+//   q    : (row block, 16 columns): LayerNorm_slots of its rows, q projection
+// Same stored values and rounding points as the fused kernel; LayerNorm sums associate differently (4 lanes x 48 elements).
+__device__ __forceinline__ bf16x8 frag16(const bf16_t* base, int64_t row, int64_t ld, int k) {
+    return *reinterpret_cast<const bf16x8*>(base + row * ld + k);
+}
+
+// LayerNorm of the wave's 16 rows held as A fragments (lane: row = lane & 15, columns 32 ks + 8 kq .. + 7, ks < 6): the row's
+// four lanes (kq = 0..3) combine with two shuffles.  Returns the normalised fragments; mean / rstd of the lane's row.
+template <int D>
+__device__ __forceinline__ void ln_frags(bf16x8 (&x)[D / 32], const float* __restrict__ gamma, const float* __restrict__ beta,
+                                         float eps, int kq, float& mean, float& rstd) {
+    constexpr int KS = D / 32;
+    float v[KS][8];
+    float s = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { v[ks][e] = (float)x[ks][e]; s += v[ks][e]; }
+    s += __shfl_xor(s, 16, 64); s += __shfl_xor(s, 32, 64);
+    mean = s * (1.f / D);
+    float q = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { const float dl = v[ks][e] - mean; q += dl * dl; }
+    q += __shfl_xor(q, 16, 64); q += __shfl_xor(q, 32, 64);
+    rstd = rsqrtf(q * (1.f / D) + eps);
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int c = ks * 32 + kq * 8 + e;
+            x[ks][e] = (__bf16)((v[ks][e] - mean) * rstd * gamma[c] + beta[c]);
+        }
+}
+
+template <int D>
+__global__ __launch_bounds__(64) void tail_gru_kernel(const focus_slot_tail_args a) {
+    constexpr int KS = D / 32, G3 = 3 * D;
+    const int lane = threadIdx.x, frow = lane & 15, kq = lane >> 4;
+    const int jt = blockIdx.x, r0 = blockIdx.y * ROWS, R = a.R;
+    const int64_t row = min(r0 + frow, R - 1);
+    const bf16_t* U = static_cast<const bf16_t*>(a.upd);
+    const bf16_t* Hs = static_cast<const bf16_t*>(a.h);
+    const bf16_t* Wi = static_cast<const bf16_t*>(a.w_ih);
+    const bf16_t* Wh = static_cast<const bf16_t*>(a.w_hh);
+    bf16x8 au[KS], ah[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) { au[ks] = frag16(U, row, D, ks * 32 + kq * 8); ah[ks] = frag16(Hs, row, D, ks * 32 + kq * 8); }
+    f32x4 gi[3], gh[3];
+    bf16x8 wi[3][KS], wh[3][KS];
+#pragma unroll
+    for (int g = 0; g < 3; ++g) {
+        const int64_t n = g * D + jt * 16 + frow;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) { wi[g][ks] = frag16(Wi, n, D, ks * 32 + kq * 8); wh[g][ks] = frag16(Wh, n, D, ks * 32 + kq * 8); }
+    }
+    __builtin_amdgcn_sched_barrier(0);                  // all 48 fragment loads in flight together (see tail_mlp2_kernel)
+#pragma unroll
+    for (int g = 0; g < 3; ++g)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) { asm volatile("" : "+v"(wi[g][ks])); asm volatile("" : "+v"(wh[g][ks])); }
+#pragma unroll
+    for (int g = 0; g < 3; ++g) {
+        gi[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        gh[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            gi[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(au[ks], wi[g][ks], gi[g], 0, 0, 0);
+            gh[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[ks], wh[g][ks], gh[g], 0, 0, 0);
+        }
+    }
+    // lane: rows kq*4 + r, hidden unit j
+    const int j = jt * 16 + frow;
+    bf16_t* G = static_cast<bf16_t*>(a.g);
+    bf16_t* HN = static_cast<bf16_t*>(a.hn);
+    float bi[3], bh[3];
+#pragma unroll
+    for (int g = 0; g < 3; ++g) { bi[g] = a.b_ih[g * D + j]; bh[g] = a.b_hh[g * D + j]; }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int rr = r0 + kq * 4 + r;
+        if (rr >= R) continue;
+        bf16_t vi[3], vh[3];
+#pragma unroll
+        for (int g = 0; g < 3; ++g) {
+            vi[g] = f32_to_bf16(gi[g][r] + bi[g]);
+            vh[g] = f32_to_bf16(gh[g][r] + bh[g]);
+            G[(int64_t)rr * G3 + g * D + j] = vi[g];
+            G[((int64_t)R + rr) * G3 + g * D + j] = vh[g];
+        }
+        const float rg = sigm_(bf16_to_f32(vi[0]) + bf16_to_f32(vh[0]));
+        const float zg = sigm_(bf16_to_f32(vi[1]) + bf16_to_f32(vh[1]));
+        const float ng = tanhf(bf16_to_f32(vi[2]) + rg * bf16_to_f32(vh[2]));
+        HN[(int64_t)rr * D + j] = f32_to_bf16((1.f - zg) * ng + zg * bf16_to_f32(Hs[(int64_t)rr * D + j]));
+    }
+}
+
+template <int D, int H>
+__global__ __launch_bounds__(64) void tail_mlp1_kernel(const focus_slot_tail_args a) {
+    constexpr int KS = D / 32;
+    const int lane = threadIdx.x, frow = lane & 15, kq = lane >> 4;
+    const int grp = blockIdx.x, r0 = blockIdx.y * ROWS, R = a.R;
+    const int64_t row = min(r0 + frow, R - 1);
+    const bf16_t* HN = static_cast<const bf16_t*>(a.hn);
+    const bf16_t* W1 = static_cast<const bf16_t*>(a.w1);
+    bf16x8 x[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) x[ks] = frag16(HN, row, D, ks * 32 + kq * 8);
+    bf16x8 w[4][KS];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) w[t][ks] = frag16(W1, (grp * 4 + t) * 16 + frow, D, ks * 32 + kq * 8);
+    float mean, rstd;
+    ln_frags<D>(x, a.ln1_g, a.ln1_b, a.ln1_eps, kq, mean, rstd);
+    if (grp == 0 && r0 + frow < R) {
+        bf16_t* Y = static_cast<bf16_t*>(a.y);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) *reinterpret_cast<bf16x8*>(Y + (int64_t)(r0 + frow) * D + ks * 32 + kq * 8) = x[ks];
+        if (kq == 0) { a.mean1[r0 + frow] = mean; a.rstd1[r0 + frow] = rstd; }
+    }
+    bf16_t* A = static_cast<bf16_t*>(a.a);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x[ks], w[t][ks], acc, 0, 0, 0);
+        const int col = (grp * 4 + t) * 16 + frow;
+        const float b = a.b1[col];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int rr = r0 + kq * 4 + r;
+            if (rr < R) A[(int64_t)rr * H + col] = f32_to_bf16(fmaxf(acc[r] + b, 0.f));
+        }
+    }
+}
+
+template <int D, int H>
+__global__ __launch_bounds__(64) void tail_mlp2_kernel(const focus_slot_tail_args a) {
+    constexpr int KS = H / 32;
+    const int lane = threadIdx.x, frow = lane & 15, kq = lane >> 4;
+    const int nt = blockIdx.x, r0 = blockIdx.y * ROWS, R = a.R;
+    const int64_t row = min(r0 + frow, R - 1);
+    const bf16_t* A = static_cast<const bf16_t*>(a.a);
+    const bf16_t* W2 = static_cast<const bf16_t*>(a.w2);
+    const bf16_t* HN = static_cast<const bf16_t*>(a.hn);
+    bf16x8 x[KS], w[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        x[ks] = frag16(A, row, H, ks * 32 + kq * 8);
+        w[ks] = frag16(W2, nt * 16 + frow, H, ks * 32 + kq * 8);
+    }
+    const int col = nt * 16 + frow;
+    float res[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) res[r] = bf16_to_f32(HN[(int64_t)min(r0 + kq * 4 + r, R - 1) * D + col]);
+    // all 48 fragment loads in flight together (one round trip): left alone hipcc interleaves load and MFMA in 58 registers,
+    // i.e. four dependent round trips for a 3 us kernel
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) { asm volatile("" : "+v"(x[ks])); asm volatile("" : "+v"(w[ks])); }
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x[ks], w[ks], acc, 0, 0, 0);
+    const float b = a.b2[col];
+    bf16_t* S = static_cast<bf16_t*>(a.s);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int rr = r0 + kq * 4 + r;
+        if (rr < R) S[(int64_t)rr * D + col] = f32_to_bf16(acc[r] + b + res[r]);
+    }
+}
+
+template <int D>
+__global__ __launch_bounds__(64) void tail_q_kernel(const focus_slot_tail_args a, const bf16_t* __restrict__ cur) {
+    constexpr int KS = D / 32;
+    const int lane = threadIdx.x, frow = lane & 15, kq = lane >> 4;
+    const int nt = blockIdx.x, r0 = blockIdx.y * ROWS, R = a.R;
+    const int64_t row = min(r0 + frow, R - 1);
+    const bf16_t* Wq = static_cast<const bf16_t*>(a.wq);
+    bf16x8 x[KS], w[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) { x[ks] = frag16(cur, row, D, ks * 32 + kq * 8); w[ks] = frag16(Wq, nt * 16 + frow, D, ks * 32 + kq * 8); }
+    float mean, rstd;
+    ln_frags<D>(x, a.ln2_g, a.ln2_b, a.ln2_eps, kq, mean, rstd);
+    if (nt == 0 && r0 + frow < R) {
+        bf16_t* SN = static_cast<bf16_t*>(a.sn);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) *reinterpret_cast<bf16x8*>(SN + (int64_t)(r0 + frow) * D + ks * 32 + kq * 8) = x[ks];
+        if (kq == 0) { a.mean2[r0 + frow] = mean; a.rstd2[r0 + frow] = rstd; }
+    }
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x[ks], w[ks], acc, 0, 0, 0);
+    bf16_t* Q = static_cast<bf16_t*>(a.q);
+    const int col = nt * 16 + frow;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int rr = r0 + kq * 4 + r;
+        if (rr < R) Q[(int64_t)rr * D + col] = f32_to_bf16(acc[r]);
+    }
+}
+
+template <int D, int H>
+int launch_tail_staged(const focus_slot_tail_args& a, hipStream_t s) {
+    const int rb = (a.R + ROWS - 1) / ROWS;
+    const bf16_t* cur = static_cast<const bf16_t*>(a.h);
+    if (a.do_gru) {
+        hipLaunchKernelGGL((tail_gru_kernel<D>), dim3(D / 16, rb), dim3(64), 0, s, a);
+        cur = static_cast<const bf16_t*>(a.hn);
+        if (a.do_mlp) {
+            hipLaunchKernelGGL((tail_mlp1_kernel<D, H>), dim3(H / 64, rb), dim3(64), 0, s, a);
+            hipLaunchKernelGGL((tail_mlp2_kernel<D, H>), dim3(D / 16, rb), dim3(64), 0, s, a);
+            cur = static_cast<const bf16_t*>(a.s);
+        }
+    }
+    if (a.do_q) hipLaunchKernelGGL((tail_q_kernel<D>), dim3(D / 16, rb), dim3(64), 0, s, a, cur);
+    FOCUS_CHECK_LAUNCH();
+    return FOCUS_OK;
+}
+
 // ---- backward -------------------------------------------------------------------------------------------------
 // The same chain run backwards on the same 16 rows per workgroup, against the TRANSPOSED bf16 weight copies ([in][out]: the
 // dX products are then the same act[16][KIN] . W'[NOUT][KIN]^T form and stream through the same ring):
@@ -552,6 +781,10 @@ extern "C" int focus_slot_tail_fwd(const focus_slot_tail_args* args, void* strea
     if (a.do_mlp && (!a.do_gru || !a.ln1_g || !a.ln1_b || !a.w1 || !a.b1 || !a.w2 || !a.b2 || !a.y || !a.mean1 || !a.rstd1 || !a.a || !a.s))
         return FOCUS_ERR_NULL;
     if (a.do_q && (!a.ln2_g || !a.ln2_b || !a.wq || !a.sn || !a.mean2 || !a.rstd2 || !a.q)) return FOCUS_ERR_NULL;
+    // the right-sized launches by default (STEVE slot update, whole-step graph: 17.5 -> 16.2 ms; graphed product loop 20.5 ->
+    // 19.2 ms; eager unchanged within its noise); FOCUS_SLOT_TAIL_STAGED=0: the one-workgroup-per-16-rows kernel
+    static const int staged = getenv("FOCUS_SLOT_TAIL_STAGED") ? atoi(getenv("FOCUS_SLOT_TAIL_STAGED")) : 1;
+    if (staged) return launch_tail_staged<192, 768>(a, static_cast<hipStream_t>(stream));
     return launch_tail_fwd<192, 768>(a, static_cast<hipStream_t>(stream));
 }
 

@@ -448,6 +448,7 @@ def test_graphed_slot_update_training_steps_equal_eager_bit_for_bit(dropout):
         if graphed:
             assert len(m._savi_graphs) == 1
     (l0, p0), (l0b, p0b), (l1, p1) = results
+    conv = lambda n: "dvae." in n or ".cnn." in n or ".pos." in n       # parameters whose gradients come from MIOpen convolutions
     # Two EAGER runs first: they give the run-to-run spread of the step itself.  Sums formed with fp32 atomics (MIOpen's
     # convolution weight gradients; the split-K fallback of the narrow layers of this reduced model) depend on the order in which
     # workgroups retire, which varies from run to run -- more so since part of the step runs on a side stream -- and Adam turns
@@ -465,7 +466,7 @@ def test_graphed_slot_update_training_steps_equal_eager_bit_for_bit(dropout):
             assert torch.equal(p0[n], p1[n]), n
             continue
         spread = float((p0[n] - p0b[n]).abs().max())
-        if spread == 0.0:
+        if spread == 0.0 and not conv(n):                             # (MIOpen's gradients may agree twice and still differ a third time)
             assert torch.equal(p0[n], p1[n]), n
             exact += 1
         else:
