@@ -783,7 +783,8 @@ extern "C" int focus_slot_tail_fwd(const focus_slot_tail_args* args, void* strea
     if (a.do_q && (!a.ln2_g || !a.ln2_b || !a.wq || !a.sn || !a.mean2 || !a.rstd2 || !a.q)) return FOCUS_ERR_NULL;
     // the right-sized launches by default (STEVE slot update, whole-step graph: 17.5 -> 16.2 ms; graphed product loop 20.5 ->
     // 19.2 ms; eager unchanged within its noise); FOCUS_SLOT_TAIL_STAGED=0: the one-workgroup-per-16-rows kernel
-    static const int staged = getenv("FOCUS_SLOT_TAIL_STAGED") ? atoi(getenv("FOCUS_SLOT_TAIL_STAGED")) : 1;
+    const char* env = getenv("FOCUS_SLOT_TAIL_STAGED");             // (read per call: tests compare the two forms in one process)
+    const int staged = env ? atoi(env) : 1;
     if (staged) return launch_tail_staged<192, 768>(a, static_cast<hipStream_t>(stream));
     return launch_tail_fwd<192, 768>(a, static_cast<hipStream_t>(stream));
 }

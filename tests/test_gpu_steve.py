@@ -474,7 +474,8 @@ def test_graphed_slot_update_training_steps_equal_eager_bit_for_bit(dropout):
     assert exact >= len(p0) // 4, (exact, len(p0))                  # a good part of the model IS reproducible bit for bit
 
 
-def test_fused_slot_tail_matches_the_unfused_loop(monkeypatch):
+@pytest.mark.parametrize("staged", [1, 0])
+def test_fused_slot_tail_matches_the_unfused_loop(monkeypatch, staged):
     """ops.slot_tail (csrc/slot_tail.hip: GRU -> LN -> MLP -> LN -> q per iteration in one launch) against the same
     SlotAttentionVideo with FOCUS_SLOT_TAIL=0 (eight launches per iteration): slots, attention maps, input gradient and every
     parameter gradient.  The two differ only in where bf16 roundings fall (the fused kernel rounds less often)."""
@@ -488,6 +489,8 @@ def test_fused_slot_tail_matches_the_unfused_loop(monkeypatch):
     x0 = torch.randn(B, T, N, D, device=d, generator=g).bfloat16()
     noise = torch.randn(B, K, D, device=d, generator=g)
     cs = torch.randn(B, T, K, D, device=d, generator=g)
+
+    monkeypatch.setenv("FOCUS_SLOT_TAIL_STAGED", str(staged))         # 1: four right-sized launches, 0: one launch per tail
 
     def run(fused, fp32=False):
         monkeypatch.setenv("FOCUS_SLOT_TAIL", "1" if fused else "0")
