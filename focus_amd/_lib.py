@@ -48,7 +48,7 @@ class SlotTailBwdArgs(ctypes.Structure):
     _fields_ = ([(n, ctypes.c_int32) for n in ("R", "D", "H", "do_gru", "do_mlp", "do_q")] +
                 [(n, ctypes.c_void_p) for n in ("dout", "dq", "h", "g", "hn", "a", "cur", "mean1", "rstd1", "mean2", "rstd2",
                                                 "ln1_g", "ln2_g", "w_ih_t", "w_hh_t", "w1_t", "w2_t", "wq_t", "dupd", "dh", "ds",
-                                                "dz", "dg", "part1", "part2")])
+                                                "dz", "dg", "part1", "part2", "ws_dsn", "ws_dy1", "ws_res")])
 
 
 class FlashArgs(ctypes.Structure):

@@ -742,6 +742,270 @@ __global__ __launch_bounds__(256) void slot_tail_bwd_kernel(const focus_slot_tai
     }
 }
 
+// ---- the backward as five right-sized launches ---------------------------------------------------------------
+//   bq   : (row block, 16 columns)        dsn = dq . Wq
+//   bln2 : (row block, 64 hidden columns) ds = LN_slots'(dsn) + dout (redundantly per workgroup), dz = (ds . W2) * (a > 0)
+//   bfc1 : (row block, 16 columns)        dy1 = dz . W1   (K = 768)
+//   bgate: (row block, 16 hidden units)   dhn = LN_mlp'(dy1) + ds (redundantly), gate gradients of those units, z * dhn
+//   bgru : (2 x row block x 16 columns)   dupd = dgi . W_ih ;  dh = dgh . W_hh + z * dhn
+// Same outputs as slot_tail_bwd_kernel (+ three [R, D] scratch matrices between the launches).
+template <int D>
+__device__ __forceinline__ void ln_bwd_frags(const bf16x8 (&dy)[D / 32], const bf16x8 (&x)[D / 32], const bf16x8* res,
+                                             const float* __restrict__ gamma, float mean, float rstd, int kq, bool live, int frow,
+                                             bf16x8 (&out)[D / 32], float* partial_g, float* partial_b) {
+    constexpr int KS = D / 32;
+    float xh[KS][8], dg[KS][8];
+    float c1 = 0.f, c2 = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            xh[ks][e] = ((float)x[ks][e] - mean) * rstd;
+            dg[ks][e] = (float)dy[ks][e] * gamma[ks * 32 + kq * 8 + e];
+            c1 += dg[ks][e];
+            c2 += dg[ks][e] * xh[ks][e];
+        }
+    c1 += __shfl_xor(c1, 16, 64); c1 += __shfl_xor(c1, 32, 64);
+    c2 += __shfl_xor(c2, 16, 64); c2 += __shfl_xor(c2, 32, 64);
+    c1 *= 1.f / D; c2 *= 1.f / D;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float v = (dg[ks][e] - c1 - xh[ks][e] * c2) * rstd;
+            if (res) v += (float)res[ks][e];
+            out[ks][e] = (__bf16)v;
+        }
+    if (partial_g) {
+        // column sums over the wave's 16 rows (the lanes that share kq): rows past R contribute nothing
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float a = live ? (float)dy[ks][e] * xh[ks][e] : 0.f, b = live ? (float)dy[ks][e] : 0.f;
+#pragma unroll
+                for (int o = 1; o < 16; o <<= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
+                if (frow == 0) { partial_g[ks * 32 + kq * 8 + e] = a; partial_b[ks * 32 + kq * 8 + e] = b; }
+            }
+    }
+}
+
+template <int D>
+__global__ __launch_bounds__(64) void tailb_q_kernel(const focus_slot_tail_bwd_args a) {
+    constexpr int KS = D / 32;
+    const int lane = threadIdx.x, frow = lane & 15, kq = lane >> 4;
+    const int nt = blockIdx.x, r0 = blockIdx.y * ROWS, R = a.R;
+    const int64_t row = min(r0 + frow, R - 1);
+    const bf16_t* DQ = static_cast<const bf16_t*>(a.dq);
+    const bf16_t* W = static_cast<const bf16_t*>(a.wq_t);
+    bf16x8 x[KS], w[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) { x[ks] = frag16(DQ, row, D, ks * 32 + kq * 8); w[ks] = frag16(W, nt * 16 + frow, D, ks * 32 + kq * 8); }
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x[ks], w[ks], acc, 0, 0, 0);
+    bf16_t* O = static_cast<bf16_t*>(a.ws_dsn);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int rr = r0 + kq * 4 + r;
+        if (rr < R) O[(int64_t)rr * D + nt * 16 + frow] = f32_to_bf16(acc[r]);
+    }
+}
+
+template <int D, int H>
+__global__ __launch_bounds__(64) void tailb_ln2_kernel(const focus_slot_tail_bwd_args a) {
+    constexpr int KS = D / 32;
+    const int lane = threadIdx.x, frow = lane & 15, kq = lane >> 4;
+    const int grp = blockIdx.x, r0 = blockIdx.y * ROWS, R = a.R, nblk = gridDim.y;
+    const bool live = r0 + frow < R;
+    const int64_t row = min(r0 + frow, R - 1);
+    bf16x8 ds[KS];
+    {
+        const bf16_t* DO = static_cast<const bf16_t*>(a.dout);
+        bf16x8 res[KS];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            if (DO) res[ks] = frag16(DO, row, D, ks * 32 + kq * 8);
+            else
+#pragma unroll
+                for (int e = 0; e < 8; ++e) res[ks][e] = (__bf16)0.f;
+        }
+        if (a.do_q) {
+            const bf16_t* DSN = static_cast<const bf16_t*>(a.ws_dsn);
+            const bf16_t* CUR = static_cast<const bf16_t*>(a.cur);
+            bf16x8 dy[KS], x[KS];
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) { dy[ks] = frag16(DSN, row, D, ks * 32 + kq * 8); x[ks] = frag16(CUR, row, D, ks * 32 + kq * 8); }
+            const bool first = grp == 0;
+            ln_bwd_frags<D>(dy, x, res, a.ln2_g, a.mean2[row], a.rstd2[row], kq, live, frow, ds,
+                            first ? a.part2 + (int64_t)blockIdx.y * D : nullptr,
+                            first ? a.part2 + (int64_t)(nblk + blockIdx.y) * D : nullptr);
+        } else {
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) ds[ks] = res[ks];
+        }
+    }
+    if (grp == 0 && live && a.ds) {
+        bf16_t* DS = static_cast<bf16_t*>(a.ds);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) *reinterpret_cast<bf16x8*>(DS + (int64_t)(r0 + frow) * D + ks * 32 + kq * 8) = ds[ks];
+    }
+    if (!a.do_mlp) return;
+    const bf16_t* W = static_cast<const bf16_t*>(a.w2_t);
+    const bf16_t* A = static_cast<const bf16_t*>(a.a);
+    bf16_t* DZ = static_cast<bf16_t*>(a.dz);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int col = (grp * 4 + t) * 16 + frow;
+        bf16x8 w[KS];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) w[ks] = frag16(W, col, D, ks * 32 + kq * 8);
+        bf16_t av[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) av[r] = A[(int64_t)min(r0 + kq * 4 + r, R - 1) * H + col];
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ds[ks], w[ks], acc, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int rr = r0 + kq * 4 + r;
+            if (rr < R) DZ[(int64_t)rr * H + col] = f32_to_bf16(bf16_to_f32(av[r]) > 0.f ? acc[r] : 0.f);
+        }
+    }
+}
+
+template <int D, int H>
+__global__ __launch_bounds__(64) void tailb_fc1_kernel(const focus_slot_tail_bwd_args a) {
+    constexpr int KS = H / 32;
+    const int lane = threadIdx.x, frow = lane & 15, kq = lane >> 4;
+    const int nt = blockIdx.x, r0 = blockIdx.y * ROWS, R = a.R;
+    const int64_t row = min(r0 + frow, R - 1);
+    const bf16_t* DZ = static_cast<const bf16_t*>(a.dz);
+    const bf16_t* W = static_cast<const bf16_t*>(a.w1_t);
+    bf16x8 x[KS], w[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) { x[ks] = frag16(DZ, row, H, ks * 32 + kq * 8); w[ks] = frag16(W, nt * 16 + frow, H, ks * 32 + kq * 8); }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) { asm volatile("" : "+v"(x[ks])); asm volatile("" : "+v"(w[ks])); }
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x[ks], w[ks], acc, 0, 0, 0);
+    bf16_t* O = static_cast<bf16_t*>(a.ws_dy1);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int rr = r0 + kq * 4 + r;
+        if (rr < R) O[(int64_t)rr * D + nt * 16 + frow] = f32_to_bf16(acc[r]);
+    }
+}
+
+template <int D>
+__global__ __launch_bounds__(64) void tailb_gate_kernel(const focus_slot_tail_bwd_args a) {
+    constexpr int KS = D / 32, G3 = 3 * D, PD = D + 8;
+    __shared__ __attribute__((aligned(16))) bf16_t sD[ROWS * PD];          // dhn rows: A-fragment layout in, (row, unit) layout out
+    const int lane = threadIdx.x, frow = lane & 15, kq = lane >> 4;
+    const int jt = blockIdx.x, r0 = blockIdx.y * ROWS, R = a.R, nblk = gridDim.y;
+    const bool live = r0 + frow < R;
+    const int64_t row = min(r0 + frow, R - 1);
+    bf16x8 dhn[KS];
+    {
+        const bf16_t* DS = static_cast<const bf16_t*>(a.ds ? a.ds : a.dout);       // the gradient arriving at h'
+        bf16x8 res[KS];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            if (DS) res[ks] = frag16(DS, row, D, ks * 32 + kq * 8);
+            else
+#pragma unroll
+                for (int e = 0; e < 8; ++e) res[ks][e] = (__bf16)0.f;
+        }
+        if (a.do_mlp) {
+            const bf16_t* DY = static_cast<const bf16_t*>(a.ws_dy1);
+            const bf16_t* HN = static_cast<const bf16_t*>(a.hn);
+            bf16x8 dy[KS], x[KS];
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) { dy[ks] = frag16(DY, row, D, ks * 32 + kq * 8); x[ks] = frag16(HN, row, D, ks * 32 + kq * 8); }
+            const bool first = jt == 0;
+            ln_bwd_frags<D>(dy, x, res, a.ln1_g, a.mean1[row], a.rstd1[row], kq, live, frow, dhn,
+                            first ? a.part1 + (int64_t)blockIdx.y * D : nullptr,
+                            first ? a.part1 + (int64_t)(nblk + blockIdx.y) * D : nullptr);
+        } else {
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) dhn[ks] = res[ks];
+        }
+    }
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) *reinterpret_cast<bf16x8*>(sD + frow * PD + ks * 32 + kq * 8) = dhn[ks];
+    __syncthreads();
+    const int j = jt * 16 + frow;
+    const bf16_t* G = static_cast<const bf16_t*>(a.g);
+    const bf16_t* Hs = static_cast<const bf16_t*>(a.h);
+    bf16_t* DG = static_cast<bf16_t*>(a.dg);
+    bf16_t* RES = static_cast<bf16_t*>(a.ws_res);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int rl = kq * 4 + r, rr = r0 + rl;
+        if (rr >= R) continue;
+        const bf16_t* ga = G + (int64_t)rr * G3;
+        const bf16_t* gb = G + ((int64_t)R + rr) * G3;
+        const float hn_ = bf16_to_f32(gb[2 * D + j]);
+        const float rg = sigm_(bf16_to_f32(ga[j]) + bf16_to_f32(gb[j]));
+        const float zg = sigm_(bf16_to_f32(ga[D + j]) + bf16_to_f32(gb[D + j]));
+        const float ng = tanhf(bf16_to_f32(ga[2 * D + j]) + rg * hn_);
+        const float hv = bf16_to_f32(Hs[(int64_t)rr * D + j]), gd = bf16_to_f32(sD[rl * PD + j]);
+        const float dn = gd * (1.f - zg), dzg = gd * (hv - ng);
+        const float dpre_n = dn * (1.f - ng * ng);
+        const float dr = dpre_n * hn_;
+        const bf16_t pr = f32_to_bf16(dr * rg * (1.f - rg)), pz = f32_to_bf16(dzg * zg * (1.f - zg));
+        const bf16_t pn = f32_to_bf16(dpre_n), pnr = f32_to_bf16(dpre_n * rg);
+        bf16_t* o0 = DG + (int64_t)rr * G3;
+        bf16_t* o1 = DG + ((int64_t)R + rr) * G3;
+        o0[j] = pr; o0[D + j] = pz; o0[2 * D + j] = pn;
+        o1[j] = pr; o1[D + j] = pz; o1[2 * D + j] = pnr;
+        RES[(int64_t)rr * D + j] = f32_to_bf16(gd * zg);
+    }
+}
+
+template <int D>
+__global__ __launch_bounds__(64) void tailb_gru_kernel(const focus_slot_tail_bwd_args a) {
+    constexpr int G3 = 3 * D, KS = G3 / 32;
+    const int lane = threadIdx.x, frow = lane & 15, kq = lane >> 4;
+    const int which = blockIdx.x / (D / 16), nt = blockIdx.x % (D / 16), r0 = blockIdx.y * ROWS, R = a.R;
+    const int64_t row = min(r0 + frow, R - 1);
+    const bf16_t* DG = static_cast<const bf16_t*>(a.dg) + (int64_t)which * R * G3;
+    const bf16_t* W = static_cast<const bf16_t*>(which ? a.w_hh_t : a.w_ih_t);
+    bf16x8 x[KS], w[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) { x[ks] = frag16(DG, row, G3, ks * 32 + kq * 8); w[ks] = frag16(W, nt * 16 + frow, G3, ks * 32 + kq * 8); }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) { asm volatile("" : "+v"(x[ks])); asm volatile("" : "+v"(w[ks])); }
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x[ks], w[ks], acc, 0, 0, 0);
+    bf16_t* O = static_cast<bf16_t*>(which ? a.dh : a.dupd);
+    const bf16_t* RES = static_cast<const bf16_t*>(a.ws_res);
+    const int col = nt * 16 + frow;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int rr = r0 + kq * 4 + r;
+        if (rr < R) O[(int64_t)rr * D + col] = f32_to_bf16(acc[r] + (which ? bf16_to_f32(RES[(int64_t)rr * D + col]) : 0.f));
+    }
+}
+
+template <int D, int H>
+int launch_tail_bwd_staged(const focus_slot_tail_bwd_args& a, hipStream_t s) {
+    const int rb = (a.R + ROWS - 1) / ROWS;
+    if (a.do_q) hipLaunchKernelGGL((tailb_q_kernel<D>), dim3(D / 16, rb), dim3(64), 0, s, a);
+    if (a.do_q || a.do_mlp) hipLaunchKernelGGL((tailb_ln2_kernel<D, H>), dim3(a.do_mlp ? H / 64 : 1, rb), dim3(64), 0, s, a);
+    if (a.do_mlp) hipLaunchKernelGGL((tailb_fc1_kernel<D, H>), dim3(D / 16, rb), dim3(64), 0, s, a);
+    if (a.do_gru) {
+        hipLaunchKernelGGL((tailb_gate_kernel<D>), dim3(D / 16, rb), dim3(64), 0, s, a);
+        hipLaunchKernelGGL((tailb_gru_kernel<D>), dim3(2 * (D / 16), rb), dim3(64), 0, s, a);
+    }
+    FOCUS_CHECK_LAUNCH();
+    return FOCUS_OK;
+}
+
 template <int D, int H>
 int launch_tail_bwd(const focus_slot_tail_bwd_args& a, hipStream_t s) {
     constexpr size_t lds = (size_t)(4 * ROWS * (D + 8) + 2 * ROWS * (3 * D + 8)) * 2 + 2 * ROWS * 4 + ROWS * (H / 8) +
@@ -801,5 +1065,17 @@ extern "C" int focus_slot_tail_bwd(const focus_slot_tail_bwd_args* args, void* s
     if (a.do_mlp && (!a.do_gru || !a.a || !a.hn || !a.mean1 || !a.rstd1 || !a.ln1_g || !a.w1_t || !a.w2_t || !a.ds || !a.dz || !a.part1))
         return FOCUS_ERR_NULL;
     if (a.do_gru && (!a.g || !a.h || !a.w_ih_t || !a.w_hh_t || !a.dg || !a.dupd)) return FOCUS_ERR_NULL;
+    const char* env = getenv("FOCUS_SLOT_TAIL_STAGED");             // 1 (default): five right-sized launches; 0: one launch
+    if (env ? atoi(env) : 1) {
+        if ((a.do_q && !a.ws_dsn) || (a.do_mlp && !a.ws_dy1) || (a.do_gru && !a.ws_res)) return FOCUS_ERR_WORKSPACE;
+        if (!a.do_gru) {
+            // the query-only application (a frame's first call): dh = LN_slots'(dq . Wq) + dout, written where ds would go
+            if (!a.do_q) return FOCUS_ERR_SHAPE;
+            focus_slot_tail_bwd_args b = a;
+            b.ds = a.dh;
+            return launch_tail_bwd_staged<192, 768>(b, static_cast<hipStream_t>(stream));
+        }
+        return launch_tail_bwd_staged<192, 768>(a, static_cast<hipStream_t>(stream));
+    }
     return launch_tail_bwd<192, 768>(a, static_cast<hipStream_t>(stream));
 }

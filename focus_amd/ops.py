@@ -2398,6 +2398,10 @@ def _slot_tail_backward_fused(ctx, dout, dq, upd, h, w_ih, w_hh, g1, w1, w2, g2,
         dg, dupd = new(2, R, 3 * D), new(R, D)
         keep += [wit, wht]
         a.g, a.w_ih_t, a.w_hh_t, a.dg, a.dupd = sv["g"].data_ptr(), wit.data_ptr(), wht.data_ptr(), dg.data_ptr(), dupd.data_ptr()
+    # [R, D] scratch between the launches of the staged form: dsn | dy1 | z * dhn
+    ws = new(3, R, D)
+    keep.append(ws)
+    a.ws_dsn, a.ws_dy1, a.ws_res = ws[0].data_ptr(), ws[1].data_ptr(), ws[2].data_ptr()
     _lib.check(L.focus_slot_tail_bwd(ctypes.byref(a), _stream()), "slot_tail_bwd")
     grads = {}
 
@@ -2425,9 +2429,10 @@ def _slot_tail_backward_fused(ctx, dout, dq, upd, h, w_ih, w_hh, g1, w1, w2, g2,
 
 
 _SlotTailFn._backward_fused = staticmethod(_slot_tail_backward_fused)
-# Measured (profiles/r03 notes in DESIGN.md 0): one workgroup per 16 rows streams 1.1 MB of weights by itself -- 35 us per
-# call against ~26 us for the five small launches it replaces, which spread their weight reads over many CUs.  It wins only
-# where launches are the cost (eager: 36 -> 34 ms per step) and loses under graph replay (17.4 -> 18.7 ms): off by default.
+# Measured: neither form of focus_slot_tail_bwd beats the five small launches of the composed backward under
+# graph replay -- one workgroup per 16 rows streams 1.1 MB of weights by itself (35 us per call; whole step 17.4 -> 18.7 ms),
+# the five right-sized launches (FOCUS_SLOT_TAIL_STAGED=1, the default form) redo the LayerNorm backward per column tile and
+# wait on scalar gate loads (16.0 -> 17.0 ms).  Both win only where launches are the cost (eager: 38 -> 35 ms).  Off by default.
 _SLOT_TAIL_BWD = _os.environ.get("FOCUS_SLOT_TAIL_BWD", "0") != "0"
 
 

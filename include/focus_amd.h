@@ -445,6 +445,7 @@ typedef struct focus_slot_tail_bwd_args {
     const float* ln1_g; const float* ln2_g;
     const void* w_ih_t; const void* w_hh_t; const void* w1_t; const void* w2_t; const void* wq_t;
     void* dupd; void* dh; void* ds; void* dz; void* dg; float* part1; float* part2;
+    void* ws_dsn; void* ws_dy1; void* ws_res;     /* [R, D] bf16 scratch between the launches of the staged form (do_q / do_mlp / do_gru) */
 } focus_slot_tail_bwd_args;
 int focus_slot_tail_bwd_blocks(int R);
 int focus_slot_tail_bwd(const focus_slot_tail_bwd_args* args, void* stream);
