@@ -83,8 +83,9 @@ def host_cores():
 
 def cpu_baseline(model, cfg, seconds_budget=75.0):
     """the CPU oracle, fp32, B=2 clips fwd+bwd on this host: 1 warm-up + 3 timed iterations with 32 threads
-    (the setting that was fastest on the shared GPU-box host) AND, budget permitting, 1 warm-up + 3 timed with one thread
-    per physical core; `value` is the better of the two, both are reported.  Plus a 1-thread figure on one
+    (the setting that was fastest on the shared GPU-box host) AND, budget permitting, ONE iteration with one thread per
+    physical core (consistently the slower setting, so one sample is enough); `value` is the better of the two, both
+    are reported.  Plus a 1-thread figure on one
     TrajectoryAttentionBlock of the same sample (the whole model on one thread would take minutes)."""
     import torch
     from focus_amd.train import synthetic_batch
@@ -101,11 +102,12 @@ def cpu_baseline(model, cfg, seconds_budget=75.0):
     t_all = time.time()
     state = {"logits": None}
 
-    def run(threads, budget_left):
-        """-> (mean seconds of the timed iterations, how many were timed) with `threads` threads; 1 warm-up first."""
+    def run(threads, budget_left, iters=4):
+        """-> (mean seconds of the timed iterations, how many were timed) with `threads` threads; 1 warm-up first
+        (with iters=1 the single iteration is the sample: an upper bound on the time, allocator warm-up included)."""
         torch.set_num_threads(threads)
         times = []
-        for it in range(4):
+        for it in range(iters):
             t0 = time.time()
             for p in params.values():
                 p.grad = None
@@ -123,7 +125,9 @@ def cpu_baseline(model, cfg, seconds_budget=75.0):
     best_t, best_c = t32, c32
     call = max(1, min(phys, nthreads))
     if call != c32 and time.time() - t_all + 2.5 * t32 < seconds_budget:
-        tp, npn = run(call, seconds_budget)
+        # one thread per core has been 3-4x SLOWER than 32 threads on every GPU-box host so far (oversubscribed
+        # small-tensor ops): one iteration is enough to show it, a warm-up + 3 more would add a minute to the bench
+        tp, npn = run(call, seconds_budget, iters=1)
         runs["threads_%d" % call] = {"clips_per_s": round(Bc / tp, 4), "timed_iterations": npn}
         if tp < best_t:
             best_t, best_c = tp, call
