@@ -1908,13 +1908,30 @@ def embed_assemble(patch, cls, pos, temp):
     return _EmbedAssembleFn.apply(patch, cls.contiguous(), pos.contiguous(), temp.contiguous())
 
 
+def rows_ok(t):
+    """[R, V] rows the one-workgroup-per-row passes of gumbel.hip take: dense, fp32 or bf16, V % 8 == 0, V <= 8192."""
+    return (t.is_cuda and t.dim() == 2 and t.is_contiguous() and t.dtype in (torch.float32, torch.bfloat16)
+            and t.data_ptr() % 16 == 0 and bool(_lib.lib().focus_rows_ok(t.shape[0], t.shape[1], _dt(t))))
+
+
 class _XentLsFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, logits, target, smoothing):
         _need_gpu(logits, target)
-        logits = logits.float().contiguous()
+        ctx.rows = rows_ok(logits)
         R, Ncls = logits.shape
         loss_rows = torch.empty(R, device=logits.device, dtype=torch.float32)
+        if ctx.rows:
+            # fp32 or bf16 logits as they are; the backward rebuilds softmax from the row log-sum-exp instead of keeping an
+            # fp32 [R, V] gradient alive (STEVE's decoder head: 196608 x 4096 per 8 clips)
+            target = target.contiguous()
+            lse = torch.empty(R, device=logits.device, dtype=torch.float32)
+            _lib.check(_lib.lib().focus_xent_rows_fwd(_p(logits), _p(target), _p(loss_rows), _p(lse), R, Ncls, smoothing,
+                                                      _dt(logits), _stream()), "xent_rows_fwd")
+            ctx.save_for_backward(logits, target, lse)
+            ctx.smoothing = smoothing
+            return loss_rows.mean()
+        logits = logits.float().contiguous()
         dlog = torch.empty_like(logits)
         _lib.check(_lib.lib().focus_xent_ls(_p(logits), _p(target.contiguous()), _p(loss_rows), _p(dlog), R, Ncls,
                                             smoothing, _stream()), "xent_ls")
@@ -1923,12 +1940,80 @@ class _XentLsFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
+        if ctx.rows:
+            logits, target, lse = ctx.saved_tensors
+            dlog = torch.empty_like(logits)
+            g = g.to(torch.float32).contiguous()
+            _lib.check(_lib.lib().focus_xent_rows_bwd(_p(logits), _p(target), _p(lse), _p(g), _p(dlog), logits.shape[0],
+                                                      logits.shape[1], ctx.smoothing, _dt(logits), _stream()), "xent_rows_bwd")
+            return dlog, None, None
         (dlog,) = ctx.saved_tensors
         return dlog * g, None, None
 
 
 def label_smoothing_ce(logits, target, smoothing=0.1):
     return _XentLsFn.apply(logits, target, smoothing)
+
+
+# --------------------------------------------------------------------------------------------------
+# Gumbel-softmax over the dVAE vocabulary (steve.py:262-271, STEVE/utils.py:47-61)
+# --------------------------------------------------------------------------------------------------
+class _GumbelFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, tau, hard, e_soft, e_hard, want_target, seed, out_dtype):
+        _need_gpu(x)
+        R, V = x.shape
+        dev = x.device
+        gen = e_soft is None
+        if gen:
+            # the draws are made in the kernel from this seed (and made again by the backward); the seed itself comes from
+            # torch's generator, on the device, so that a captured step draws fresh noise on every replay
+            if seed is None:
+                seed = torch.randint(-2 ** 31, 2 ** 31 - 1, (4,), device=dev, dtype=torch.int32)
+            assert seed.dtype == torch.int32 and seed.numel() == 4 and seed.is_cuda and seed.is_contiguous()
+            e_hard = None
+        else:
+            e_soft = e_soft.to(torch.float32).contiguous()
+            e_hard = e_hard.to(torch.float32).contiguous() if want_target else None
+        z = torch.empty_like(x, dtype=out_dtype or x.dtype)
+        target = torch.empty(R, device=dev, dtype=torch.int64) if want_target else None
+        stats = torch.empty(R, 4, device=dev, dtype=torch.float32)
+        _lib.check(_lib.lib().focus_gumbel_fwd(_p(x), _p(e_soft) if e_soft is not None else None,
+                                               _p(e_hard) if e_hard is not None else None,
+                                               _p(seed) if gen else None, _p(z),
+                                               _p(target) if target is not None else None, _p(stats), R, V, float(tau),
+                                               int(bool(hard)), _dt(x), _dt(z), _stream()), "gumbel_fwd")
+        ctx.save_for_backward(x, stats, *([seed] if gen else [e_soft]))
+        ctx.gen, ctx.tau, ctx.zdtype = gen, float(tau), z.dtype
+        if target is None:
+            return z, None
+        ctx.mark_non_differentiable(target)
+        return z, target
+
+    @staticmethod
+    def backward(ctx, dz, _dtarget):
+        x, stats, noise = ctx.saved_tensors
+        dz = dz.contiguous()
+        if dz.dtype != ctx.zdtype:
+            dz = dz.to(ctx.zdtype)
+        dx = torch.empty_like(x)
+        _lib.check(_lib.lib().focus_gumbel_bwd(_p(x), None if ctx.gen else _p(noise), _p(noise) if ctx.gen else None,
+                                               _p(stats), _p(dz), _p(dx), x.shape[0], x.shape[1], ctx.tau, _dt(x), _dt(dz), _stream()),
+                   "gumbel_bwd")
+        return dx, None, None, None, None, None, None, None
+
+
+def gumbel_softmax_rows(x, tau, hard, e_soft=None, e_hard=None, want_target=True, seed=None, out_dtype=None):
+    """x [R, V] raw logits (rows_ok) -> (z [R, V] in x's dtype -- or bf16 from fp32 logits with out_dtype --, target [R] int64
+    or None).
+
+    z = gumbel_softmax(log_softmax(x), tau, hard) of STEVE/utils.py:47-61; target = the arg-max of the reference's second,
+    hard sample (steve.py:268-269), which is the arg-max of log_softmax(x) + G_hard.  e_soft / e_hard: the Exp(1) draws
+    (both given, e.g. the reference's own in a parity test) or None: drawn in the kernel, regenerated by the backward, from
+    `seed` (int32 [4] on the device: two words per stream; default: drawn from torch's generator)."""
+    assert (e_soft is None) == (e_hard is None) or not want_target, "pass both noise tensors or neither"
+    return _GumbelFn.apply(x, tau, hard, e_soft, e_hard, want_target, seed, out_dtype)
+
 
 
 # --------------------------------------------------------------------------------------------------

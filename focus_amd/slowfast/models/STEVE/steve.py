@@ -331,9 +331,25 @@ class STEVE(nn.Module):
         # ones and an NCHW caller pays a layout transpose before and after every convolution (batched_transpose_32x32: 6 ms of
         # a 162 ms step); the token path wants [B*T, H*W, C] rows anyway.  Shapes, values and state_dict keys are unchanged.
         self.channels_last = os.environ.get("FOCUS_STEVE_CHANNELS_LAST", "1") != "0"
+        # FOCUS_STEVE_CONV_BF16=0: the convolutions in fp32 whatever the compute type; FOCUS_STEVE_ROWS=0: the Gumbel-softmax
+        # passes over the vocabulary as ATen launches
+        self.conv_dtype = torch.bfloat16 if (self.compute_dtype == torch.bfloat16 and
+                                             os.environ.get("FOCUS_STEVE_CONV_BF16", "1") != "0") else None
+        self.fused_rows = os.environ.get("FOCUS_STEVE_ROWS", "1") != "0"
         if self.channels_last:
             self.dvae.to(memory_format=torch.channels_last)
             self.steve_encoder.cnn.to(memory_format=torch.channels_last)
+
+    def _conv(self, stack, x):
+        """A convolution stack (dVAE decoder, CNN encoder; MIOpen) in the step's compute type: bf16 under
+        TRAIN.MIXED_PRECISION -- where the reference's fp16 autocast runs them (steve_train_net.py:95) -- else fp32.  The
+        dVAE ENCODER stays fp32 in both modes: its output are the logits of a 4096-way softmax whose gradient is divided by
+        tau, bf16 gains 8 % on that stack (the vocabulary projection dominates it) and costs a tenth of the gradient's
+        accuracy (tests/test_gpu_steve.py); the sample it feeds the decoder is written in bf16 by the Gumbel kernel."""
+        if self.conv_dtype is None or not x.is_cuda:
+            return stack(x)
+        with torch.autocast("cuda", dtype=self.conv_dtype):
+            return stack(x)
 
     def _frames(self, video):
         """[B,T,C,H,W] -> [B*T,C,H,W] in the memory format the convolutions run in."""
@@ -344,7 +360,7 @@ class STEVE(nn.Module):
     def _slots(self, video, noise=None):
         B, T, C, H, W = video.shape
         enc = self.steve_encoder
-        emb = enc.pos(enc.cnn(self._frames(video)))                                       # B*T, d_model, H_enc, W_enc
+        emb = enc.pos(self._conv(enc.cnn, self._frames(video)))                                       # B*T, d_model, H_enc, W_enc
         H_enc, W_enc = emb.shape[-2:]
         emb_set = emb.permute(0, 2, 3, 1).flatten(start_dim=1, end_dim=2).to(self.compute_dtype)    # B*T, H_enc*W_enc, d_model
         ln = enc.layer_norm
@@ -388,23 +404,39 @@ class STEVE(nn.Module):
         # of an NCHW tensor ATen runs them with its strided "spatial" kernels -- 29 of the 162 ms of kernel time of a training
         # step at 24 x 128 x 128 -- and the same vectors normalised along a contiguous axis take a tenth of that.  Same
         # values; the decoder's 1x1 convolution receives the channels-last view (MIOpen's own layout).
-        z_logits = F.log_softmax(self.dvae.encoder(video_flat).permute(0, 2, 3, 1), dim=-1)   # B*T, H_enc, W_enc, vocab
+        enc_out = self.dvae.encoder(video_flat).permute(0, 2, 3, 1)                       # B*T, H_enc, W_enc, vocab
         last = lambda e: None if e is None else e.permute(0, 2, 3, 1)
-        z_soft = gumbel_softmax(z_logits, tau, hard, dim=-1, noise=last(noise.get("gumbel_soft"))).permute(0, 3, 1, 2)
-        # the hard sample is only ever read through its arg-max (:268-269), which is the arg-max of the perturbed logits:
-        # softmax is monotonic, so no second softmax, one-hot scatter and straight-through sum over 4096 x 1024 x B*T values
-        e_hard = last(noise.get("gumbel_hard"))
-        if e_hard is None:
-            e_hard = torch.empty_like(z_logits).exponential_()
-        with torch.no_grad():
-            target = (z_logits - (e_hard + torch.finfo(z_logits.dtype).tiny).log()).argmax(dim=-1).flatten(start_dim=1)
+        e_soft, e_hard = last(noise.get("gumbel_soft")), last(noise.get("gumbel_hard"))
+        rows = enc_out.reshape(-1, self.vocab_size)                                       # a view of channels-last logits
+        if self.fused_rows and (e_soft is None) == (e_hard is None) and ops.rows_ok(rows):
+            # log_softmax, both Gumbel perturbations, the relaxed sample and the hard sample's arg-max in one pass over the
+            # rows (csrc/gumbel.hip); noise not given = drawn in the kernel
+            flat = lambda e: None if e is None else e.reshape(-1, self.vocab_size)
+            z_rows, target = ops.gumbel_softmax_rows(rows, tau, hard, flat(e_soft), flat(e_hard),
+                                                     out_dtype=self.conv_dtype)
+            z_soft = z_rows.view(enc_out.shape).permute(0, 3, 1, 2)
+            target = target.view(enc_out.shape[0], -1)
+        else:
+            z_logits = F.log_softmax(enc_out.float(), dim=-1)
+            z_soft = gumbel_softmax(z_logits, tau, hard, dim=-1, noise=e_soft).permute(0, 3, 1, 2)
+            # the hard sample is only ever read through its arg-max (:268-269), which is the arg-max of the perturbed logits:
+            # softmax is monotonic, so no second softmax, one-hot scatter and straight-through sum over 4096 x 1024 x B*T values
+            if e_hard is None:
+                e_hard = torch.empty_like(z_logits).exponential_()
+            with torch.no_grad():
+                target = (z_logits - (e_hard + torch.finfo(z_logits.dtype).tiny).log()).argmax(dim=-1).flatten(start_dim=1)
         z_emb = dec.dict.dictionary(target)                                               # B*T, H_enc*W_enc, d_model
         z_emb = torch.cat([dec.bos.expand(B * T, -1, -1), z_emb], dim=1)
         z_emb = dec.pos(z_emb)
 
         # dvae recon (:274-275)
-        dvae_recon = self.dvae.decoder(z_soft).reshape(B, T, C, H, W)
-        dvae_mse = ((video - dvae_recon) ** 2).sum() / (B * T)
+        # (the squared error is summed per frame, then over frames: ATen's single-pass reduction of all 9 M elements to one
+        # scalar takes 1.3 ms here; rows are taken in the memory order of the convolutions' layout)
+        recon_flat = self._conv(self.dvae.decoder, z_soft).float()                        # B*T, C, H, W
+        err = video_flat - recon_flat
+        err = err.permute(0, 2, 3, 1) if self.channels_last else err
+        dvae_mse = err.reshape(B * T, -1).square().sum(dim=1).sum() / (B * T)
+        dvae_recon = recon_flat.reshape(B, T, C, H, W)
 
         # slots (:277-300)
         slots, attns = self._slots(video, noise.get("slots"))

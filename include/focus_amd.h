@@ -484,6 +484,31 @@ size_t focus_traj_time2_gw_workspace_bytes(int R, int heads, int d);
 int focus_traj_time2_gw(const void* g, const void* q2, const void* wk, int64_t wk_ld, void* dq2, float* dwk, void* ws,
                         size_t ws_bytes, int R, int heads, int d, int dtype, void* stream);
 
+/* Row passes over the [frames * tokens, vocabulary] tensors of STEVE.forward (gumbel.hip); one workgroup per row, the row in
+ * registers: V % 8 == 0, 8 <= V <= 8192, R < 2^31, dtype fp32 or bf16 (focus_rows_ok).
+ *
+ * focus_gumbel_fwd (steve.py:262-271 with utils.py:47-61): logp = log_softmax(x);  z = softmax((logp + G_soft) / tau), or the
+ * straight-through value (one_hot(argmax z) - z) + z when `hard`;  target[r] = argmax(logp + G_hard) -- the only use the
+ * reference makes of its second, hard sample (target may be NULL).  G = -log(E + tiny), E ~ Exp(1): e_soft / e_hard [R, V]
+ * fp32 are the draws (the reference's torch.empty_like(logits).exponential_()), or both NULL and the draws are generated in
+ * the kernel from `seed` (4 x uint32 on the device: soft stream, hard stream), which the backward regenerates.
+ * x, dx [R, V] `dtype`; z, dz [R, V] `dtype_z` (= dtype, or bf16 under fp32 logits: a bf16 decoder behind an fp32 encoder);
+ * stats [R, 4] fp32 (row max, log-sum, and the same of the tempered logits) for the backward.
+ * focus_gumbel_bwd: dx = d(loss)/d(x) from dz = d(loss)/d(z) (gradient of the soft sample in both modes). */
+int focus_rows_ok(int64_t R, int V, int dtype);
+int focus_gumbel_fwd(const void* x, const float* e_soft, const float* e_hard, const void* seed, void* z, int64_t* target,
+                     float* stats, int64_t R, int V, float tau, int hard, int dtype, int dtype_z, void* stream);
+int focus_gumbel_bwd(const void* x, const float* e_soft, const void* seed, const float* stats, const void* dz, void* dx,
+                     int64_t R, int V, float tau, int dtype, int dtype_z, void* stream);
+
+/* Label-smoothing cross entropy (losses.py:53-59; steve.py:303-306 with smoothing 0) on fp32 or bf16 logits [R, V]:
+ * loss_rows [R] and the row log-sum-exp lse [R] fp32; the backward rebuilds softmax from lse and writes
+ * dlogits = ((softmax - (1 - smoothing) onehot - smoothing / V) / R) * g[0] in `dtype` (g: device scalar, fp32). */
+int focus_xent_rows_fwd(const void* logits, const int64_t* target, float* loss_rows, float* lse, int64_t R, int V,
+                        float smoothing, int dtype, void* stream);
+int focus_xent_rows_bwd(const void* logits, const int64_t* target, const float* lse, const float* g, void* dlogits,
+                        int64_t R, int V, float smoothing, int dtype, void* stream);
+
 /* xdiag[b,s,:] = xt[b,s,s/P,:] (attention.py:533-535) and its adjoint dxt[b,s,s/P,:] += dxdiag[b,s,:]. */
 int focus_diag_gather(const void* xt, void* xdiag, int B, int S, int F, int C, int dtype, void* stream);
 int focus_diag_scatter_add(const void* dxdiag, void* dxt, int B, int S, int F, int C, int dtype, void* stream);

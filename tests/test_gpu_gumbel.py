@@ -1,0 +1,194 @@
+"""The row passes of csrc/gumbel.hip through the C ABI: Gumbel-softmax over the dVAE vocabulary (steve.py:262-271 with
+STEVE/utils.py:47-61) and the cross entropy of the decoder head (steve.py:303-306), against the same arithmetic written with
+torch operators (fp32), with supplied Exp(1) draws -- what a parity run with the reference's own draws does -- and with draws
+generated in the kernel, whose hash has its numpy twin here."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+TINY = float(torch.finfo(torch.float32).tiny)
+
+
+def _ops():
+    from focus_amd import ops
+    return ops
+
+
+def torch_reference(x, e_soft, e_hard, tau, hard):
+    """utils.py:47-61 on log_softmax(x) (steve.py:262-266) and the arg-max of the hard sample (steve.py:268-269)."""
+    logp = F.log_softmax(x, dim=-1)
+    soft = F.softmax((logp - (e_soft + TINY).log()) / tau, dim=-1)
+    z = soft
+    if hard:
+        one_hot = torch.zeros_like(soft).scatter_(-1, soft.argmax(-1, keepdim=True), 1.0)
+        z = one_hot - soft.detach() + soft
+    z_hard = F.softmax((logp - (e_hard + TINY).log()) / tau, dim=-1)
+    return z, z_hard.argmax(-1), logp
+
+
+def mix32(x):
+    x = x.astype(np.uint64)
+    x ^= x >> np.uint64(16)
+    x = (x * np.uint64(0x7feb352d)) & np.uint64(0xffffffff)
+    x ^= x >> np.uint64(15)
+    x = (x * np.uint64(0x846ca68b)) & np.uint64(0xffffffff)
+    x ^= x >> np.uint64(16)
+    return x
+
+
+def exp1_draws(s0, s1, R, V):
+    """numpy twin of exp1_draw / gumbel_row in csrc/gumbel.hip: E[r, c] ~ Exp(1) from 23 hashed bits."""
+    rows = np.arange(R, dtype=np.uint64)
+    row_key = (mix32((rows & np.uint64(0xffffffff)) ^ np.uint64(s0)) + (rows >> np.uint64(32))) & np.uint64(0xffffffff)
+    cols = (np.arange(V, dtype=np.uint64) * np.uint64(0x9E3779B9)) & np.uint64(0xffffffff)
+    h = mix32(row_key[:, None] ^ cols[None, :] ^ np.uint64(s1))
+    u = ((h >> np.uint64(9)).astype(np.float32) + np.float32(0.5)) * np.float32(1.0 / 8388608.0)
+    return (-np.float32(0.6931471805599453) * np.log2(u)).astype(np.float32)
+
+
+@pytest.mark.parametrize("R,V", [(37, 64), (16, 2056), (24, 4096), (5, 8192)])
+@pytest.mark.parametrize("hard", [False, True])
+def test_gumbel_rows_supplied_noise_fp32(R, V, hard):
+    ops = _ops()
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(R * 7 + V)
+    x = (3.0 * torch.randn(R, V, device=dev, generator=g)).requires_grad_(True)
+    e_soft = torch.empty(R, V, device=dev).exponential_(generator=g)
+    e_hard = torch.empty(R, V, device=dev).exponential_(generator=g)
+    w = torch.randn(R, V, device=dev, generator=g)
+    tau = 0.7
+    assert ops.rows_ok(x)
+    z, target = ops.gumbel_softmax_rows(x, tau, hard, e_soft, e_hard)
+    (z * w).sum().backward()
+    dx, x.grad = x.grad, None
+    zr, tr, _ = torch_reference(x, e_soft, e_hard, tau, hard)
+    (zr * w).sum().backward()
+    assert torch.equal(target, tr)
+    assert (z - zr).abs().max().item() < 2e-6
+    if hard:
+        assert torch.equal(z.argmax(-1), zr.argmax(-1)) and float(z.max()) <= 1.0 + 2e-7
+    scale = x.grad.abs().max().item()
+    assert (dx - x.grad).abs().max().item() < 2e-5 * scale + 1e-7
+
+
+@pytest.mark.parametrize("hard", [False, True])
+def test_gumbel_rows_supplied_noise_bf16(hard):
+    """bf16 logits in, bf16 sample out, bf16 gradient in and out (the convolutions around it run in bf16 under
+    TRAIN.MIXED_PRECISION); the arithmetic between is fp32."""
+    ops = _ops()
+    dev = torch.device("cuda:0")
+    R, V, tau = 48, 4096, 0.5
+    g = torch.Generator(device=dev).manual_seed(5)
+    x = (2.0 * torch.randn(R, V, device=dev, generator=g)).bfloat16().requires_grad_(True)
+    e_soft = torch.empty(R, V, device=dev).exponential_(generator=g)
+    e_hard = torch.empty(R, V, device=dev).exponential_(generator=g)
+    w = torch.randn(R, V, device=dev, generator=g).bfloat16()
+    z, target = ops.gumbel_softmax_rows(x, tau, hard, e_soft, e_hard)
+    assert z.dtype == torch.bfloat16
+    (z.float() * w.float()).sum().backward()
+    dx, x.grad = x.grad.float(), None
+    xf = x.detach().float().requires_grad_(True)
+    zr, tr, _ = torch_reference(xf, e_soft, e_hard, tau, hard)
+    (zr * w.float()).sum().backward()
+    assert torch.equal(target, tr)
+    assert torch.equal(z, zr.bfloat16()) or (z.float() - zr).abs().max().item() < 4e-3      # one bf16 step at most
+    scale = xf.grad.abs().max().item()
+    assert (dx - xf.grad).abs().max().item() < 1e-2 * scale
+
+
+@pytest.mark.parametrize("gen", [False, True])
+def test_gumbel_rows_fp32_logits_bf16_sample(gen):
+    """The form STEVE.forward uses under TRAIN.MIXED_PRECISION: fp32 logits and d(logits), the sample and its gradient in
+    bf16 (what the bf16 decoder behind it reads and returns) == the fp32 kernel's sample rounded once."""
+    ops = _ops()
+    dev = torch.device("cuda:0")
+    R, V, tau = 32, 4096, 0.6
+    g = torch.Generator(device=dev).manual_seed(21)
+    x = (2.0 * torch.randn(R, V, device=dev, generator=g)).requires_grad_(True)
+    w = torch.randn(R, V, device=dev, generator=g).bfloat16()
+    if gen:
+        kw = dict(seed=torch.tensor([5, 6, 7, 8], device=dev, dtype=torch.int32))
+    else:
+        kw = dict(e_soft=torch.empty(R, V, device=dev).exponential_(generator=g),
+                  e_hard=torch.empty(R, V, device=dev).exponential_(generator=g))
+    z, target = ops.gumbel_softmax_rows(x, tau, False, out_dtype=torch.bfloat16, **kw)
+    assert z.dtype == torch.bfloat16
+    (z.float() * w.float()).sum().backward()
+    dx, x.grad = x.grad, None
+    assert dx.dtype == torch.float32
+    z32, t32 = ops.gumbel_softmax_rows(x, tau, False, **kw)
+    (z32 * w.float()).sum().backward()
+    assert torch.equal(target, t32) and torch.equal(z, z32.bfloat16())
+    assert torch.equal(dx, x.grad)               # the same bf16 gradient values enter the same arithmetic
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_gumbel_rows_generated_noise(dtype):
+    """Draws made in the kernel == the numpy twin of the hash; the backward regenerates the same draws."""
+    ops = _ops()
+    dev = torch.device("cuda:0")
+    R, V, tau = 40, 4096, 0.8
+    g = torch.Generator(device=dev).manual_seed(11)
+    x = (2.0 * torch.randn(R, V, device=dev, generator=g)).to(dtype).requires_grad_(True)
+    w = torch.randn(R, V, device=dev, generator=g)
+    seed = torch.tensor([123456789, -987654321, 42, -7], device=dev, dtype=torch.int32)
+    z, target = ops.gumbel_softmax_rows(x, tau, False, seed=seed)
+    (z.float() * w).sum().backward()
+    dx = x.grad.float()
+    su = [int(v) & 0xffffffff for v in seed.tolist()]
+    e_soft = torch.from_numpy(exp1_draws(su[0], su[1], R, V)).to(dev)
+    e_hard = torch.from_numpy(exp1_draws(su[2], su[3], R, V)).to(dev)
+    xf = x.detach().float().requires_grad_(True)
+    zr, tr, _ = torch_reference(xf, e_soft, e_hard, tau, False)
+    (zr * w).sum().backward()
+    tol = 2e-5 if dtype == torch.float32 else 4e-3
+    assert (z.float() - zr).abs().max().item() < tol           # hardware log2 / exp2 against libm: ~1e-6 relative
+    assert int((target != tr).sum()) <= 1
+    scale = xf.grad.abs().max().item()
+    assert (dx - xf.grad).abs().max().item() < (1e-4 if dtype == torch.float32 else 1e-2) * scale
+    # same seed -> same sample; another seed -> another sample
+    z2, t2 = ops.gumbel_softmax_rows(x.detach(), tau, False, seed=seed)
+    assert torch.equal(z2, z.detach()) and torch.equal(t2, target)
+    z3, t3 = ops.gumbel_softmax_rows(x.detach(), tau, False, seed=seed + 1)
+    assert not torch.equal(t3, target)
+
+
+def test_gumbel_generated_noise_is_exponential():
+    """Uniform logits: the targets are uniform over the vocabulary, the two streams are independent, and the draws have the
+    moments of Exp(1)."""
+    ops = _ops()
+    dev = torch.device("cuda:0")
+    R, V = 65536, 64
+    x = torch.zeros(R, V, device=dev)
+    z, target = ops.gumbel_softmax_rows(x, 1.0, True)
+    counts = torch.bincount(target, minlength=V).float()
+    sigma = (R / V * (1 - 1 / V)) ** 0.5
+    assert (counts - R / V).abs().max().item() < 5.5 * sigma
+    agree = (z.argmax(-1) == target).float().mean().item()
+    assert abs(agree - 1.0 / V) < 5 * (1.0 / V / R) ** 0.5 + 1e-3
+    e = exp1_draws(1, 2, 4096, 256).astype(np.float64)
+    assert abs(e.mean() - 1.0) < 0.01 and abs(e.var() - 1.0) < 0.03
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("R,V,smoothing", [(50, 4096, 0.0), (33, 64, 0.1), (7, 8192, 0.0)])
+def test_xent_rows(dtype, R, V, smoothing):
+    ops = _ops()
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(R + V)
+    logits = (2.0 * torch.randn(R, V, device=dev, generator=g)).to(dtype).requires_grad_(True)
+    target = torch.randint(0, V, (R,), device=dev, generator=g)
+    assert ops.rows_ok(logits)
+    loss = ops.label_smoothing_ce(logits, target, smoothing)
+    (loss * 3.5).backward()
+    ref_in = logits.detach().float().requires_grad_(True)
+    ref = F.cross_entropy(ref_in, target, label_smoothing=smoothing)
+    (ref * 3.5).backward()
+    assert abs(loss.item() - ref.item()) < 2e-5 * max(1.0, abs(ref.item()))
+    assert logits.grad.dtype == dtype
+    scale = ref_in.grad.abs().max().item()
+    tol = 1e-5 if dtype == torch.float32 else 8e-3
+    assert (logits.grad.float() - ref_in.grad).abs().max().item() < tol * scale

@@ -112,7 +112,9 @@ def test_steve_forward_vs_reference_fixture(mixed):
     close(recon, a["recon"], tol, "recon")
     close(attns, a["attns"], tol, "attns")
     close(ce, a["cross_entropy"], tol, "cross_entropy")
-    close(mse, a["mse"], 1e-3, "mse")                                # the dVAE stays fp32 in both modes
+    # mixed: the dVAE's convolutions run in bf16, as under the reference's autocast (steve_train_net.py:95); its Gumbel-softmax
+    # arithmetic is fp32 in both modes
+    close(mse, a["mse"], 5e-3 if mixed else 1e-3, "mse")
     (mse + ce).backward()
     # bf16: the CNN / encoder gradients come back through the decoder's cross-attention, the slot projection and
     # T x iterations slot updates (GRU + softmax over slots) in bf16 storage: the deep-chain factor of the module header
