@@ -277,6 +277,34 @@ __global__ __launch_bounds__(256) void xent_rows_bwd_kernel(const T* __restrict_
     store_row<T, NC>(dlogits + r * V, V, v);
 }
 
+// ---- out = residual + dropout(y): the three residual branches of a decoder block (transformer.py:45-47, :147-163) -----------
+// keep(i) = 16 hashed bits of (seed, i) >= thr, thr = round(p * 65536); survivors are scaled by 65536 / (65536 - thr).
+// One 32-bit hash serves two neighbouring elements.  The backward of the branch is the same pass over the incoming gradient
+// with res == NULL: the mask is a function of (seed, index) and is never stored.   (numpy twin: tests/test_gpu_gumbel.py)
+template <typename T>
+__global__ __launch_bounds__(256) void dropout_add_kernel(const T* __restrict__ y, const T* __restrict__ res,
+                                                          const uint32_t* __restrict__ seed, uint32_t thr, T* __restrict__ out,
+                                                          int64_t n) {
+    const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 8;
+    if (i >= n) return;
+    const uint32_t s0 = seed[0], s1 = seed[1];
+    const float inv = 65536.f / (float)(65536u - thr);
+    float v[8], r[8];
+    ld8<T>(y + i, v);
+    if (res) ld8<T>(res + i, r);
+    const uint64_t pair = (uint64_t)i >> 1;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const uint64_t pj = pair + j;
+        const uint32_t h = mix32((uint32_t)pj ^ s0) ^ ((uint32_t)(pj >> 32) * 0x9E3779B9u + s1);
+        const float a = (h & 0xffffu) >= thr ? v[2 * j] * inv : 0.f;
+        const float b = (h >> 16) >= thr ? v[2 * j + 1] * inv : 0.f;
+        v[2 * j] = res ? r[2 * j] + a : a;
+        v[2 * j + 1] = res ? r[2 * j + 1] + b : b;
+    }
+    st8<T>(out + i, v);
+}
+
 bool rows_ok(int64_t R, int V) { return R > 0 && R < (1ll << 31) && V >= 8 && V % 8 == 0 && V <= 8192; }
 
 }  // namespace
@@ -371,6 +399,22 @@ extern "C" int focus_xent_rows_bwd(const void* logits, const int64_t* target, co
         hipLaunchKernelGGL((xent_rows_bwd_kernel<T, NC>), dim3((unsigned)R), dim3(256), 0, (hipStream_t)stream,
                            (const T*)logits, target, lse, g, (T*)dlogits, V, smoothing, (float)R);
     }));
+    FOCUS_CHECK_LAUNCH();
+    return FOCUS_OK;
+}
+
+extern "C" int focus_dropout_add(const void* y, const void* res, const void* seed, int thr, void* out, int64_t n, int dtype,
+                                 void* stream) {
+    if (!y || !seed || !out) return FOCUS_ERR_NULL;
+    if (n <= 0 || n % 8 || thr < 0 || thr >= 65536) return FOCUS_ERR_SHAPE;
+    if (dtype != FOCUS_F32 && dtype != FOCUS_BF16) return FOCUS_ERR_DTYPE;
+    if (!focus_aligned(y, 16) || !focus_aligned(out, 16) || (res && !focus_aligned(res, 16))) return FOCUS_ERR_ALIGN;
+    const int64_t blocks = cdiv64(n / 8, 256);
+    if (blocks >= (1ll << 31)) return FOCUS_ERR_SHAPE;
+    GUMBEL_T(dtype, {
+        hipLaunchKernelGGL((dropout_add_kernel<T>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const T*)y,
+                           (const T*)res, (const uint32_t*)seed, (uint32_t)thr, (T*)out, n);
+    });
     FOCUS_CHECK_LAUNCH();
     return FOCUS_OK;
 }

@@ -1956,6 +1956,48 @@ def label_smoothing_ce(logits, target, smoothing=0.1):
 
 
 # --------------------------------------------------------------------------------------------------
+# residual + dropout(branch) (the decoder blocks of STEVE: transformer.py:45-47, :147-163)
+# --------------------------------------------------------------------------------------------------
+class _DropoutAddFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, y, residual, thr, seed):
+        out = torch.empty_like(y)
+        _lib.check(_lib.lib().focus_dropout_add(_p(y), _p(residual) if residual is not None else None, _p(seed), thr, _p(out),
+                                                y.numel(), _dt(y), _stream()), "dropout_add")
+        ctx.save_for_backward(seed)
+        ctx.thr, ctx.has_res = thr, residual is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (seed,) = ctx.saved_tensors
+        g = g.contiguous()
+        dy = torch.empty_like(g)
+        _lib.check(_lib.lib().focus_dropout_add(_p(g), None, _p(seed), ctx.thr, _p(dy), g.numel(), _dt(g), _stream()),
+                   "dropout_add_bwd")
+        return dy, (g if ctx.has_res else None), None, None
+
+
+def dropout_add(y, residual, p, training, seed=None):
+    """residual + F.dropout(y, p, training) (residual may be None).  On the GPU, for dense fp32 / bf16 tensors, one pass whose
+    mask is a hash of (seed, element index) -- rebuilt by the backward, never stored; `seed`: int32 [2] on the device
+    (default: drawn from torch's generator).  p is quantised to drop_threshold(p) / 65536."""
+    if not training or p <= 0.0:
+        return y if residual is None else residual + y
+    thr = drop_threshold(p)
+    ok = (y.is_cuda and y.is_contiguous() and y.dtype in (torch.float32, torch.bfloat16) and y.numel() % 8 == 0
+          and y.numel() > 0 and y.data_ptr() % 16 == 0 and thr > 0
+          and (residual is None or (residual.shape == y.shape and residual.dtype == y.dtype and residual.is_contiguous()
+                                    and residual.data_ptr() % 16 == 0)))
+    if not ok:
+        out = torch.nn.functional.dropout(y, p, True)
+        return out if residual is None else residual + out
+    if seed is None:
+        seed = torch.randint(-2 ** 31, 2 ** 31 - 1, (2,), device=y.device, dtype=torch.int32)
+    return _DropoutAddFn.apply(y, residual, thr, seed)
+
+
+# --------------------------------------------------------------------------------------------------
 # Gumbel-softmax over the dVAE vocabulary (steve.py:262-271, STEVE/utils.py:47-61)
 # --------------------------------------------------------------------------------------------------
 class _GumbelFn(torch.autograd.Function):

@@ -55,8 +55,7 @@ class MultiHeadAttention(nn.Module):
                 drop = F.dropout(torch.ones(B, self.num_heads, T, S, device=q.device, dtype=q.dtype), p, True)
             a = ops.small_attention(Q, Kt, V, self.num_heads, d ** -0.5, causal=causal, drop=drop)
         if self.training and self.output_dropout.p > 0.0:
-            out = self.output_dropout(ops.linear(a, self.proj_o.weight))
-            return out if residual is None else residual + out
+            return ops.dropout_add(ops.linear(a, self.proj_o.weight), residual, self.output_dropout.p, True)
         return ops.linear(a, self.proj_o.weight, residual=residual)
 
 
@@ -74,7 +73,8 @@ def _ffn(seq, x, residual, training):
     """Linear -> ReLU -> Linear -> Dropout (+ residual): one fused op, the residual in the second GEMM's epilogue."""
     up, down, drop = seq[0], seq[2], seq[3]
     if training and drop.p > 0.0:
-        return residual + drop(ops.mlp(x, up.weight, up.bias, down.weight, down.bias, act=ops.EPI_RELU))
+        y = ops.mlp(x, up.weight, up.bias, down.weight, down.bias, act=ops.EPI_RELU)
+        return ops.dropout_add(y, residual, drop.p, True)          # mask from a seed, rebuilt by the backward (gumbel.hip)
     return ops.mlp(x, up.weight, up.bias, down.weight, down.bias, residual=residual, act=ops.EPI_RELU)
 
 

@@ -509,6 +509,13 @@ int focus_xent_rows_fwd(const void* logits, const int64_t* target, float* loss_r
 int focus_xent_rows_bwd(const void* logits, const int64_t* target, const float* lse, const float* g, void* dlogits,
                         int64_t R, int V, float smoothing, int dtype, void* stream);
 
+/* out[i] = (res ? res[i] : 0) + keep(i) * y[i] * 65536 / (65536 - thr): a residual branch that ends in nn.Dropout
+ * (transformer.py:45-47, :147-163) in one pass.  keep(i) = 16 hashed bits of (seed, i) >= thr, thr = round(p * 65536);
+ * seed: 2 x uint32 on the device.  The branch's backward is the same call on the incoming gradient with res = NULL.
+ * n % 8 == 0, 16-byte aligned pointers, fp32 or bf16. */
+int focus_dropout_add(const void* y, const void* res, const void* seed, int thr, void* out, int64_t n, int dtype,
+                      void* stream);
+
 /* xdiag[b,s,:] = xt[b,s,s/P,:] (attention.py:533-535) and its adjoint dxt[b,s,s/P,:] += dxdiag[b,s,:]. */
 int focus_diag_gather(const void* xt, void* xdiag, int B, int S, int F, int C, int dtype, void* stream);
 int focus_diag_scatter_add(const void* dxdiag, void* dxt, int B, int S, int F, int C, int dtype, void* stream);

@@ -192,3 +192,45 @@ def test_xent_rows(dtype, R, V, smoothing):
     scale = ref_in.grad.abs().max().item()
     tol = 1e-5 if dtype == torch.float32 else 8e-3
     assert (logits.grad.float() - ref_in.grad).abs().max().item() < tol * scale
+
+
+def keep_mask(s0, s1, n, thr):
+    """numpy twin of dropout_add_kernel's mask: element i survives when its 16 hashed bits are >= thr."""
+    pair = np.arange(n // 2, dtype=np.uint64)
+    h = mix32((pair & np.uint64(0xffffffff)) ^ np.uint64(s0)) ^ \
+        (((pair >> np.uint64(32)) * np.uint64(0x9E3779B9) + np.uint64(s1)) & np.uint64(0xffffffff))
+    lo, hi = h & np.uint64(0xffff), h >> np.uint64(16)
+    return np.stack([lo >= thr, hi >= thr], axis=1).reshape(-1)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("with_res", [True, False])
+def test_dropout_add(dtype, with_res):
+    """residual + dropout(y) in one pass == the same mask applied with torch operators; the backward rebuilds the mask."""
+    ops = _ops()
+    dev = torch.device("cuda:0")
+    shape, p = (6, 1024, 192), 0.1
+    g = torch.Generator(device=dev).manual_seed(3)
+    y = torch.randn(shape, device=dev, generator=g).to(dtype).requires_grad_(True)
+    res = torch.randn(shape, device=dev, generator=g).to(dtype).requires_grad_(True) if with_res else None
+    w = torch.randn(shape, device=dev, generator=g).to(dtype)
+    seed = torch.tensor([2024, -17], device=dev, dtype=torch.int32)
+    out = ops.dropout_add(y, res, p, True, seed=seed)
+    assert out.dtype == dtype and out.shape == y.shape
+    out.backward(w)
+    thr = ops.drop_threshold(p)
+    su = [int(v) & 0xffffffff for v in seed.tolist()]
+    keep = torch.from_numpy(keep_mask(su[0], su[1], y.numel(), thr)).to(dev).view(shape)
+    inv = 65536.0 / (65536 - thr)
+    ref = keep * y.detach().float() * inv + (res.detach().float() if with_res else 0.0)
+    tol = 1e-6 if dtype == torch.float32 else 8e-3
+    assert (out.float() - ref).abs().max().item() <= tol * max(1.0, ref.abs().max().item())
+    assert torch.equal(out.detach() == (res.detach() if with_res else 0), ~keep) or abs(keep.float().mean().item() - 0.9) < 5e-3
+    assert abs(keep.float().mean().item() - (1 - thr / 65536)) < 3e-3
+    dref = keep * w.float() * inv
+    assert (y.grad.float() - dref).abs().max().item() <= tol * dref.abs().max().item()
+    if with_res:
+        assert torch.equal(res.grad, w)
+    # evaluation / p = 0: the plain sum
+    assert torch.equal(ops.dropout_add(y.detach(), res.detach() if with_res else None, p, False),
+                       y.detach() + res.detach() if with_res else y.detach())
