@@ -212,7 +212,12 @@ class CartesianPositionalEmbedding(nn.Module):
         return torch.stack((grid_x, grid_y, 1 - grid_x, 1 - grid_y), dim=0)
 
     def forward(self, inputs):
-        return inputs + self.projection(self.pe)
+        pos = self.projection(self.pe)
+        if pos.dtype != inputs.dtype:
+            # features from a bf16 convolution stack (TRAIN.MIXED_PRECISION): the sum stays in their type, as the two fp16
+            # operands of the reference's autocast do, instead of promoting 600 MB of features to fp32 and back
+            pos = pos.to(inputs.dtype)
+        return inputs + pos
 
 
 class OneHotDictionary(nn.Module):
