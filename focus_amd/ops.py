@@ -1984,8 +1984,10 @@ def dropout_add(y, residual, p, training, seed=None):
     (default: drawn from torch's generator).  p is quantised to drop_threshold(p) / 65536."""
     if not training or p <= 0.0:
         return y if residual is None else residual + y
+    _need_gpu(y, residual)
     thr = drop_threshold(p)
-    ok = (y.is_cuda and y.is_contiguous() and y.dtype in (torch.float32, torch.bfloat16) and y.numel() % 8 == 0
+    # (shapes the kernel does not take -- odd element counts, strided views -- keep ATen's dropout, on the GPU)
+    ok = (y.is_contiguous() and y.dtype in (torch.float32, torch.bfloat16) and y.numel() % 8 == 0
           and y.numel() > 0 and y.data_ptr() % 16 == 0 and thr > 0
           and (residual is None or (residual.shape == y.shape and residual.dtype == y.dtype and residual.is_contiguous()
                                     and residual.data_ptr() % 16 == 0)))
