@@ -7,6 +7,8 @@ import pytest
 import torch
 import torch.nn.functional as F
 
+from rng_twins import exp1_draws, keep_mask
+
 pytestmark = pytest.mark.gpu
 
 TINY = float(torch.finfo(torch.float32).tiny)
@@ -18,35 +20,13 @@ def _ops():
 
 
 def torch_reference(x, e_soft, e_hard, tau, hard):
-    """utils.py:47-61 on log_softmax(x) (steve.py:262-266) and the arg-max of the hard sample (steve.py:268-269)."""
-    logp = F.log_softmax(x, dim=-1)
-    soft = F.softmax((logp - (e_soft + TINY).log()) / tau, dim=-1)
-    z = soft
-    if hard:
-        one_hot = torch.zeros_like(soft).scatter_(-1, soft.argmax(-1, keepdim=True), 1.0)
-        z = one_hot - soft.detach() + soft
-    z_hard = F.softmax((logp - (e_hard + TINY).log()) / tau, dim=-1)
+    """The oracle's gumbel_softmax (oracle/focus_oracle.py, pinned by the reference's STEVE fixture) on log_softmax(x)
+    (steve.py:262-264) and the arg-max of the hard sample (steve.py:266)."""
+    from oracle import focus_oracle as fo
+    logp = torch.log_softmax(x, dim=-1)
+    z = fo.gumbel_softmax(logp, tau, hard, -1, e_soft)
+    z_hard = fo.gumbel_softmax(logp, tau, True, -1, e_hard).detach()
     return z, z_hard.argmax(-1), logp
-
-
-def mix32(x):
-    x = x.astype(np.uint64)
-    x ^= x >> np.uint64(16)
-    x = (x * np.uint64(0x7feb352d)) & np.uint64(0xffffffff)
-    x ^= x >> np.uint64(15)
-    x = (x * np.uint64(0x846ca68b)) & np.uint64(0xffffffff)
-    x ^= x >> np.uint64(16)
-    return x
-
-
-def exp1_draws(s0, s1, R, V):
-    """numpy twin of exp1_draw / gumbel_row in csrc/gumbel.hip: E[r, c] ~ Exp(1) from 23 hashed bits."""
-    rows = np.arange(R, dtype=np.uint64)
-    row_key = (mix32((rows & np.uint64(0xffffffff)) ^ np.uint64(s0)) + (rows >> np.uint64(32))) & np.uint64(0xffffffff)
-    cols = (np.arange(V, dtype=np.uint64) * np.uint64(0x9E3779B9)) & np.uint64(0xffffffff)
-    h = mix32(row_key[:, None] ^ cols[None, :] ^ np.uint64(s1))
-    u = ((h >> np.uint64(9)).astype(np.float32) + np.float32(0.5)) * np.float32(1.0 / 8388608.0)
-    return (-np.float32(0.6931471805599453) * np.log2(u)).astype(np.float32)
 
 
 @pytest.mark.parametrize("R,V", [(37, 64), (16, 2056), (24, 4096), (5, 8192)])
@@ -192,15 +172,6 @@ def test_xent_rows(dtype, R, V, smoothing):
     scale = ref_in.grad.abs().max().item()
     tol = 1e-5 if dtype == torch.float32 else 8e-3
     assert (logits.grad.float() - ref_in.grad).abs().max().item() < tol * scale
-
-
-def keep_mask(s0, s1, n, thr):
-    """numpy twin of dropout_add_kernel's mask: element i survives when its 16 hashed bits are >= thr."""
-    pair = np.arange(n // 2, dtype=np.uint64)
-    h = mix32((pair & np.uint64(0xffffffff)) ^ np.uint64(s0)) ^ \
-        (((pair >> np.uint64(32)) * np.uint64(0x9E3779B9) + np.uint64(s1)) & np.uint64(0xffffffff))
-    lo, hi = h & np.uint64(0xffff), h >> np.uint64(16)
-    return np.stack([lo >= thr, hi >= thr], axis=1).reshape(-1)
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
