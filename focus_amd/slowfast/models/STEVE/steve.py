@@ -17,9 +17,9 @@ from .transformer import TransformerDecoder, TransformerEncoder
 from .utils import Conv2dBlock, conv2d, gru_cell, gumbel_softmax, linear
 
 # Next-frame k / v on a side stream (see _loop_fused): opt-in.  Eager runs are bit-reproducible with it, but whole-step graph
-# replays were not always (tools/steve_pipeline_check.py: d(k), d(v) reaching the projection's backward before they were
-# complete -- fenced since -- and, once in nine replays after the fence, a first replay whose forward differed); a replay that
-# is not bit-identical to the eager step is not shipped as the default for 0.4 ms.
+# replays are not (tools/steve_pipeline_check.py, profiles/r03_steve_pipeline_check.txt: first d(k), d(v) reaching the
+# projection's backward before they were complete -- fenced since --, and still 9 of 30 replays whose forward diverges at one
+# frame: a slot-attention call that read unfinished keys / values).  Off until that is understood.
 _PIPELINE_KV = os.environ.get("FOCUS_STEVE_PIPELINE", "0") != "0"
 _SIDE_STREAMS = {}
 

@@ -1,5 +1,7 @@
 """Diagnostic: is the slot update reproducible run to run (eager), and does a whole-step graph replay equal it, with the
-next-frame k/v pipeline on the side stream?   python tools/steve_pipeline_check.py [batch=32]"""
+next-frame k/v pipeline on the side stream?   python tools/steve_pipeline_check.py [batch=32] [captures=1]
+captures > 1: that many FRESH captures, each replayed three times (the mismatch seen in round 3 was in the first replay of
+one capture in nine); for every mismatch the first frame whose slots differ is printed."""
 import sys
 
 import torch
@@ -45,10 +47,22 @@ for i in range(1, 4):
     bad = [n for n, a_, b_ in zip(names, runs[0], runs[i]) if not torch.equal(a_, b_)]
     print("eager run %d vs 0: %s" % (i, "identical" if not bad else "DIFFERS in " + ", ".join(bad[:8])))
 s = a = None
-reset()
-gs = GraphedStep(fwd_bwd, reset=reset)
-for i in range(3):
-    out = gs.replay()
-    cur = snap(*out)
-    bad = [n for n, a_, b_ in zip(names, runs[0], cur) if not torch.equal(a_, b_)]
-    print("replay %d vs eager 0: %s" % (i, "identical" if not bad else "DIFFERS in " + ", ".join(bad[:8])))
+ncap = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+for c in range(ncap):
+    reset()
+    gs = GraphedStep(fwd_bwd, reset=reset)
+    for i in range(3):
+        out = gs.replay()
+        cur = snap(*out)
+        bad = [n for n, a_, b_ in zip(names, runs[0], cur) if not torch.equal(a_, b_)]
+        where = ""
+        if bad:
+            ds = (cur[0].float() - runs[0][0].float()).abs().amax(dim=(0, 2, 3))        # slots [B,T,K,D] -> per frame
+            da = (cur[1].float() - runs[0][1].float()).abs().amax(dim=(0, 2, 3))
+            ft = [int(t) for t in torch.nonzero(ds > 0).flatten()[:4]]
+            fa = [int(t) for t in torch.nonzero(da > 0).flatten()[:4]]
+            where = "  (slots differ first at frames %s, max %.3g; attn at %s, max %.3g)" % (ft, float(ds.max()), fa, float(da.max()))
+        print("capture %d replay %d vs eager 0: %s%s" % (c, i, "identical" if not bad else "DIFFERS in " + ", ".join(bad[:8]), where),
+              flush=True)
+    del gs, out, cur
+    torch.cuda.synchronize()
