@@ -21,6 +21,7 @@ from .utils import Conv2dBlock, conv2d, gru_cell, gumbel_softmax, linear
 # projection's backward before they were complete -- fenced since --, and still 9 of 30 replays whose forward diverges at one
 # frame: a slot-attention call that read unfinished keys / values).  Off until that is understood.
 _PIPELINE_KV = os.environ.get("FOCUS_STEVE_PIPELINE", "0") != "0"
+_PIPELINE_JOIN = os.environ.get("FOCUS_STEVE_PIPELINE_JOIN", "event")      # "event" | "stream" (tools/steve_pipeline_check.py)
 _SIDE_STREAMS = {}
 
 
@@ -40,7 +41,10 @@ class _KVFence(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, k, v, main, side, ready):
-        main.wait_event(ready)
+        if _PIPELINE_JOIN == "stream":        # experiment knob: join on everything the side stream has been given so far
+            main.wait_stream(side)
+        else:
+            main.wait_event(ready)
         k.record_stream(main)
         v.record_stream(main)
         ctx.streams = (main, side)
