@@ -47,6 +47,46 @@ def test_hot_path_has_no_cpu_fallback(built):
         ops.layer_norm(x, torch.ones(8), torch.zeros(8), 1e-6)
 
 
+def test_row_kernels_validate_before_launching(built):
+    """gumbel.hip's entry points refuse bad arguments with the ABI's error codes before any launch (no GPU needed), and the
+    operators above them refuse CPU tensors."""
+    from focus_amd import _lib, ops
+    lib = _lib.lib()
+    F32, BF16 = _lib.F32, _lib.BF16
+    assert lib.focus_rows_ok(196608, 4096, BF16) == 1 and lib.focus_rows_ok(5, 8192, F32) == 1
+    assert lib.focus_rows_ok(5, 4100, F32) == 0 and lib.focus_rows_ok(5, 8200, F32) == 0         # V % 8, V <= 8192
+    assert lib.focus_rows_ok(0, 4096, F32) == 0 and lib.focus_rows_ok(5, 4096, _lib.FP8_E4M3) == 0
+    buf = ctypes.create_string_buffer(1 << 16)
+    a = ctypes.addressof(buf)
+    a += -a % 16
+    ptr = ctypes.c_void_p(a)
+    NULL, SHAPE, DTYPE, ALIGN = -5, -1, -2, -3
+    assert lib.focus_gumbel_fwd(None, None, None, ptr, ptr, None, ptr, 4, 64, 1.0, 0, F32, F32, None) == NULL
+    assert lib.focus_gumbel_fwd(ptr, None, None, None, ptr, None, ptr, 4, 64, 1.0, 0, F32, F32, None) == NULL   # no noise, no seed
+    assert lib.focus_gumbel_fwd(ptr, ptr, None, None, ptr, ptr, ptr, 4, 64, 1.0, 0, F32, F32, None) == NULL     # target without e_hard
+    assert lib.focus_gumbel_fwd(ptr, None, None, ptr, ptr, None, ptr, 4, 60, 1.0, 0, F32, F32, None) == SHAPE
+    assert lib.focus_gumbel_fwd(ptr, None, None, ptr, ptr, None, ptr, 4, 64, 0.0, 0, F32, F32, None) == SHAPE    # tau > 0
+    assert lib.focus_gumbel_fwd(ptr, None, None, ptr, ptr, None, ptr, 4, 64, 1.0, 0, BF16, F32, None) == DTYPE   # fp32 sample of bf16 logits
+    odd = ctypes.c_void_p(a + 4)
+    assert lib.focus_gumbel_fwd(odd, None, None, ptr, ptr, None, ptr, 4, 64, 1.0, 0, F32, F32, None) == ALIGN
+    assert lib.focus_gumbel_bwd(ptr, None, None, ptr, ptr, ptr, 4, 64, 1.0, F32, F32, None) == NULL              # neither noise nor seed
+    assert lib.focus_xent_rows_fwd(ptr, ptr, ptr, None, 4, 64, 0.0, F32, None) == NULL
+    assert lib.focus_xent_rows_bwd(ptr, ptr, ptr, ptr, ptr, 4, 12, 0.0, F32, None) == SHAPE
+    assert lib.focus_dropout_add(ptr, None, None, 6554, ptr, 64, F32, None) == NULL
+    assert lib.focus_dropout_add(ptr, None, ptr, 6554, ptr, 60, F32, None) == SHAPE
+    assert lib.focus_dropout_add(ptr, None, ptr, 65536, ptr, 64, F32, None) == SHAPE
+    assert lib.focus_dropout_add(ptr, odd, ptr, 6554, ptr, 64, BF16, None) == ALIGN
+    x = torch.randn(4, 64)
+    assert not ops.rows_ok(x)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ops.gumbel_softmax_rows(x, 1.0, False)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ops.dropout_add(x, x, 0.1, True)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ops.label_smoothing_ce(x, torch.zeros(4, dtype=torch.long), 0.0)
+    assert torch.equal(ops.dropout_add(x, x, 0.1, False), x + x)          # evaluation: the plain sum, any device
+
+
 def test_config_and_registry_surface():
     from focus_amd.slowfast.config.defaults import assert_and_infer_cfg, get_cfg
     from focus_amd.slowfast.models import MODEL_REGISTRY, build_model
