@@ -408,11 +408,9 @@ class STEVE(nn.Module):
         dec = self.steve_decoder
         video_flat = self._frames(video)                                                  # B*T, C, H, W
 
-        # dvae encode (:262-271)
-        # The vocabulary axis is moved LAST for the three softmax-family passes over the [B*T, 4096, H/4, W/4] logits: as dim=1
-        # of an NCHW tensor ATen runs them with its strided "spatial" kernels -- 29 of the 162 ms of kernel time of a training
-        # step at 24 x 128 x 128 -- and the same vectors normalised along a contiguous axis take a tenth of that.  Same
-        # values; the decoder's 1x1 convolution receives the channels-last view (MIOpen's own layout).
+        # dvae encode (:262-271).  The vocabulary axis is moved LAST: the rows of the channels-last logits are what the row
+        # kernels read, and the ATen passes of the other branch run on a contiguous axis instead of as strided dim=1
+        # ("spatial") kernels.  Same values; the decoder's 1x1 convolution receives the channels-last view (MIOpen's layout).
         enc_out = self.dvae.encoder(video_flat).permute(0, 2, 3, 1)                       # B*T, H_enc, W_enc, vocab
         last = lambda e: None if e is None else e.permute(0, 2, 3, 1)
         e_soft, e_hard = last(noise.get("gumbel_soft")), last(noise.get("gumbel_hard"))
