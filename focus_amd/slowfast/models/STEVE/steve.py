@@ -22,6 +22,7 @@ from .utils import Conv2dBlock, conv2d, gru_cell, gumbel_softmax, linear
 # frame: a slot-attention call that read unfinished keys / values).  Off until that is understood.
 _PIPELINE_KV = os.environ.get("FOCUS_STEVE_PIPELINE", "0") != "0"
 _PIPELINE_JOIN = os.environ.get("FOCUS_STEVE_PIPELINE_JOIN", "event")      # "event" | "stream" (tools/steve_pipeline_check.py)
+_PIPELINE_AHEAD1 = os.environ.get("FOCUS_STEVE_PIPELINE_AHEAD1", "0") != "0"
 _SIDE_STREAMS = {}
 
 
@@ -169,6 +170,8 @@ class SlotAttentionVideo(nn.Module):
             if pipe:
                 k_t, v_t = _KVFence.apply(ahead[0], ahead[1], main, side, ready)
                 if t + 1 < T:
+                    if _PIPELINE_AHEAD1:      # experiment knob: the side stream at most one frame ahead of the recurrence
+                        side.wait_stream(main)
                     with torch.cuda.stream(side):
                         ahead = keys_values(t + 1)
                         ready = side.record_event()
