@@ -144,13 +144,16 @@ def live_autograd_tensors(device=None):
     """CUDA tensors that still hang on an autograd graph (grad_fn is not None), found through the garbage collector's
     object list: the outputs of an earlier forward that somebody still references."""
     import gc
+    import warnings
     found = []
-    for o in gc.get_objects():
-        try:
-            if isinstance(o, torch.Tensor) and o.is_cuda and o.grad_fn is not None and (device is None or o.device == device):
-                found.append(o)
-        except Exception:       # objects in odd states while being torn down
-            pass
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")      # isinstance() on lazy module proxies (torch.distributed.reduce_op) warns
+        for o in gc.get_objects():
+            try:
+                if isinstance(o, torch.Tensor) and o.is_cuda and o.grad_fn is not None and (device is None or o.device == device):
+                    found.append(o)
+            except Exception:       # objects in odd states while being torn down
+                pass
     return found
 
 
