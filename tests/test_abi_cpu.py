@@ -137,3 +137,28 @@ def test_slot_module_surface():
     m = SlotAttentionVideo(3, 3, 12, 8, 16, num_predictor_blocks=2, num_predictor_heads=2, dropout=0.0)
     assert sorted(m.state_dict().keys()) == sorted(p.keys())
     m.load_state_dict({k: v.float() for k, v in p.items()})
+
+
+@pytest.mark.parametrize("mixed", [False, True])
+def test_steve_precision_plan(mixed):
+    """Which parts of STEVE.forward run in which type: under TRAIN.MIXED_PRECISION the token path and the
+    dVAE decoder / CNN encoder convolutions in bf16, the dVAE encoder and its Gumbel-softmax arithmetic in fp32; otherwise
+    fp32 throughout.  The module tree and parameter types are the reference's in both modes (fp32 masters)."""
+    from focus_amd.slowfast.config.defaults import get_cfg
+    from focus_amd.slowfast.models import MODEL_REGISTRY
+    cfg = get_cfg()
+    cfg.MODEL.MODEL_NAME = "STEVE"
+    cfg.TRAIN.MIXED_PRECISION = mixed
+    s = cfg.SLOTS
+    s.NUM_ITERS, s.NUM_SLOTS, s.CNN_HID_SIZE, s.SIZE, s.DIM, s.MLP_HID_SIZE, s.IMG_SIZE, s.VOCAB_SIZE = 2, 3, 8, 16, 16, 32, 16, 32
+    s.NUM_PREDICTOR_BLOCKS, s.NUM_PREDICTOR_HEADS = 1, 2
+    s.DECODER.DIM, s.DECODER.NUM_BLOCKS, s.DECODER.NUM_HEADS = 16, 1, 2
+    m = MODEL_REGISTRY.get("STEVE")(cfg)
+    assert m.compute_dtype == (torch.bfloat16 if mixed else torch.float32)
+    assert m.conv_dtype == (torch.bfloat16 if mixed else None)
+    assert m.fused_rows and m.channels_last
+    assert all(p.dtype == torch.float32 for p in m.parameters() if p.is_floating_point())     # (the causal mask is a bool parameter)
+    x = torch.rand(2, 3, 16, 16)
+    assert m._conv(m.dvae.encoder, x).dtype == torch.float32          # CPU tensors: no autocast, and the encoder never gets one
+    with pytest.raises(RuntimeError, match="no CPU fallback"):        # the model itself runs on the GPU only
+        m(torch.rand(1, 2, 3, 16, 16), 1.0, True)
