@@ -23,6 +23,7 @@ from .utils import Conv2dBlock, conv2d, gru_cell, gumbel_softmax, linear
 _PIPELINE_KV = os.environ.get("FOCUS_STEVE_PIPELINE", "0") != "0"
 _PIPELINE_JOIN = os.environ.get("FOCUS_STEVE_PIPELINE_JOIN", "event")      # "event" | "stream" (tools/steve_pipeline_check.py)
 _PIPELINE_AHEAD1 = os.environ.get("FOCUS_STEVE_PIPELINE_AHEAD1", "0") != "0"
+_PIPELINE_FENCE = os.environ.get("FOCUS_STEVE_PIPELINE_FENCE", "0") != "0"
 _SIDE_STREAMS = {}
 
 
@@ -174,6 +175,9 @@ class SlotAttentionVideo(nn.Module):
                         side.wait_stream(main)
                     with torch.cuda.stream(side):
                         ahead = keys_values(t + 1)
+                        if _PIPELINE_FENCE:   # experiment knob: a tiny kernel that reads k, v between the products and the join
+                            ops.cast(ahead[0].reshape(-1)[:8], torch.float32)
+                            ops.cast(ahead[1].reshape(-1)[:8], torch.float32)
                         ready = side.record_event()
             else:
                 k_t, v_t = keys_values(t)
